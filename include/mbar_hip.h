@@ -1,0 +1,152 @@
+/*
+ * mbar_hip.h -- C ABI of libmbar_hip.so: the MI355X (gfx950) MBAR solver hot path.
+ *
+ * This is the drop-in boundary for ONE path of choderalab/pymbar: the array math and solver
+ * loops of pymbar/mbar_solvers.py (reference paths below are relative to the pymbar source
+ * tree).  The reference is pure Python with no FFI; the binding a pymbar maintainer would add is
+ * a ctypes module exporting the same names as pymbar.mbar_solvers (see INTEGRATION.md and
+ * pymbar_amd/mbar_solvers.py, which is that module).
+ *
+ * Conventions
+ *   - plain C, no torch / no C++ types; every pointer is a host pointer to caller-owned memory
+ *     unless stated otherwise; all floating point is IEEE fp64; sizes are int64_t.
+ *   - return value 0 = MBAR_OK, negative = error; mbar_last_error() gives the message.
+ *   - a context owns the device-resident (K x N_local) reduced-potential matrix of ONE rank and
+ *     is not thread-safe (one context per caller thread).  One process drives one GPU.
+ *   - "p_nk" below is N_k * W_nk = N_k exp(f_k - u_kn) / sum_j N_j exp(f_j - u_jn): the
+ *     probability that sample n was drawn from state k (rows sum to 1; 0 for unsampled states).
+ *     With s_k = sum_n W_nk:  gradient g_k = N_k (s_k - 1) = psum_k - N_k   (mbar_solvers.py:284-292)
+ *                             SCI      f'_k = f_k - log s_k                   (mbar_solvers.py:231-242)
+ *                             Hessian  H = diag(psum) - gram                  (mbar_solvers.py:395-411)
+ *   - when a communicator is attached (mbar_ctx_comm_init / mbar_ctx_set_host_allreduce) every
+ *     reduced output (psum, sumlogden, gram, lognum) is the sum over all ranks' column shards.
+ */
+#ifndef MBAR_HIP_H
+#define MBAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mbar_ctx mbar_ctx;
+
+#define MBAR_OK 0
+#define MBAR_ERR_ARG (-1)      /* bad argument                                   */
+#define MBAR_ERR_HIP (-2)      /* a HIP runtime call failed                      */
+#define MBAR_ERR_NODEVICE (-3) /* no usable gfx950 device                        */
+#define MBAR_ERR_STATE (-4)    /* call sequence error (e.g. N_k not set)         */
+#define MBAR_ERR_COMM (-5)     /* RCCL / host all-reduce failure                 */
+#define MBAR_ERR_NUMERIC (-6)  /* non-finite intermediate where one is not legal */
+
+/* mbar_eval flags */
+#define MBAR_EVAL_GRAM 1u        /* also accumulate gram_ij = sum_n p_ni p_nj at f[0]          */
+#define MBAR_EVAL_USE_OFFSET 2u  /* sumlogden = sum_n (logden_n - d_n), d_n from mbar_ctx_set_objective_offset */
+
+/* kernel classes for mbar_ctx_timing */
+#define MBAR_TIMER_LSE 0    /* per-sample log-sum-exp + per-state sums (evaluation pass)   */
+#define MBAR_TIMER_GRAM 1   /* fp64 MFMA Gram / Hessian pass                              */
+#define MBAR_TIMER_REDUCE 2 /* partial-sum reductions                                      */
+#define MBAR_TIMER_OTHER 3  /* logW writer, robust per-state LSE, generator                */
+#define MBAR_TIMER_COUNT 4
+
+/* ---- library / device -------------------------------------------------------------------- */
+int mbar_version(void);
+/* Message of the last error on this context (ctx may be NULL: last error of a failed create). */
+const char* mbar_last_error(const mbar_ctx* ctx);
+int mbar_device_count(int* count);
+int mbar_device_info(int device, char* name, int name_len, int* compute_units, int64_t* total_mem_bytes);
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* Allocate a context on `device` for K states and N_local samples (this rank's column shard).
+ * Replaces the implicit "arrays live in host RAM" of the reference (mbar.py:243). */
+int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local);
+void mbar_ctx_destroy(mbar_ctx* ctx);
+int mbar_ctx_synchronize(mbar_ctx* ctx);
+/* Tuning / test knobs: "staging" (0 = LDS-DMA, 1 = through registers), "grid_blocks" (0 = auto),
+ * "force_generic" (1 = use the layout-agnostic fallback kernels), "check_finite" (default 1). */
+int mbar_ctx_set_option(mbar_ctx* ctx, const char* key, int64_t value);
+
+/* ---- data ---------------------------------------------------------------------------------- */
+/* Copy columns [col0_host, col0_host+ncols) of a C-contiguous host matrix u_host[K][ld_host]
+ * (the u_kn of mbar_solvers.py:174-203, row pitch ld_host) into device columns
+ * [col0_dev, col0_dev+ncols) of this rank's shard. */
+int mbar_ctx_upload_u(mbar_ctx* ctx, const double* u_host, int64_t ld_host, int64_t col0_host,
+                      int64_t ncols, int64_t col0_dev);
+int mbar_ctx_download_u(mbar_ctx* ctx, double* out, int64_t ld_out);
+/* Fill the shard on the device with the synthetic harmonic ladder of SURVEY.md 8(d):
+ * global sample n (n_global0 <= n < n_global0+N_local) belongs to the state given by the
+ * cumulative N_k_global, x_n ~ Normal(O_s, K_s^-1/2) from a counter-based RNG keyed by
+ * (seed, n), u[l][n] = K_l (x_n - O_l)^2 / 2.  Same data for any sharding of n. */
+int mbar_ctx_generate_harmonic(mbar_ctx* ctx, uint64_t seed, const double* O_k, const double* K_k,
+                               const int64_t* N_k_global, int64_t n_global0);
+/* GLOBAL sample counts per state as doubles (the float cast of mbar_solvers.py:792); zeros allowed:
+ * such states contribute nothing to denominators (mbar_solvers.py:238 with b=N_k). */
+int mbar_ctx_set_Nk(mbar_ctx* ctx, const double* N_k);
+
+/* ---- multi-GPU (one process per GPU; N sharded; one small all-reduce per pass) ------------- */
+int mbar_comm_unique_id(void* id128);                 /* rank 0: ncclGetUniqueId (128 bytes)     */
+int mbar_ctx_comm_init(mbar_ctx* ctx, const void* id128, int rank, int nranks); /* RCCL over xGMI */
+/* Fallback transport: fn(buf, count, op, user) must all-reduce `count` doubles in place
+ * (op 0 = sum, 1 = max) across ranks on the host. */
+typedef int (*mbar_allreduce_fn)(double* buf, int64_t count, int op, void* user);
+int mbar_ctx_set_host_allreduce(mbar_ctx* ctx, mbar_allreduce_fn fn, void* user, int rank, int nranks);
+
+/* ---- L1 evaluation (replaces mbar_solvers.py L1 functions) -------- */
+/* One fused sweep of u_kn for nf (1 or 2) free-energy vectors f[nf][K]:
+ *   psum[i][k]   = sum_n p_nk(f_i)              (K per f; 0 for states with N_k = 0)
+ *   sumlogden[i] = sum_n logden_n(f_i)  [ - d_n with MBAR_EVAL_USE_OFFSET ]
+ *   gram[K][K]   = sum_n p_ni p_nj at f_0       (only with MBAR_EVAL_GRAM; fp64 MFMA)
+ * logden_n(f_i) stays on the device in slot i.  Any output pointer may be NULL. */
+int mbar_eval(mbar_ctx* ctx, const double* f, int nf, unsigned flags, double* psum,
+              double* sumlogden, double* gram);
+/* d_n := logden_n(f0): the per-sample offset that replaces precondition_u_kn
+ * (mbar_solvers.py:697-707) for the objective; f0 = NULL clears it. */
+int mbar_ctx_set_objective_offset(mbar_ctx* ctx, const double* f0);
+/* lognum_k = log sum_n exp(-logden_n(f) - u_kn) for ALL K states (unsampled ones included),
+ * in log space like mbar_solvers.py:240-241; self_consistent_update = -lognum. */
+int mbar_lognum(mbar_ctx* ctx, const double* f, double* lognum);
+/* logden_n(f) for this rank's samples (mbar_solvers.py:238). */
+int mbar_logden(mbar_ctx* ctx, const double* f, double* out_n);
+/* log W_nk = f_k - u_kn - logden_n written as out[k][n] with row pitch ld_out (this rank's
+ * shard).  Memory-identical to the reference's F-ordered (N, K) result (mbar_solvers.py:439-449). */
+int mbar_logw(mbar_ctx* ctx, const double* f, double* out_kn, int64_t ld_out);
+/* gramW[K][K] = sum_n W_ni W_nj and wsum[k] = sum_n W_nk for ALL states (W^T W of
+ * mbar.py:1816,1849 and compute_overlap mbar.py:606); fp64 MFMA. */
+int mbar_gram_w(mbar_ctx* ctx, const double* f, double* gramW, double* wsum);
+
+/* ---- solver loops (replace adaptive(), mbar_solvers.py:510-667) ---------------------------- */
+typedef struct mbar_solve_result {
+    int64_t iterations; /* iterations executed                                   */
+    int64_t nr_iter;    /* ... of which Newton-Raphson steps were accepted       */
+    int64_t sci_iter;   /* ... of which self-consistent steps were accepted      */
+    int32_t success;    /* convergence test of mbar_solvers.py:636 met           */
+    int32_t reserved;
+    double max_delta;   /* last relative change                                  */
+    double gnorm;       /* |g| at the returned f                                 */
+    double wall_ms;     /* host wall time of the loop                            */
+} mbar_solve_result;
+
+/* Adaptive NR/SCI on the states with N_k > 0 (others are left untouched).  f_inout[K].
+ * history (may be NULL): rows of 4 doubles {choice(0 sci,1 nr), |g_sci|, |g_nr|, max_delta}.
+ * check_convergence = 0 runs exactly maxiter iterations (benchmarking). */
+int mbar_solve_adaptive(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxiter,
+                        int64_t min_sc_iter, double gamma, int check_convergence,
+                        double* history, int64_t history_rows, mbar_solve_result* result);
+/* Pure self-consistent iteration, device-resident (f update and convergence measure on the
+ * device; the host looks every `check_every` iterations). */
+int mbar_solve_sci(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxiter, int check_convergence,
+                   mbar_solve_result* result);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+/* Accumulated HIP-event time and launch count of one kernel class since the last reset. */
+int mbar_ctx_timing(mbar_ctx* ctx, int which, double* total_ms, int64_t* launches);
+int mbar_ctx_timing_reset(mbar_ctx* ctx);
+/* Peak-rate micro-benchmark of v_mfma_f64_16x16x4_f64 on this device (TFLOP/s). */
+int mbar_mfma_f64_peak(mbar_ctx* ctx, double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBAR_HIP_H */

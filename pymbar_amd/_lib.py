@@ -1,0 +1,128 @@
+"""ctypes binding of libmbar_hip.so (include/mbar_hip.h).  Thin: no numpy logic lives here.
+
+The product path has exactly one compute backend -- the gfx950 library.  If it cannot be loaded,
+or no MI355X is visible, every entry point raises :class:`BackendUnavailable`; there is no CPU
+fallback (the numpy oracle under ``oracle/`` is test infrastructure and is never imported here).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmbar_hip.so")
+
+MBAR_OK = 0
+EVAL_GRAM = 1
+EVAL_USE_OFFSET = 2
+TIMER_LSE, TIMER_GRAM, TIMER_REDUCE, TIMER_OTHER = 0, 1, 2, 3
+
+
+class BackendUnavailable(RuntimeError):
+    """libmbar_hip.so is missing / not loadable, or there is no gfx950 device."""
+
+
+class MbarHipError(RuntimeError):
+    """A libmbar_hip call returned an error code."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libmbar_hip error {code}: {message}")
+        self.code = code
+
+
+class SolveResult(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int64),
+        ("nr_iter", C.c_int64),
+        ("sci_iter", C.c_int64),
+        ("success", C.c_int32),
+        ("reserved", C.c_int32),
+        ("max_delta", C.c_double),
+        ("gnorm", C.c_double),
+        ("wall_ms", C.c_double),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_void_p)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); this table is also what tests/test_capi_symbols.py checks against
+# the declarations in include/mbar_hip.h
+SIGNATURES = {
+    "mbar_version": (C.c_int, []),
+    "mbar_last_error": (C.c_char_p, [_ctx]),
+    "mbar_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mbar_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), _ip]),
+    "mbar_ctx_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int64, C.c_int64]),
+    "mbar_ctx_destroy": (None, [_ctx]),
+    "mbar_ctx_synchronize": (C.c_int, [_ctx]),
+    "mbar_ctx_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int64]),
+    "mbar_ctx_upload_u": (C.c_int, [_ctx, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "mbar_ctx_download_u": (C.c_int, [_ctx, _dp, C.c_int64]),
+    "mbar_ctx_generate_harmonic": (C.c_int, [_ctx, C.c_uint64, _dp, _dp, _ip, C.c_int64]),
+    "mbar_ctx_set_Nk": (C.c_int, [_ctx, _dp]),
+    "mbar_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mbar_ctx_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "mbar_ctx_set_host_allreduce": (C.c_int, [_ctx, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]),
+    "mbar_eval": (C.c_int, [_ctx, _dp, C.c_int, C.c_uint, _dp, _dp, _dp]),
+    "mbar_ctx_set_objective_offset": (C.c_int, [_ctx, _dp]),
+    "mbar_lognum": (C.c_int, [_ctx, _dp, _dp]),
+    "mbar_logden": (C.c_int, [_ctx, _dp, _dp]),
+    "mbar_logw": (C.c_int, [_ctx, _dp, _dp, C.c_int64]),
+    "mbar_gram_w": (C.c_int, [_ctx, _dp, _dp, _dp]),
+    "mbar_solve_adaptive": (C.c_int, [_ctx, _dp, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_int,
+                                      _dp, C.c_int64, C.POINTER(SolveResult)]),
+    "mbar_solve_sci": (C.c_int, [_ctx, _dp, C.c_double, C.c_int64, C.c_int, C.POINTER(SolveResult)]),
+    "mbar_ctx_timing": (C.c_int, [_ctx, C.c_int, _dp, _ip]),
+    "mbar_ctx_timing_reset": (C.c_int, [_ctx]),
+    "mbar_mfma_f64_peak": (C.c_int, [_ctx, _dp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load libmbar_hip.so and attach signatures.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendUnavailable(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  pymbar_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the ROCm install
+        raise BackendUnavailable(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error(ctx=None):
+    msg = load_library().mbar_last_error(ctx)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(code, ctx=None):
+    if code != MBAR_OK:
+        raise MbarHipError(code, last_error(ctx))
+
+
+def device_count():
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.mbar_device_count(C.byref(n))
+    return n.value if rc == MBAR_OK else 0
+
+
+def require_device():
+    """Raise BackendUnavailable unless a gfx950 GPU can be used."""
+    if device_count() < 1:
+        raise BackendUnavailable(
+            "no HIP device visible: pymbar_amd computes only on an MI355X (gfx950) through "
+            "libmbar_hip.so and has no CPU fallback")

@@ -1,0 +1,1158 @@
+// Host side of libmbar_hip.so: the C ABI declared in include/mbar_hip.h.
+//
+// Owns the device-resident shard of u_kn, drives the gfx950 kernels of mbar_kernels.hip, performs the
+// (tiny) cross-rank all-reduce through RCCL, and runs the solver loops that the reference writes in
+// Python (adaptive(): pymbar/mbar_solvers.py:510-667).  No PyTorch, no BLAS/LAPACK: the K x K Newton
+// system is solved here by a Cholesky factorisation of the gauge-fixed Hessian with a Jacobi
+// pseudo-inverse fallback (minimum-norm semantics of numpy.linalg.lstsq, mbar_solvers.py:582-583).
+#include "../../include/mbar_hip.h"
+#include "mbar_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+using namespace mbar;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string& err) {
+        if (handle) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) {
+            err = std::string("dlopen(librccl) failed: ") + dlerror();
+            return false;
+        }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(handle, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(handle, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) {
+            err = "librccl is missing a required symbol";
+            return false;
+        }
+        return true;
+    }
+};
+RcclApi g_rccl;
+
+struct TimerPair {
+    hipEvent_t a, b;
+    int which;
+};
+
+}  // namespace
+
+struct mbar_ctx {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    int64_t K = 0, Kp = 0, N = 0, ld = 0;
+    bool have_Nk = false;
+    std::vector<double> Nk, lnNk;   // K
+    std::vector<int> sampled;       // indices with N_k > 0
+    // device
+    double* u = nullptr;
+    double* logden[3] = {nullptr, nullptr, nullptr};
+    double* dn = nullptr;           // objective offsets (or null)
+    double* small = nullptr;        // aden[2][Kp] | anum[Kp] | f[Kp] | Nk[Kp] | lnNk[Kp] | delta[...]
+    double* part = nullptr;         // per-wave partial records
+    size_t part_doubles = 0;
+    double* scratch = nullptr;      // level-1 reduction scratch
+    size_t scratch_doubles = 0;
+    double* red = nullptr;          // reduced outputs (contiguous: psum | obj | gram blocks)
+    size_t red_doubles = 0;
+    double* hred = nullptr;         // pinned host mirror of red
+    double* lognum_part = nullptr;
+    size_t lognum_part_doubles = 0;
+    double* f_hist = nullptr;       // SCI f history [batch][Kp]
+    // options
+    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1;
+    // comm
+    ncclComm_t comm = nullptr;
+    mbar_allreduce_fn host_reduce = nullptr;
+    void* host_reduce_user = nullptr;
+    int rank = 0, nranks = 1;
+    // timing
+    std::vector<TimerPair> pending;
+    std::vector<hipEvent_t> pool;
+    double t_ms[MBAR_TIMER_COUNT] = {0, 0, 0, 0};
+    int64_t t_n[MBAR_TIMER_COUNT] = {0, 0, 0, 0};
+    std::string error;
+};
+
+namespace {
+
+int fail(mbar_ctx* c, int code, const std::string& msg) {
+    if (c) c->error = msg;
+    g_last_error = msg;
+    return code;
+}
+#define HIPCHK(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(ctx, MBAR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+// ---- timing --------------------------------------------------------------------------------
+hipEvent_t get_event(mbar_ctx* c) {
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct ScopedTimer {
+    mbar_ctx* c;
+    TimerPair tp;
+    bool on;
+    ScopedTimer(mbar_ctx* c_, int which) : c(c_), on(false) {
+        tp.a = tp.b = nullptr;
+        if (!c->opt_timing) return;
+        tp.a = get_event(c);
+        tp.b = get_event(c);
+        tp.which = which;
+        if (tp.a && tp.b) {
+            on = hipEventRecord(tp.a, c->stream) == hipSuccess;
+        }
+    }
+    ~ScopedTimer() {
+        if (on) {
+            hipEventRecord(tp.b, c->stream);
+            c->pending.push_back(tp);
+        }
+    }
+};
+void flush_timers(mbar_ctx* c) {
+    for (auto& tp : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, tp.a, tp.b) == hipSuccess) {
+            c->t_ms[tp.which] += ms;
+            c->t_n[tp.which] += 1;
+        }
+        c->pool.push_back(tp.a);
+        c->pool.push_back(tp.b);
+    }
+    c->pending.clear();
+}
+int sync_stream(mbar_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    flush_timers(c);
+    return MBAR_OK;
+}
+
+// ---- device buffer helpers -------------------------------------------------------------------
+int ensure(mbar_ctx* c, double** p, size_t* have, size_t want) {
+    if (*have >= want) return MBAR_OK;
+    if (*p) HIPCHK(c, hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    HIPCHK(c, hipMalloc((void**)p, want * sizeof(double)));
+    *have = want;
+    return MBAR_OK;
+}
+// layout of c->small (doubles)
+inline double* d_aden(mbar_ctx* c) { return c->small; }                      // [2][Kp]
+inline double* d_anum(mbar_ctx* c) { return c->small + 2 * c->Kp; }          // [Kp]
+inline double* d_f(mbar_ctx* c) { return c->small + 3 * c->Kp; }             // [Kp]
+inline double* d_Nk(mbar_ctx* c) { return c->small + 4 * c->Kp; }            // [Kp]
+inline double* d_lnNk(mbar_ctx* c) { return c->small + 5 * c->Kp; }          // [Kp]
+inline double* d_delta(mbar_ctx* c) { return c->small + 6 * c->Kp; }         // [256]
+inline double* d_misc(mbar_ctx* c) { return c->small + 6 * c->Kp + 256; }    // [4*Kp]
+inline size_t small_doubles(int64_t Kp) { return (size_t)(10 * Kp + 256); }
+
+// ---- collectives -------------------------------------------------------------------------------
+int allreduce_dev(mbar_ctx* c, double* dev, int64_t count, int op) {
+    if (c->nranks <= 1) return MBAR_OK;
+    if (c->comm) {
+        ncclResult_t r = g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax,
+                                          c->comm, c->stream);
+        if (r != ncclSuccess)
+            return fail(c, MBAR_ERR_COMM, std::string("ncclAllReduce: ") +
+                                              (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+        return MBAR_OK;
+    }
+    if (c->host_reduce) {
+        std::vector<double> h((size_t)count);
+        HIPCHK(c, hipMemcpyAsync(h.data(), dev, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->host_reduce(h.data(), count, op, c->host_reduce_user) != 0)
+            return fail(c, MBAR_ERR_COMM, "host all-reduce callback failed");
+        HIPCHK(c, hipMemcpyAsync(dev, h.data(), count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MBAR_OK;
+    }
+    return fail(c, MBAR_ERR_STATE, "nranks > 1 but no communicator attached");
+}
+int allreduce_host(mbar_ctx* c, double* host, int64_t count, int op) {
+    if (c->nranks <= 1) return MBAR_OK;
+    if (c->host_reduce && !c->comm) {
+        if (c->host_reduce(host, count, op, c->host_reduce_user) != 0)
+            return fail(c, MBAR_ERR_COMM, "host all-reduce callback failed");
+        return MBAR_OK;
+    }
+    double* tmp = d_misc(c);
+    if (count > 4 * c->Kp) return fail(c, MBAR_ERR_ARG, "allreduce_host: buffer too large");
+    HIPCHK(c, hipMemcpyAsync(tmp, host, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = allreduce_dev(c, tmp, count, op);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(host, tmp, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MBAR_OK;
+}
+
+// ---- evaluation building blocks -----------------------------------------------------------------
+bool use_fast(const mbar_ctx* c) { return c->K <= MAX_FAST_K && !c->opt_force_generic; }
+
+// Host vector a[k] = f[k] + ln N_k (-inf where N_k = 0 or k >= K), written into out[rows].
+void build_aden(const mbar_ctx* c, const double* f, double* out, int64_t rows) {
+    const double ninf = -std::numeric_limits<double>::infinity();
+    for (int64_t k = 0; k < rows; ++k) out[k] = (k < c->K && c->Nk[k] > 0.0) ? f[k] + c->lnNk[k] : ninf;
+}
+
+// Evaluation pass for nf vectors whose aden already sits in d_aden (device, row pitch `rows`).
+// Results: red[0 .. nf*rows) = psum, red[nf*rows .. nf*rows+nf) = sum logden.  Not all-reduced.
+int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool use_offset) {
+    const double* dn = use_offset ? c->dn : nullptr;
+    if (use_fast(c)) {
+        const int nb = (int)(rows / 16);
+        const int64_t ntiles = (c->N + TS - 1) / TS;
+        LaunchGeom g = lse_geometry(nb, c->num_cu, ntiles, c->opt_grid);
+        const size_t rec = (size_t)nf * rows;
+        int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rec + nf));
+        if (rc) return rc;
+        rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * (rec + nf));
+        if (rc) return rc;
+        double* psum_part = c->part;
+        double* obj_part = c->part + (size_t)g.nwaves * rec;
+        {
+            ScopedTimer t(c, MBAR_TIMER_LSE);
+            HIPCHK(c, launch_lse(c->stream, nb, nf, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), ld0,
+                                 ld1, dn, psum_part, obj_part));
+        }
+        {
+            ScopedTimer t(c, MBAR_TIMER_REDUCE);
+            HIPCHK(c, launch_reduce(c->stream, psum_part, g.nwaves, (int64_t)rec, c->scratch, c->red));
+            HIPCHK(c, launch_reduce(c->stream, obj_part, g.nwaves, nf, c->scratch, c->red + rec));
+        }
+        return MBAR_OK;
+    }
+    // generic: one f at a time
+    for (int i = 0; i < nf; ++i) {
+        int blocks = 0, cblocks = 0;
+        int rc = ensure(c, &c->part, &c->part_doubles, (size_t)c->num_cu * 8 + (size_t)512 * c->K);
+        if (rc) return rc;
+        rc = ensure(c, &c->scratch, &c->scratch_doubles, (size_t)64 * (c->K + 8));
+        if (rc) return rc;
+        double* ldst = i == 0 ? ld0 : ld1;
+        if (!ldst) ldst = c->logden[i];  // the column-sum kernel needs logden even if the caller does not
+        {
+            ScopedTimer t(c, MBAR_TIMER_LSE);
+            HIPCHK(c, launch_lse_generic(c->stream, c->num_cu, c->u, c->ld, c->N, c->K, d_aden(c) + i * rows,
+                                         ldst, dn, c->part, &blocks));
+        }
+        {
+            ScopedTimer t(c, MBAR_TIMER_REDUCE);
+            HIPCHK(c, launch_reduce(c->stream, c->part, blocks, 1, c->scratch, c->red + nf * rows + i));
+        }
+        {
+            ScopedTimer t(c, MBAR_TIMER_LSE);
+            HIPCHK(c, launch_colsum_generic(c->stream, c->num_cu, c->u, c->ld, c->N, c->K, d_aden(c) + i * rows,
+                                            ldst, c->part, &cblocks));
+        }
+        {
+            ScopedTimer t(c, MBAR_TIMER_REDUCE);
+            HIPCHK(c, hipMemsetAsync(c->red + i * rows, 0, rows * sizeof(double), c->stream));
+            HIPCHK(c, launch_reduce(c->stream, c->part, cblocks, c->K, c->scratch, c->red + i * rows));
+        }
+    }
+    return MBAR_OK;
+}
+
+// Gram-pass geometry: list of (kind, row_i0, row_j0, nb) launches and where their blocks land.
+struct GramPlan {
+    struct Item { bool diag; int64_t ri, rj; int nb; int nblk; size_t off; };
+    std::vector<Item> items;
+    size_t total_blocks = 0;
+};
+GramPlan gram_plan(int64_t Kp) {
+    GramPlan p;
+    if (Kp <= 128) {
+        int nb = (int)(Kp / 16);
+        p.items.push_back({true, 0, 0, nb, nb * (nb + 1) / 2, 0});
+        p.total_blocks = (size_t)nb * (nb + 1) / 2;
+        return p;
+    }
+    const int P = (int)(Kp / PANEL);
+    size_t off = 0;
+    for (int a = 0; a < P; ++a) {
+        p.items.push_back({true, (int64_t)a * PANEL, (int64_t)a * PANEL, 4, 10, off});
+        off += 10;
+    }
+    for (int a = 0; a < P; ++a)
+        for (int b = a + 1; b < P; ++b) {
+            p.items.push_back({false, (int64_t)a * PANEL, (int64_t)b * PANEL, 4, 16, off});
+            off += 16;
+        }
+    p.total_blocks = off;
+    return p;
+}
+
+// Gram pass with operand exp(anum_k - u_kn - logden_n); anum (device) has Kp entries.
+// Results: gram blocks at red + red_off (plan order), per-state operand sums at red + ps_off (Kp).
+int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, size_t ps_off,
+             const GramPlan& plan) {
+    const int64_t ntiles = (c->N + TS - 1) / TS;
+    const bool dma = c->opt_staging == 0;
+    for (const auto& it : plan.items) {
+        const int tile_rows = it.diag ? it.nb * 16 : 128;
+        LaunchGeom g = gram_geometry(tile_rows, c->num_cu, ntiles, c->opt_grid);
+        const size_t rec = (size_t)it.nblk * 256;
+        const size_t prec = it.diag ? (size_t)it.nb * 16 : 0;
+        int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rec + prec));
+        if (rc) return rc;
+        rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * rec);
+        if (rc) return rc;
+        double* gp = c->part;
+        double* pp = c->part + (size_t)g.nwaves * rec;
+        {
+            ScopedTimer t(c, MBAR_TIMER_GRAM);
+            if (it.diag)
+                HIPCHK(c, launch_gram_diag(c->stream, it.nb, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, logden,
+                                           it.ri, gp, pp));
+            else
+                HIPCHK(c, launch_gram_off(c->stream, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
+                                          logden, it.ri, it.rj, gp));
+        }
+        {
+            ScopedTimer t(c, MBAR_TIMER_REDUCE);
+            HIPCHK(c, launch_reduce(c->stream, gp, g.nwaves, (int64_t)rec, c->scratch, c->red + red_off + it.off * 256));
+            if (it.diag)
+                HIPCHK(c, launch_reduce(c->stream, pp, g.nwaves, (int64_t)prec, c->scratch, c->red + ps_off + it.ri));
+        }
+    }
+    return MBAR_OK;
+}
+
+// Scatter reduced blocks (host copy) into a dense symmetric K x K matrix.
+void unpack_gram(const GramPlan& plan, const double* blocks, int64_t K, double* G) {
+    for (const auto& it : plan.items) {
+        int b = 0;
+        for (int I = 0; I < it.nb; ++I) {
+            for (int J = it.diag ? I : 0; J < it.nb; ++J) {
+                const double* blk = blocks + (it.off + b) * 256;
+                for (int r = 0; r < 16; ++r)
+                    for (int q = 0; q < 16; ++q) {
+                        const int64_t gi = it.ri + 16 * I + r, gj = it.rj + 16 * J + q;
+                        if (gi < K && gj < K) {
+                            const double v = blk[r * 16 + q];
+                            if (it.diag && I == J) {
+                                if (q >= r) { G[gi * K + gj] = v; G[gj * K + gi] = v; }
+                            } else {
+                                G[gi * K + gj] = v;
+                                G[gj * K + gi] = v;
+                            }
+                        }
+                    }
+                ++b;
+            }
+        }
+    }
+}
+
+int ensure_red(mbar_ctx* c, size_t want) {
+    if (c->red_doubles >= want) return MBAR_OK;
+    if (c->red) HIPCHK(c, hipFree(c->red));
+    if (c->hred) HIPCHK(c, hipHostFree(c->hred));
+    c->red = nullptr;
+    c->hred = nullptr;
+    c->red_doubles = 0;
+    HIPCHK(c, hipMalloc((void**)&c->red, want * sizeof(double)));
+    HIPCHK(c, hipHostMalloc((void**)&c->hred, want * sizeof(double), hipHostMallocDefault));
+    c->red_doubles = want;
+    return MBAR_OK;
+}
+
+// Row pitch of the aden / psum vectors: the padded state count (padded_K() only produces values
+// for which the fused kernel has an instantiation: 16..128 step 16, 192, 256).
+int64_t lse_rows(const mbar_ctx* c) { return c->Kp; }
+
+// Core of mbar_eval: f points to nf*K doubles on the host.  Leaves logden in ld0/ld1.
+int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0, double* ld1, double* psum,
+              double* sumlogden, double* gram) {
+    if (!c->have_Nk) return fail(c, MBAR_ERR_STATE, "mbar_ctx_set_Nk has not been called");
+    if (nf < 1 || nf > 2) return fail(c, MBAR_ERR_ARG, "nf must be 1 or 2");
+    const bool want_gram = (flags & MBAR_EVAL_GRAM) != 0;
+    const bool use_off = (flags & MBAR_EVAL_USE_OFFSET) != 0;
+    if (use_off && !c->dn) return fail(c, MBAR_ERR_STATE, "objective offset requested but not set");
+    const int64_t rows = lse_rows(c);
+    GramPlan plan;
+    if (want_gram) plan = gram_plan(c->Kp);
+    const size_t n_ps = (size_t)nf * rows, n_obj = nf;
+    const size_t off_gram = n_ps + n_obj, n_gram = plan.total_blocks * 256;
+    const size_t off_gps = off_gram + n_gram, n_gps = want_gram ? (size_t)c->Kp : 0;
+    const size_t total = off_gps + n_gps;
+    int rc = ensure_red(c, total);
+    if (rc) return rc;
+    // aden -> device
+    std::vector<double> h((size_t)nf * rows);
+    for (int i = 0; i < nf; ++i) build_aden(c, f + (size_t)i * c->K, h.data() + (size_t)i * rows, rows);
+    HIPCHK(c, hipMemcpyAsync(d_aden(c), h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // h goes out of scope below; tiny copy
+    rc = run_lse(c, nf, rows, ld0, ld1, use_off);
+    if (rc) return rc;
+    if (want_gram) {
+        // p-mode operand: anum = aden of f[0] (Kp entries)
+        std::vector<double> an((size_t)c->Kp);
+        build_aden(c, f, an.data(), c->Kp);
+        HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        rc = run_gram(c, d_anum(c), ld0, off_gram, off_gps, plan);
+        if (rc) return rc;
+    }
+    rc = allreduce_dev(c, c->red, (int64_t)total, 0);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    rc = sync_stream(c);
+    if (rc) return rc;
+    if (psum)
+        for (int i = 0; i < nf; ++i)
+            for (int64_t k = 0; k < c->K; ++k) psum[(size_t)i * c->K + k] = c->hred[(size_t)i * rows + k];
+    if (sumlogden)
+        for (int i = 0; i < nf; ++i) sumlogden[i] = c->hred[n_ps + i];
+    if (want_gram && gram) {
+        std::fill(gram, gram + (size_t)c->K * c->K, 0.0);
+        unpack_gram(plan, c->hred + off_gram, c->K, gram);
+    }
+    if (c->opt_check_finite) {
+        for (size_t i = 0; i < n_ps + n_obj; ++i)
+            if (!std::isfinite(c->hred[i])) {
+                // not fatal for the caller's control flow (the reference also propagates NaN), but flagged
+                c->error = "non-finite partial sum in evaluation pass";
+                break;
+            }
+    }
+    return MBAR_OK;
+}
+
+// ---- dense K x K helpers (host) ---------------------------------------------------------------
+// Cholesky solve of A x = b (A m x m SPD, row-major, destroyed).  Returns false on breakdown.
+bool chol_solve(std::vector<double>& A, std::vector<double>& b, int m) {
+    for (int j = 0; j < m; ++j) {
+        double d = A[(size_t)j * m + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * m + k] * A[(size_t)j * m + k];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        d = std::sqrt(d);
+        A[(size_t)j * m + j] = d;
+        for (int i = j + 1; i < m; ++i) {
+            double s = A[(size_t)i * m + j];
+            for (int k = 0; k < j; ++k) s -= A[(size_t)i * m + k] * A[(size_t)j * m + k];
+            A[(size_t)i * m + j] = s / d;
+        }
+    }
+    for (int i = 0; i < m; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= A[(size_t)i * m + k] * b[k];
+        b[i] = s / A[(size_t)i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < m; ++k) s -= A[(size_t)k * m + i] * b[k];
+        b[i] = s / A[(size_t)i * m + i];
+    }
+    for (int i = 0; i < m; ++i)
+        if (!std::isfinite(b[i])) return false;
+    return true;
+}
+
+// Cyclic Jacobi eigendecomposition of a symmetric matrix: A = V diag(w) V^T.
+void jacobi_eigh(std::vector<double> A, int m, std::vector<double>& w, std::vector<double>& V) {
+    V.assign((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i) V[(size_t)i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < m; ++i) {
+            diag += A[(size_t)i * m + i] * A[(size_t)i * m + i];
+            for (int j = i + 1; j < m; ++j) off += A[(size_t)i * m + j] * A[(size_t)i * m + j];
+        }
+        if (off <= 1e-30 * (diag + 1e-300)) break;
+        for (int p = 0; p < m - 1; ++p)
+            for (int q = p + 1; q < m; ++q) {
+                const double apq = A[(size_t)p * m + q];
+                if (apq == 0.0) continue;
+                const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < m; ++k) {
+                    const double akp = A[(size_t)k * m + p], akq = A[(size_t)k * m + q];
+                    A[(size_t)k * m + p] = cs * akp - sn * akq;
+                    A[(size_t)k * m + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < m; ++k) {
+                    const double apk = A[(size_t)p * m + k], aqk = A[(size_t)q * m + k];
+                    A[(size_t)p * m + k] = cs * apk - sn * aqk;
+                    A[(size_t)q * m + k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < m; ++k) {
+                    const double vkp = V[(size_t)k * m + p], vkq = V[(size_t)k * m + q];
+                    V[(size_t)k * m + p] = cs * vkp - sn * vkq;
+                    V[(size_t)k * m + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    w.resize(m);
+    for (int i = 0; i < m; ++i) w[i] = A[(size_t)i * m + i];
+}
+
+// Newton direction: x = H^+ g - (H^+ g)[0]  (mbar_solvers.py:582-583).  H is PSD with null vector 1;
+// fixing x[0] = 0 and solving the (m-1) x (m-1) SPD system gives the same vector.  If that system is
+// not positive definite (disconnected states), fall back to the minimum-norm pseudo-inverse solution.
+void newton_direction(const std::vector<double>& H, const std::vector<double>& g, int m, std::vector<double>& x) {
+    x.assign(m, 0.0);
+    if (m <= 1) return;
+    const int r = m - 1;
+    std::vector<double> A((size_t)r * r), b(r);
+    for (int i = 0; i < r; ++i) {
+        b[i] = g[i + 1];
+        for (int j = 0; j < r; ++j) A[(size_t)i * r + j] = H[(size_t)(i + 1) * m + (j + 1)];
+    }
+    if (chol_solve(A, b, r)) {
+        for (int i = 0; i < r; ++i) x[i + 1] = b[i];
+        return;
+    }
+    std::vector<double> w, V;
+    jacobi_eigh(H, m, w, V);
+    double wmax = 0.0;
+    for (double v : w) wmax = std::max(wmax, std::fabs(v));
+    const double cut = wmax * std::numeric_limits<double>::epsilon() * m;
+    std::vector<double> y(m, 0.0);
+    for (int e = 0; e < m; ++e) {
+        if (std::fabs(w[e]) <= cut) continue;
+        double proj = 0.0;
+        for (int k = 0; k < m; ++k) proj += V[(size_t)k * m + e] * g[k];
+        proj /= w[e];
+        for (int k = 0; k < m; ++k) y[k] += V[(size_t)k * m + e] * proj;
+    }
+    for (int k = 0; k < m; ++k) x[k] = y[k] - y[0];
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int mbar_version(void) { return 100; }
+
+const char* mbar_last_error(const mbar_ctx* ctx) { return ctx ? ctx->error.c_str() : g_last_error.c_str(); }
+
+int mbar_device_count(int* count) {
+    if (!count) return fail(nullptr, MBAR_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, MBAR_ERR_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return MBAR_OK;
+}
+
+int mbar_device_info(int device, char* name, int name_len, int* compute_units, int64_t* total_mem_bytes) {
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) return fail(nullptr, MBAR_ERR_NODEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (name && name_len > 0) {
+        std::snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (total_mem_bytes) *total_mem_bytes = (int64_t)p.totalGlobalMem;
+    return MBAR_OK;
+}
+
+int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
+    if (!out) return fail(nullptr, MBAR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (K < 1 || N_local < 1) return fail(nullptr, MBAR_ERR_ARG, "K and N_local must be >= 1");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return fail(nullptr, MBAR_ERR_NODEVICE, "no HIP device visible (libmbar_hip needs an MI355X / gfx950 GPU)");
+    if (device < 0 || device >= n) return fail(nullptr, MBAR_ERR_ARG, "device index out of range");
+    mbar_ctx* c = new mbar_ctx();
+    c->device = device;
+    c->K = K;
+    c->Kp = padded_K(K);
+    c->N = N_local;
+    c->ld = (N_local + TS - 1) / TS * TS;
+#define CRT(expr)                                                                                   \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            int rc_ = fail(nullptr, MBAR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+            mbar_ctx_destroy(c);                                                                    \
+            return rc_;                                                                             \
+        }                                                                                           \
+    } while (0)
+    CRT(hipSetDevice(device));
+    hipDeviceProp_t p;
+    CRT(hipGetDeviceProperties(&p, device));
+    c->num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        int rc = fail(nullptr, MBAR_ERR_NODEVICE, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+        mbar_ctx_destroy(c);
+        return rc;
+    }
+    CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t ubytes = (size_t)c->Kp * c->ld * sizeof(double);
+    CRT(hipMalloc((void**)&c->u, ubytes));
+    CRT(hipMemsetAsync(c->u, 0, ubytes, c->stream));
+    for (int i = 0; i < 3; ++i) {
+        CRT(hipMalloc((void**)&c->logden[i], (size_t)c->ld * sizeof(double)));
+        CRT(hipMemsetAsync(c->logden[i], 0, (size_t)c->ld * sizeof(double), c->stream));
+    }
+    CRT(hipMalloc((void**)&c->small, small_doubles(c->Kp) * sizeof(double)));
+    CRT(hipMemsetAsync(c->small, 0, small_doubles(c->Kp) * sizeof(double), c->stream));
+    CRT(hipStreamSynchronize(c->stream));
+#undef CRT
+    c->Nk.assign(K, 0.0);
+    c->lnNk.assign(K, 0.0);
+    *out = c;
+    return MBAR_OK;
+}
+
+void mbar_ctx_destroy(mbar_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    flush_timers(c);
+    for (auto e : c->pool) hipEventDestroy(e);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->u) hipFree(c->u);
+    for (int i = 0; i < 3; ++i)
+        if (c->logden[i]) hipFree(c->logden[i]);
+    if (c->dn) hipFree(c->dn);
+    if (c->small) hipFree(c->small);
+    if (c->part) hipFree(c->part);
+    if (c->scratch) hipFree(c->scratch);
+    if (c->red) hipFree(c->red);
+    if (c->hred) hipHostFree(c->hred);
+    if (c->lognum_part) hipFree(c->lognum_part);
+    if (c->f_hist) hipFree(c->f_hist);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mbar_ctx_synchronize(mbar_ctx* c) {
+    if (!c) return fail(nullptr, MBAR_ERR_ARG, "ctx is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return sync_stream(c);
+}
+
+int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    const std::string k(key);
+    if (k == "staging") c->opt_staging = value;
+    else if (k == "grid_blocks") c->opt_grid = value;
+    else if (k == "force_generic") c->opt_force_generic = value;
+    else if (k == "check_finite") c->opt_check_finite = value;
+    else if (k == "timing") c->opt_timing = value;
+    else if (k == "sci_batch") c->opt_sci_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
+    else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
+    return MBAR_OK;
+}
+
+int mbar_ctx_upload_u(mbar_ctx* c, const double* u_host, int64_t ld_host, int64_t col0_host, int64_t ncols,
+                      int64_t col0_dev) {
+    if (!c || !u_host) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (ncols < 0 || col0_dev < 0 || col0_dev + ncols > c->N || col0_host < 0 || col0_host + ncols > ld_host)
+        return fail(c, MBAR_ERR_ARG, "column range out of bounds");
+    if (ncols == 0) return MBAR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(c->u + col0_dev, (size_t)c->ld * sizeof(double), u_host + col0_host,
+                               (size_t)ld_host * sizeof(double), (size_t)ncols * sizeof(double), (size_t)c->K,
+                               hipMemcpyHostToDevice, c->stream));
+    return sync_stream(c);
+}
+
+int mbar_ctx_download_u(mbar_ctx* c, double* out, int64_t ld_out) {
+    if (!c || !out || ld_out < c->N) return fail(c, MBAR_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(double), c->u, (size_t)c->ld * sizeof(double),
+                               (size_t)c->N * sizeof(double), (size_t)c->K, hipMemcpyDeviceToHost, c->stream));
+    return sync_stream(c);
+}
+
+int mbar_ctx_generate_harmonic(mbar_ctx* c, uint64_t seed, const double* O_k, const double* K_k,
+                               const int64_t* N_k_global, int64_t n_global0) {
+    if (!c || !O_k || !K_k || !N_k_global) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int64_t> cum((size_t)c->K + 1, 0);
+    for (int64_t k = 0; k < c->K; ++k) cum[k + 1] = cum[k] + N_k_global[k];
+    if (n_global0 < 0 || n_global0 + c->N > cum[c->K]) return fail(c, MBAR_ERR_ARG, "shard exceeds sum(N_k)");
+    double* dO = d_misc(c);
+    double* dK = d_misc(c) + c->Kp;
+    int64_t* dC = reinterpret_cast<int64_t*>(d_misc(c) + 2 * c->Kp);
+    HIPCHK(c, hipMemcpyAsync(dO, O_k, c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dK, K_k, c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dC, cum.data(), (c->K + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    {
+        ScopedTimer t(c, MBAR_TIMER_OTHER);
+        HIPCHK(c, launch_generate_harmonic(c->stream, c->u, c->ld, c->N, c->K, seed, dO, dK, dC, n_global0));
+    }
+    return sync_stream(c);
+}
+
+int mbar_ctx_set_Nk(mbar_ctx* c, const double* N_k) {
+    if (!c || !N_k) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    c->sampled.clear();
+    for (int64_t k = 0; k < c->K; ++k) {
+        if (!(N_k[k] >= 0.0) || !std::isfinite(N_k[k])) return fail(c, MBAR_ERR_ARG, "N_k must be finite and >= 0");
+        c->Nk[k] = N_k[k];
+        c->lnNk[k] = N_k[k] > 0.0 ? std::log(N_k[k]) : -std::numeric_limits<double>::infinity();
+        if (N_k[k] > 0.0) c->sampled.push_back((int)k);
+    }
+    if (c->sampled.empty()) return fail(c, MBAR_ERR_ARG, "at least one state must have samples");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<double> h(2 * (size_t)c->Kp, 0.0);
+    for (int64_t k = 0; k < c->Kp; ++k) {
+        h[k] = k < c->K ? c->Nk[k] : 0.0;
+        h[c->Kp + k] = k < c->K ? c->lnNk[k] : -std::numeric_limits<double>::infinity();
+    }
+    HIPCHK(c, hipMemcpyAsync(d_Nk(c), h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_Nk = true;
+    return MBAR_OK;
+}
+
+int mbar_comm_unique_id(void* id128) {
+    if (!id128) return fail(nullptr, MBAR_ERR_ARG, "id128 is NULL");
+    std::string err;
+    if (!g_rccl.load(err)) return fail(nullptr, MBAR_ERR_COMM, err);
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, MBAR_ERR_COMM, "ncclGetUniqueId failed");
+    std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return MBAR_OK;
+}
+
+int mbar_ctx_comm_init(mbar_ctx* c, const void* id128, int rank, int nranks) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MBAR_ERR_ARG, "bad argument");
+    std::string err;
+    if (!g_rccl.load(err)) return fail(c, MBAR_ERR_COMM, err);
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, id, rank);
+    if (r != ncclSuccess)
+        return fail(c, MBAR_ERR_COMM, std::string("ncclCommInitRank: ") +
+                                          (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    c->comm = comm;
+    c->rank = rank;
+    c->nranks = nranks;
+    return MBAR_OK;
+}
+
+int mbar_ctx_set_host_allreduce(mbar_ctx* c, mbar_allreduce_fn fn, void* user, int rank, int nranks) {
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks || (!fn && nranks > 1)) return fail(c, MBAR_ERR_ARG, "bad argument");
+    c->host_reduce = fn;
+    c->host_reduce_user = user;
+    c->rank = rank;
+    c->nranks = nranks;
+    return MBAR_OK;
+}
+
+int mbar_eval(mbar_ctx* c, const double* f, int nf, unsigned flags, double* psum, double* sumlogden, double* gram) {
+    if (!c || !f) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    return eval_core(c, f, nf, flags, c->logden[0], c->logden[1], psum, sumlogden, gram);
+}
+
+int mbar_ctx_set_objective_offset(mbar_ctx* c, const double* f0) {
+    if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!f0) {
+        if (c->dn) HIPCHK(c, hipFree(c->dn));
+        c->dn = nullptr;
+        return MBAR_OK;
+    }
+    double* tmp = nullptr;
+    if (!c->dn) {
+        HIPCHK(c, hipMalloc((void**)&tmp, (size_t)c->ld * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(tmp, 0, (size_t)c->ld * sizeof(double), c->stream));
+    } else {
+        tmp = c->dn;
+        c->dn = nullptr;
+    }
+    int rc = eval_core(c, f0, 1, 0, tmp, nullptr, nullptr, nullptr, nullptr);
+    c->dn = tmp;
+    return rc;
+}
+
+int mbar_logden(mbar_ctx* c, const double* f, double* out_n) {
+    if (!c || !f || !out_n) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_n, c->logden[0], (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return sync_stream(c);
+}
+
+int mbar_lognum(mbar_ctx* c, const double* f, double* lognum) {
+    if (!c || !f || !lognum) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const int64_t nch = lognum_chunks(c->N);
+    rc = ensure(c, &c->lognum_part, &c->lognum_part_doubles, (size_t)2 * c->K * nch + 2 * c->K);
+    if (rc) return rc;
+    double* pmax = c->lognum_part;
+    double* psum = pmax + (size_t)c->K * nch;
+    double* omax = psum + (size_t)c->K * nch;
+    double* osum = omax + c->K;
+    HIPCHK(c, hipMemsetAsync(d_anum(c), 0, (size_t)c->Kp * sizeof(double), c->stream));  // anum = 0
+    {
+        ScopedTimer t(c, MBAR_TIMER_OTHER);
+        HIPCHK(c, launch_lognum(c->stream, c->u, c->ld, c->N, c->K, d_anum(c), c->logden[0], pmax, psum, nch));
+        HIPCHK(c, launch_lognum_merge(c->stream, pmax, psum, c->K, nch, omax, osum));
+    }
+    std::vector<double> hm(c->K), hs(c->K);
+    HIPCHK(c, hipMemcpyAsync(hm.data(), omax, c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs.data(), osum, c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    rc = sync_stream(c);
+    if (rc) return rc;
+    if (c->nranks > 1) {
+        std::vector<double> gm = hm;
+        for (int64_t k0 = 0; k0 < c->K; k0 += 4 * c->Kp) {
+            const int64_t cnt = std::min<int64_t>(4 * c->Kp, c->K - k0);
+            rc = allreduce_host(c, gm.data() + k0, cnt, 1);
+            if (rc) return rc;
+        }
+        for (int64_t k = 0; k < c->K; ++k) hs[k] = (hm[k] == gm[k]) ? hs[k] : hs[k] * std::exp(hm[k] - gm[k]);
+        for (int64_t k0 = 0; k0 < c->K; k0 += 4 * c->Kp) {
+            const int64_t cnt = std::min<int64_t>(4 * c->Kp, c->K - k0);
+            rc = allreduce_host(c, hs.data() + k0, cnt, 0);
+            if (rc) return rc;
+        }
+        hm = gm;
+    }
+    for (int64_t k = 0; k < c->K; ++k) lognum[k] = hm[k] + std::log(hs[k]);
+    return MBAR_OK;
+}
+
+int mbar_logw(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out) {
+    if (!c || !f || !out_kn || ld_out < c->N) return fail(c, MBAR_ERR_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    // stream the result through a device staging buffer in row blocks to bound extra memory
+    const int64_t rows_per = std::max<int64_t>(1, std::min<int64_t>(c->K, (int64_t)((256ull << 20) / ((size_t)c->ld * 8))));
+    double* stage = nullptr;
+    HIPCHK(c, hipMalloc((void**)&stage, (size_t)rows_per * c->ld * sizeof(double)));
+    HIPCHK(c, hipMemcpyAsync(d_f(c), f, c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int64_t k0 = 0; k0 < c->K; k0 += rows_per) {
+        const int64_t nr = std::min(rows_per, c->K - k0);
+        {
+            ScopedTimer t(c, MBAR_TIMER_OTHER);
+            hipError_t e = launch_logw(c->stream, c->u + k0 * c->ld, c->ld, c->N, nr, d_f(c) + k0, c->logden[0], stage, c->ld);
+            if (e != hipSuccess) { hipFree(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
+        }
+        hipError_t e = hipMemcpy2DAsync(out_kn + k0 * ld_out, (size_t)ld_out * sizeof(double), stage,
+                                        (size_t)c->ld * sizeof(double), (size_t)c->N * sizeof(double), (size_t)nr,
+                                        hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
+    }
+    flush_timers(c);
+    HIPCHK(c, hipFree(stage));
+    return MBAR_OK;
+}
+
+int mbar_gram_w(mbar_ctx* c, const double* f, double* gramW, double* wsum) {
+    if (!c || !f) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    GramPlan plan = gram_plan(c->Kp);
+    const size_t n_gram = plan.total_blocks * 256, total = n_gram + (size_t)c->Kp;
+    rc = ensure_red(c, total);
+    if (rc) return rc;
+    std::vector<double> an((size_t)c->Kp, -std::numeric_limits<double>::infinity());
+    for (int64_t k = 0; k < c->K; ++k) an[k] = f[k];
+    HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = run_gram(c, d_anum(c), c->logden[0], 0, n_gram, plan);
+    if (rc) return rc;
+    rc = allreduce_dev(c, c->red, (int64_t)total, 0);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    rc = sync_stream(c);
+    if (rc) return rc;
+    if (gramW) {
+        std::fill(gramW, gramW + (size_t)c->K * c->K, 0.0);
+        unpack_gram(plan, c->hred, c->K, gramW);
+    }
+    if (wsum)
+        for (int64_t k = 0; k < c->K; ++k) wsum[k] = c->hred[n_gram + k];
+    return MBAR_OK;
+}
+
+int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, int64_t min_sc_iter, double gamma,
+                        int check_convergence, double* history, int64_t history_rows, mbar_solve_result* result) {
+    if (!c || !f_inout) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (!c->have_Nk) return fail(c, MBAR_ERR_STATE, "mbar_ctx_set_Nk has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = now_ms();
+    const int64_t K = c->K;
+    const int m = (int)c->sampled.size();
+    const int first = c->sampled[0];
+    std::vector<double> f(f_inout, f_inout + K), f_old(K), cand(2 * (size_t)K), psum(K), psum2(2 * (size_t)K);
+    std::vector<double> gram((size_t)K * K), H((size_t)m * m), g(m), x;
+    mbar_solve_result res;
+    std::memset(&res, 0, sizeof(res));
+    int cur = 0;  // logden slot of the current f
+    // initial gradient (mbar_solvers.py:570)
+    int rc = eval_core(c, f.data(), 1, 0, c->logden[cur], nullptr, psum.data(), nullptr, nullptr);
+    if (rc) return rc;
+    double max_delta = std::numeric_limits<double>::quiet_NaN();
+    bool done = false;
+    const GramPlan plan = gram_plan(c->Kp);
+    for (int64_t it = 0; it < maxiter && !done; ++it) {
+        // ---- pass A: Gram at f with the known logden -> Hessian (mbar_solvers.py:581) ----
+        {
+            const size_t n_gram = plan.total_blocks * 256, total = n_gram + (size_t)c->Kp;
+            rc = ensure_red(c, total);
+            if (rc) return rc;
+            std::vector<double> an((size_t)c->Kp);
+            build_aden(c, f.data(), an.data(), c->Kp);
+            HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            rc = run_gram(c, d_anum(c), c->logden[cur], 0, n_gram, plan);
+            if (rc) return rc;
+            rc = allreduce_dev(c, c->red, (int64_t)total, 0);
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            rc = sync_stream(c);
+            if (rc) return rc;
+            unpack_gram(plan, c->hred, K, gram.data());
+        }
+        for (int i = 0; i < m; ++i) {
+            const int ki = c->sampled[i];
+            g[i] = psum[ki] - c->Nk[ki];
+            for (int j = 0; j < m; ++j) H[(size_t)i * m + j] = -gram[(size_t)ki * K + c->sampled[j]];
+            H[(size_t)i * m + i] += psum[ki];
+        }
+        newton_direction(H, g, m, x);  // :582-583
+        double* f_sci = cand.data();
+        double* f_nr = cand.data() + K;
+        std::copy(f.begin(), f.end(), f_sci);
+        std::copy(f.begin(), f.end(), f_nr);
+        for (int i = 0; i < m; ++i) {
+            const int k = c->sampled[i];
+            f_nr[k] = f[k] - gamma * x[i];                         // :584
+            f_sci[k] = f[k] - std::log(psum[k] / c->Nk[k]);        // :587 via s_k
+        }
+        const double shift = f_sci[first];
+        for (int i = 0; i < m; ++i) f_sci[c->sampled[i]] -= shift;  // :588
+        // ---- pass B: both candidates in one sweep (:589-594) ----
+        const int sA = (cur + 1) % 3, sB = (cur + 2) % 3;
+        rc = eval_core(c, cand.data(), 2, 0, c->logden[sA], c->logden[sB], psum2.data(), nullptr, nullptr);
+        if (rc) return rc;
+        double gn_sci = 0.0, gn_nr = 0.0;
+        for (int i = 0; i < m; ++i) {
+            const int k = c->sampled[i];
+            const double a = psum2[k] - c->Nk[k], b = psum2[K + k] - c->Nk[k];
+            gn_sci += a * a;
+            gn_nr += b * b;
+        }
+        f_old = f;
+        int choice;
+        if (gn_sci < gn_nr || res.sci_iter < min_sc_iter) {  // :607
+            std::copy(f_sci, f_sci + K, f.begin());
+            std::copy(psum2.begin(), psum2.begin() + K, psum.begin());
+            cur = sA;
+            res.sci_iter++;
+            choice = 0;
+        } else {
+            std::copy(f_nr, f_nr + K, f.begin());
+            std::copy(psum2.begin() + K, psum2.end(), psum.begin());
+            cur = sB;
+            res.nr_iter++;
+            choice = 1;
+        }
+        // convergence measures on the sampled states except the first (:627-633)
+        const double small = std::min(1e-8, tol);
+        max_delta = 0.0;
+        double max_diff = 0.0;
+        bool nan_seen = false;
+        for (int i = 1; i < m; ++i) {
+            const int k = c->sampled[i];
+            const double div = std::fabs(f[k]) < small ? 1.0 : std::fabs(f[k]);
+            const double d1 = std::fabs(f[k] - f_old[k]) / div, d2 = std::fabs(f_sci[k] - f_nr[k]) / div;
+            if (std::isnan(d1)) nan_seen = true;
+            max_delta = std::max(max_delta, d1);
+            max_diff = std::max(max_diff, d2);
+        }
+        if (nan_seen) max_delta = std::numeric_limits<double>::quiet_NaN();
+        res.iterations = it + 1;
+        if (history && it < history_rows) {
+            history[4 * it + 0] = choice;
+            history[4 * it + 1] = std::sqrt(gn_sci);
+            history[4 * it + 2] = std::sqrt(gn_nr);
+            history[4 * it + 3] = max_delta;
+        }
+        if (check_convergence && (std::isnan(max_delta) || (max_delta < tol && max_diff < std::sqrt(tol)))) {  // :636
+            res.success = 1;
+            done = true;
+        }
+    }
+    double gn = 0.0;
+    for (int i = 0; i < m; ++i) {
+        const int k = c->sampled[i];
+        gn += (psum[k] - c->Nk[k]) * (psum[k] - c->Nk[k]);
+    }
+    res.gnorm = std::sqrt(gn);
+    res.max_delta = max_delta;
+    res.wall_ms = now_ms() - t0;
+    std::copy(f.begin(), f.end(), f_inout);
+    if (result) *result = res;
+    return MBAR_OK;
+}
+
+int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, int check_convergence,
+                   mbar_solve_result* result) {
+    if (!c || !f_inout) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (!c->have_Nk) return fail(c, MBAR_ERR_STATE, "mbar_ctx_set_Nk has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = now_ms();
+    const int64_t K = c->K, Kp = c->Kp;
+    const int first = c->sampled[0];
+    mbar_solve_result res;
+    std::memset(&res, 0, sizeof(res));
+    const int64_t rows = lse_rows(c);
+    const int64_t batch = c->opt_sci_batch;
+    if (!c->f_hist) HIPCHK(c, hipMalloc((void**)&c->f_hist, (size_t)256 * Kp * sizeof(double)));
+    int rc = ensure_red(c, (size_t)rows + 8);
+    if (rc) return rc;
+    // initial f and aden on the device
+    std::vector<double> hf((size_t)Kp, 0.0), ha((size_t)std::max(rows, Kp));
+    for (int64_t k = 0; k < K; ++k) hf[k] = f_inout[k];
+    build_aden(c, f_inout, ha.data(), std::max(rows, Kp));
+    HIPCHK(c, hipMemcpyAsync(d_f(c), hf.data(), Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_aden(c), ha.data(), std::max(rows, Kp) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> hdelta(batch);
+    int64_t it = 0;
+    bool done = false;
+    double last_delta = std::numeric_limits<double>::quiet_NaN();
+    while (it < maxiter && !done) {
+        const int64_t nb = std::min(batch, maxiter - it);
+        for (int64_t b = 0; b < nb; ++b) {
+            rc = run_lse(c, 1, rows, nullptr, nullptr, false);
+            if (rc) return rc;
+            rc = allreduce_dev(c, c->red, rows, 0);
+            if (rc) return rc;
+            HIPCHK(c, launch_sci_update(c->stream, c->red, d_Nk(c), d_lnNk(c), K, std::max(rows, Kp), first, tol,
+                                        d_f(c), d_aden(c), d_delta(c) + b));
+            HIPCHK(c, hipMemcpyAsync(c->f_hist + (size_t)b * Kp, d_f(c), Kp * sizeof(double), hipMemcpyDeviceToDevice,
+                                     c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(hdelta.data(), d_delta(c), nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        rc = sync_stream(c);
+        if (rc) return rc;
+        int64_t stop = nb;  // index within the batch of the accepted iterate
+        if (check_convergence)
+            for (int64_t b = 0; b < nb; ++b)
+                if (std::isnan(hdelta[b]) || hdelta[b] < tol) {
+                    stop = b + 1;
+                    done = true;
+                    res.success = 1;
+                    break;
+                }
+        it += stop;
+        last_delta = hdelta[stop - 1];
+        HIPCHK(c, hipMemcpyAsync(hf.data(), c->f_hist + (size_t)(stop - 1) * Kp, Kp * sizeof(double),
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    for (int64_t k = 0; k < K; ++k)
+        if (c->Nk[k] > 0.0) f_inout[k] = hf[k];
+    res.iterations = it;
+    res.sci_iter = it;
+    res.max_delta = last_delta;
+    res.wall_ms = now_ms() - t0;
+    if (result) *result = res;
+    return MBAR_OK;
+}
+
+int mbar_ctx_timing(mbar_ctx* c, int which, double* total_ms, int64_t* launches) {
+    if (!c || which < 0 || which >= MBAR_TIMER_COUNT) return fail(c, MBAR_ERR_ARG, "bad argument");
+    if (total_ms) *total_ms = c->t_ms[which];
+    if (launches) *launches = c->t_n[which];
+    return MBAR_OK;
+}
+
+int mbar_ctx_timing_reset(mbar_ctx* c) {
+    if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    for (int i = 0; i < MBAR_TIMER_COUNT; ++i) {
+        c->t_ms[i] = 0.0;
+        c->t_n[i] = 0;
+    }
+    return MBAR_OK;
+}
+
+int mbar_mfma_f64_peak(mbar_ctx* c, double* tflops) {
+    if (!c || !tflops) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int blocks = c->num_cu * 2, iters = 20000;
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    HIPCHK(c, launch_mfma_peak(c->stream, blocks, 100, d_misc(c)));  // warm-up
+    HIPCHK(c, hipEventRecord(a, c->stream));
+    HIPCHK(c, launch_mfma_peak(c->stream, blocks, iters, d_misc(c)));
+    HIPCHK(c, hipEventRecord(b, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    const double flop = (double)blocks * 4 /*waves*/ * iters * 4 /*mfma*/ * 2048.0;
+    *tflops = flop / (ms * 1e-3) * 1e-12;
+    return MBAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Internal interface between the host C-ABI (mbar_capi.cpp) and the gfx950 kernels
+// (mbar_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mbar {
+
+constexpr int TS = 16;       // samples per wave tile (one 128-byte line per state row)
+constexpr int GROUPS = 4;    // 4-sample MFMA groups per tile
+constexpr int MAX_FAST_K = 256;   // fast (LDS-staged, MFMA-layout) kernels handle K <= 256
+constexpr int PANEL = 64;    // Gram panel width (states) when K > 128
+
+// Rounded-up state count of the device matrix.
+inline int64_t padded_K(int64_t K) {
+    if (K <= 128) return (K + 15) / 16 * 16;
+    return (K + PANEL - 1) / PANEL * PANEL;
+}
+// Supported block counts (16 states each) of the fused evaluation kernel.
+inline int lse_nb_for(int64_t Kp) {
+    static const int nbs[] = {1, 2, 3, 4, 5, 6, 7, 8, 12, 16};
+    int need = (int)(Kp / 16);
+    for (int nb : nbs) if (nb >= need) return nb;
+    return 0;
+}
+
+struct LaunchGeom {
+    int blocks;       // grid size
+    int waves;        // waves per block
+    int nwaves;       // blocks * waves = number of per-wave partial records
+    size_t lds_bytes;
+};
+
+// ---- evaluation pass -------------------------------------------------------------------------
+// psum_part: [nwaves][nf][16*nb], obj_part: [nwaves][nf]; logden0/1 may be null (not stored).
+LaunchGeom lse_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
+hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g,
+                      const double* u, int64_t ld, int64_t N, const double* aden /*[nf][16nb]*/,
+                      double* logden0, double* logden1, const double* dn,
+                      double* psum_part, double* obj_part);
+
+// ---- Gram pass (known logden) ------------------------------------------------------------------
+// Diagonal panel: states [row0, row0+16nb) against themselves, nblk = nb(nb+1)/2 blocks, block b
+// enumerates (I,J) with I<=J in row-major order.  Off-diagonal panel pair: nbi x nbj blocks.
+// gram_part: [nwaves][nblk][256], psum_part: [nwaves][16*nb] (diag only; may be null for off-diag).
+LaunchGeom gram_geometry(int tile_rows, int num_cu, int64_t ntiles, int64_t grid_override);
+hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u,
+                            int64_t ld, int64_t N, const double* anum /*indexed from row0*/,
+                            const double* logden, int64_t row0, double* gram_part, double* psum_part);
+hipError_t launch_gram_off(hipStream_t s, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
+                           int64_t N, const double* anum_i, const double* anum_j, const double* logden,
+                           int64_t row_i0, int64_t row_j0, double* gram_part);
+
+// ---- layout-agnostic fallbacks (any K) ---------------------------------------------------------
+hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
+                              const double* aden, double* logden, const double* dn,
+                              double* obj_part /*[blocks]*/, int* blocks_out);
+hipError_t launch_colsum_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
+                                 const double* anum, const double* logden,
+                                 double* psum_part /*[blocks_x][K]*/, int* blocks_out);
+
+// ---- reductions / small kernels ----------------------------------------------------------------
+// out[i] = sum_p part[p*count + i]; scratch must hold ceil(nparts/32)*count doubles.
+hipError_t launch_reduce(hipStream_t s, const double* part, int64_t nparts, int64_t count,
+                         double* scratch, double* out);
+// robust per-state log-sum-exp over n of (anum_k - u_kn - logden_n): partial (max,sum) per chunk
+hipError_t launch_lognum(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K,
+                         const double* anum, const double* logden,
+                         double* pmax /*[K][nchunks]*/, double* psum /*[K][nchunks]*/, int64_t nchunks);
+int64_t lognum_chunks(int64_t N);
+hipError_t launch_lognum_merge(hipStream_t s, const double* pmax, const double* psum, int64_t K,
+                               int64_t nchunks, double* out_max /*[K]*/, double* out_sum /*[K]*/);
+hipError_t launch_logw(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K,
+                       const double* f, const double* logden, double* out, int64_t ld_out);
+hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_t N, int64_t K,
+                                    uint64_t seed, const double* O_k, const double* K_k,
+                                    const int64_t* cumN /*[K+1]*/, int64_t n_global0);
+// device-resident SCI step: f' = f - log(psum/N_k) on sampled states, gauge, aden' = f' + ln N_k
+hipError_t launch_sci_update(hipStream_t s, const double* psum, const double* Nk, const double* lnNk,
+                             int64_t K, int64_t Kp, int first_state, double tol, double* f, double* aden,
+                             double* delta_out);
+hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink);
+
+}  // namespace mbar

@@ -1,0 +1,986 @@
+// gfx950 (CDNA4 / MI355X) kernels of the MBAR solver hot path.
+//
+// Data layout.  u is the (Kp x ld) row-major fp64 matrix of reduced potentials u[k][n] of this
+// rank's column shard (Kp = padded state count, ld = N rounded up to 16; padding is zero-filled and
+// masked).  The fast kernels process "wave tiles" of 16 consecutive samples x all states: one
+// 128-byte line per state row, staged into a wave-private LDS buffer by LDS-DMA
+// (global_load_lds_dwordx4, 8 rows per instruction).  Inside LDS, row k is stored rotated by
+// (k & 14) doubles so that the MFMA-operand read -- lane l holds state 16*I + (l & 15) of sample
+// 4*g + (l >> 4), the A/B layout of v_mfma_f64_16x16x4_f64 -- is a conflict-free ds_read_b64.
+// In that layout
+//   * the per-sample reduction over states (log-sum-exp denominator, mbar_solvers.py:238) is an
+//     in-register reduction over the block index I plus a 16-lane DPP butterfly,
+//   * the per-state reduction over samples (numerator sums, mbar_solvers.py:240-241) is a plain
+//     per-lane accumulation, and
+//   * the K x K contraction W^T W of the Hessian (mbar_solvers.py:407) is
+//     acc[I][J] += mfma_f64_16x16x4(p[I], p[J]) with no data movement at all.
+// Waves never synchronise with each other; every wave streams its own tiles (tile index strided by
+// the number of waves in the grid) with a one-tile DMA prefetch.
+#include "mbar_internal.h"
+
+#include <math.h>
+
+namespace mbar {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// All-reduce over the 16 lanes of a DPP row (= the 16 states a sample has in one register):
+// quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_mirror.
+__device__ __forceinline__ double row16_max(double x) {
+    x = fmax(x, dpp_move<0xB1>(x));
+    x = fmax(x, dpp_move<0x4E>(x));
+    x = fmax(x, dpp_move<0x141>(x));
+    x = fmax(x, dpp_move<0x140>(x));
+    return x;
+}
+__device__ __forceinline__ double row16_sum(double x) {
+    x += dpp_move<0xB1>(x);
+    x += dpp_move<0x4E>(x);
+    x += dpp_move<0x141>(x);
+    x += dpp_move<0x140>(x);
+    return x;
+}
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x = fmax(x, __shfl_xor(x, m));
+    return x;
+}
+
+// Stage one wave tile (ROWS state rows x 16 samples starting at column n0) into `dst`.
+// DMA instruction j fills LDS bytes [1024 j, 1024 j + 1024): lane l -> row 8j + (l >> 3),
+// positions 2(l & 7), 2(l & 7)+1 of that row, which hold samples (pos - (row & 14)) & 15.
+// rowmap(tile_row) gives the global row.
+template <int ROWS, bool DMA, typename RowMap>
+__device__ __forceinline__ void stage_tile(const double* __restrict__ u, int64_t ld, int64_t n0,
+                                           char* dst, int lane, RowMap rowmap) {
+    constexpr int NDMA = ROWS / 8;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+        const int tr = 8 * j + (lane >> 3);
+        const int pos = 2 * (lane & 7);
+        const int smp = (pos - (tr & 14)) & 15;
+        const double* src = u + rowmap(tr) * ld + n0 + smp;
+        if constexpr (DMA) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024),
+                                             16, 0, 0);
+        } else {
+            const double2 v = *reinterpret_cast<const double2*>(src);
+            *reinterpret_cast<double2*>(dst + j * 1024 + lane * 16) = v;
+        }
+    }
+}
+
+// Stage the 16 per-sample values v[n0 .. n0+16) (128 bytes) behind a tile: lanes 0..7 move 16 bytes each.
+// Going through LDS-DMA (instead of an ordinary VGPR load) keeps hipcc from draining the whole DMA
+// prefetch with an s_waitcnt vmcnt(0) at the first use of the loaded register.
+template <bool DMA>
+__device__ __forceinline__ void stage_vec16(const double* __restrict__ v, int64_t n0, char* dst, int lane) {
+    if (lane < 8) {
+        const double* src = v + n0 + 2 * lane;
+        if constexpr (DMA) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else {
+            *reinterpret_cast<double2*>(dst + lane * 16) = *reinterpret_cast<const double2*>(src);
+        }
+    }
+}
+
+// Pin a loaded value into its register *now*: the compiler must place the s_waitcnt for the load here
+// (before any DMA is in flight) instead of a conservative vmcnt(0) at the first use inside the loop.
+__device__ __forceinline__ void settle(double& x) { asm volatile("" : "+v"(x)); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct RowIdentity {
+    int64_t row0;
+    __device__ __forceinline__ int64_t operator()(int tr) const { return row0 + tr; }
+};
+struct RowTwoPanels {
+    int64_t row_i0, row_j0;
+    int split;
+    __device__ __forceinline__ int64_t operator()(int tr) const {
+        return tr < split ? row_i0 + tr : row_j0 + (tr - split);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass: per-sample log-sum-exp over states + per-state sums of p_nk, for NF vectors f.
+//   aden[f][k] = f_k + ln N_k (-inf for unsampled / padded states)
+//   logden_n   = log sum_k exp(aden_k - u_kn)                    (mbar_solvers.py:238)
+//   p_nk       = exp(aden_k - u_kn - logden_n),  psum_k = sum_n p_nk   (= N_k sum_n W_nk)
+// One exp per matrix element per f: e = exp(x - max) is kept in registers and normalised by the
+// reciprocal of its sum.
+// ---------------------------------------------------------------------------------------------
+template <int NB, int NF, bool DMA>
+__global__ void __launch_bounds__(256)
+k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+      const double* __restrict__ aden, double* __restrict__ logden0, double* __restrict__ logden1,
+      const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16;
+    constexpr int TILE_BYTES = ROWS * TS * 8;
+    constexpr int NDMA = ROWS / 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem + wave * (2 * TILE_BYTES);
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const RowIdentity rows{0};
+
+    double a[NF][NB], acc[NF][NB], obj[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        obj[f] = 0.0;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            a[f][I] = aden[f * ROWS + 16 * I + ks];
+            acc[f][I] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) settle(a[f][I]);
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    int64_t t = gw;
+    int cur = 0;
+    if constexpr (DMA) {
+        if (t < ntiles) stage_tile<ROWS, true>(u, ld, t * TS, buf, lane, rows);
+    }
+    for (; t < ntiles; t += W) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        if constexpr (DMA) {
+            const int64_t tn = t + W;
+            if (tn < ntiles) {
+                stage_tile<ROWS, true>(u, ld, tn * TS, buf + (cur ^ 1) * TILE_BYTES, lane, rows);
+                wait_vm<NDMA>();
+            } else {
+                wait_vm<0>();
+            }
+        } else {
+            stage_tile<ROWS, false>(u, ld, t * TS, cbuf, lane, rows);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        double mm[NF], ss[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { mm[f] = 0.0; ss[f] = 1.0; }
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            double uv[NB];
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+                uv[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
+            const bool valid = (t * TS + 4 * g + ns) < N;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                double x[NB];
+                double m = -INFINITY;
+#pragma unroll
+                for (int I = 0; I < NB; ++I) { x[I] = a[f][I] - uv[I]; m = fmax(m, x[I]); }
+                m = row16_max(m);
+                double s = 0.0;
+#pragma unroll
+                for (int I = 0; I < NB; ++I) { x[I] = exp(x[I] - m); s += x[I]; }
+                s = row16_sum(s);
+                const double r = valid ? 1.0 / s : 0.0;
+#pragma unroll
+                for (int I = 0; I < NB; ++I) acc[f][I] = fma(x[I], r, acc[f][I]);
+                if ((ks & 3) == g) { mm[f] = m; ss[f] = s; }
+            }
+        }
+        // lanes with (ks & 3) == g hold (max, sum) of sample 4 g + ns: one log per tile
+        {
+            const int64_t n = t * TS + 4 * (ks & 3) + ns;
+            const bool writer = (ks < 4) && (n < N);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const double ldv = mm[f] + log(ss[f]);
+                if (writer) {
+                    double* out = f == 0 ? logden0 : logden1;
+                    if (out) out[n] = ldv;
+                    obj[f] += dn ? (ldv - dn[n]) : ldv;
+                }
+            }
+        }
+        cur ^= 1;
+    }
+    // per-wave partial sums: fold the four sample sub-lanes, lanes 0..15 own one state each
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(gw * NF + f) * ROWS + 16 * I + lane] = v;
+        }
+        const double o = wave_sum(obj[f]);
+        if (lane == 0) obj_part[gw * NF + f] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram pass with known logden:  p = exp(anum_k - u_kn - logden_n)  (no cross-state dependency),
+// acc[I][J] += p[I]^T p[J] on the fp64 matrix cores.  DIAG: one panel against itself, upper
+// triangular blocks only; otherwise an NBI x NBJ rectangle between two panels.
+// Output block b, register r, lane l  ->  element (row = (l >> 4) + 4 r, col = l & 15) of block b.
+// ---------------------------------------------------------------------------------------------
+template <int NBI, int NBJ, bool DIAG, bool DMA>
+__global__ void __launch_bounds__(256, 1)
+k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+       const double* __restrict__ anum_i, const double* __restrict__ anum_j,
+       const double* __restrict__ logden, int64_t row_i0, int64_t row_j0,
+       double* __restrict__ gram_part, double* __restrict__ psum_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NBT = DIAG ? NBI : NBI + NBJ;  // blocks of 16 states staged per tile
+    constexpr int ROWS = NBT * 16;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the tile's 16 logden values
+    constexpr int NDMA = ROWS / 8 + 1;
+    constexpr int NBLK = DIAG ? NBI * (NBI + 1) / 2 : NBI * NBJ;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem + wave * (2 * TILE_BYTES);
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const RowTwoPanels rows{row_i0, row_j0, DIAG ? ROWS : NBI * 16};
+
+    double a[NBT], ps[NBT];
+#pragma unroll
+    for (int I = 0; I < NBT; ++I) {
+        a[I] = (DIAG || I < NBI) ? anum_i[16 * I + ks] : anum_j[16 * (I - NBI) + ks];
+        ps[I] = 0.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NBT; ++I) settle(a[I]);
+    v4d acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    int64_t t = gw;
+    int cur = 0;
+    if constexpr (DMA) {
+        if (t < ntiles) {
+            stage_tile<ROWS, true>(u, ld, t * TS, buf, lane, rows);
+            stage_vec16<true>(logden, t * TS, buf + U_BYTES, lane);
+        }
+    }
+    for (; t < ntiles; t += W) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        if constexpr (DMA) {
+            const int64_t tn = t + W;
+            if (tn < ntiles) {
+                char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+                stage_tile<ROWS, true>(u, ld, tn * TS, nbuf, lane, rows);
+                stage_vec16<true>(logden, tn * TS, nbuf + U_BYTES, lane);
+                wait_vm<NDMA>();
+            } else {
+                wait_vm<0>();
+            }
+        } else {
+            stage_tile<ROWS, false>(u, ld, t * TS, cbuf, lane, rows);
+            stage_vec16<false>(logden, t * TS, cbuf + U_BYTES, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        double ldc[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g)
+            ldc[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const bool valid = (t * TS + 4 * g + ns) < N;
+            double p[NBT];
+#pragma unroll
+            for (int I = 0; I < NBT; ++I) {
+                const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
+                const double e = exp(a[I] - uv - ldc[g]);
+                p[I] = valid ? e : 0.0;
+                ps[I] += p[I];
+            }
+            if constexpr (DIAG) {
+                int b = 0;
+#pragma unroll
+                for (int I = 0; I < NBI; ++I)
+#pragma unroll
+                    for (int J = I; J < NBI; ++J) {
+                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[I], p[J], acc[b], 0, 0, 0);
+                        ++b;
+                    }
+            } else {
+#pragma unroll
+                for (int I = 0; I < NBI; ++I)
+#pragma unroll
+                    for (int J = 0; J < NBJ; ++J)
+                        acc[I * NBJ + J] =
+                            __builtin_amdgcn_mfma_f64_16x16x4f64(p[I], p[NBI + J], acc[I * NBJ + J], 0, 0, 0);
+            }
+        }
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = acc[b][r];
+    if (psum_part) {
+#pragma unroll
+        for (int I = 0; I < NBT; ++I) {
+            double v = ps[I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[gw * ROWS + 16 * I + lane] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram pass, paired-wave variant for a full 128-state panel (NB = 8: 36 upper-triangular blocks =
+// 288 accumulator registers, more than the 256 AGPRs one wave can hold without the compiler
+// rotating accumulators through VGPRs after every MFMA).  A workgroup has 8 waves = 4 tile streams
+// x 2 halves; the two waves of a stream share the LDS tile, each computes all the operands p (the
+// exp work is duplicated, the matrix pipe is the bound) and owns every other block (18 blocks, 144
+// AGPRs), so two waves fit per SIMD and the hardware overlaps one wave's exp with the other's MFMA.
+// One workgroup barrier per tile: [wait own DMA] [barrier] [issue DMA of the next tile into the
+// buffer everybody just finished] [compute].
+// ---------------------------------------------------------------------------------------------
+template <int NB, int H, int NBLK>
+__device__ __forceinline__ void gram_half_group(const double (&p)[NB], v4d (&acc)[NBLK]) {
+    int b = 0, mine = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+            if ((b & 1) == H) {
+                acc[mine] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[I], p[J], acc[mine], 0, 0, 0);
+                ++mine;
+            }
+            ++b;
+        }
+}
+
+template <int NB, bool DMA, int HALF>
+__device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+                                               const double* __restrict__ anum, const double* __restrict__ logden,
+                                               int64_t row0, double* __restrict__ gram_part,
+                                               double* __restrict__ psum_part, char* smem, int lane, int stream) {
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;
+    constexpr int NDMA = ROWS / 8;
+    constexpr int NBLK = NB * (NB + 1) / 2;
+    constexpr int NMINE = HALF == 0 ? (NBLK + 1) / 2 : NBLK / 2;  // blocks b with (b & 1) == HALF
+    constexpr int STREAMS = 4;
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem + stream * (2 * TILE_BYTES);
+    const int64_t gs = (int64_t)blockIdx.x * STREAMS + stream;   // global stream id = partial record
+    const int64_t S = (int64_t)gridDim.x * STREAMS;
+    const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
+    const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;  // block-uniform trip count
+    const RowIdentity rows{row0};
+
+    double a[NB], ps[NB / 2];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) a[I] = anum[16 * I + ks];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) settle(a[I]);
+#pragma unroll
+    for (int I = 0; I < NB / 2; ++I) ps[I] = 0.0;
+    v4d acc[NMINE];
+#pragma unroll
+    for (int b = 0; b < NMINE; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    // this wave stages DMA instructions j with (j & 1) == HALF; half 0 also stages the logden slot
+    auto stage_mine = [&](int64_t tile, char* dst) {
+#pragma unroll
+        for (int j = HALF; j < NDMA; j += 2) {
+            const int tr = 8 * j + (lane >> 3);
+            const int pp = 2 * (lane & 7);
+            const int smp = (pp - (tr & 14)) & 15;
+            const double* src = u + rows(tr) * ld + tile * TS + smp;
+            if constexpr (DMA) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+            } else {
+                *reinterpret_cast<double2*>(dst + j * 1024 + lane * 16) = *reinterpret_cast<const double2*>(src);
+            }
+        }
+        if constexpr (HALF == 0) stage_vec16<DMA>(logden, tile * TS, dst + U_BYTES, lane);
+    };
+
+    int64_t t = gs;
+    int cur = 0;
+    if (t < ntiles) stage_mine(t, buf);
+    for (int64_t it = 0; it < niter; ++it, t += S) {
+        wait_vm<0>();
+        __syncthreads();
+        const bool active = t < ntiles;
+        char* cbuf = buf + cur * TILE_BYTES;
+        if (active && t + S < ntiles) stage_mine(t + S, buf + (cur ^ 1) * TILE_BYTES);
+        if (active) {
+            double ldc[GROUPS];
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g)
+                ldc[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                const bool valid = (t * TS + 4 * g + ns) < N;
+                double p[NB];
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
+                    const double e = exp(a[I] - uv - ldc[g]);
+                    p[I] = valid ? e : 0.0;
+                }
+#pragma unroll
+                for (int I = 0; I < NB / 2; ++I) ps[I] += p[HALF * (NB / 2) + I];
+                gram_half_group<NB, HALF, NMINE>(p, acc);
+            }
+        }
+        cur ^= 1;
+    }
+    // block b of the full enumeration lives in half (b & 1) at slot b >> 1
+#pragma unroll
+    for (int sl = 0; sl < NMINE; ++sl) {
+        const int b = 2 * sl + HALF;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gram_part[((gs * NBLK + b) * 4 + r) * 64 + lane] = acc[sl][r];
+    }
+    if (psum_part) {
+#pragma unroll
+        for (int I = 0; I < NB / 2; ++I) {
+            double v = ps[I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[gs * ROWS + 16 * (HALF * (NB / 2) + I) + lane] = v;
+        }
+    }
+}
+
+template <int NB, bool DMA>
+__global__ void __launch_bounds__(512, 2)
+k_gram_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+            const double* __restrict__ anum, const double* __restrict__ logden, int64_t row0,
+            double* __restrict__ gram_part, double* __restrict__ psum_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stream = wave & 3;
+    if ((wave >> 2) == 0)
+        gram_pair_body<NB, DMA, 0>(u, ld, N, ntiles, anum, logden, row0, gram_part, psum_part, smem, lane, stream);
+    else
+        gram_pair_body<NB, DMA, 1>(u, ld, N, ntiles, anum, logden, row0, gram_part, psum_part, smem, lane, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layout-agnostic fallbacks (any K): lanes along n, one sample per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_lse_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
+              const double* __restrict__ aden, double* __restrict__ logden,
+              const double* __restrict__ dn, double* __restrict__ obj_part) {
+    __shared__ double red[4];
+    double obj = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        double m = -INFINITY, s = 0.0;
+        for (int64_t k = 0; k < K; ++k) {
+            const double ak = aden[k];
+            if (ak == -INFINITY) continue;  // uniform: unsampled state
+            const double x = ak - u[k * ld + n];
+            if (m == -INFINITY) {
+                m = x;
+                s = 1.0;
+            } else {
+                const double d = x - m;
+                const double e = exp(-fabs(d));
+                s = d > 0.0 ? fma(s, e, 1.0) : s + e;
+                m = fmax(m, x);
+            }
+        }
+        const double ldv = m + log(s);
+        if (logden) logden[n] = ldv;
+        obj += dn ? (ldv - dn[n]) : ldv;
+    }
+    obj = wave_sum(obj);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = obj;
+    __syncthreads();
+    if (threadIdx.x == 0) obj_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// psum_part[blockIdx.x][k] = sum over this block's samples of exp(anum_k - u_kn - logden_n);
+// blockIdx.y selects a group of 8 states.
+__global__ void __launch_bounds__(256)
+k_colsum_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
+                 const double* __restrict__ anum, const double* __restrict__ logden,
+                 double* __restrict__ psum_part) {
+    __shared__ double red[4][8];
+    const int64_t k0 = (int64_t)blockIdx.y * 8;
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const double ldv = logden[n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = k0 + j;
+            if (k < K) acc[j] += exp(anum[k] - u[k * ld + n] - ldv);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double v = wave_sum(acc[j]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && k0 + threadIdx.x < K) {
+        const int j = threadIdx.x;
+        psum_part[(int64_t)blockIdx.x * K + k0 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reductions and small kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_reduce(const double* __restrict__ part, int64_t nparts, int64_t count, int64_t chunk,
+         double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t p0 = (int64_t)blockIdx.y * chunk;
+    const int64_t p1 = p0 + chunk < nparts ? p0 + chunk : nparts;
+    double s = 0.0;
+    for (int64_t p = p0; p < p1; ++p) s += part[p * count + i];
+    out[(int64_t)blockIdx.y * count + i] = s;
+}
+
+// Robust per-state log-sum-exp over samples (log space, like the reference's second logsumexp):
+// block = 1024 samples; for every state k the block max and sum of exp(x - max) are emitted.
+constexpr int LOGNUM_CHUNK = 1024;
+__global__ void __launch_bounds__(256)
+k_lognum(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
+         const double* __restrict__ anum, const double* __restrict__ logden,
+         double* __restrict__ pmax, double* __restrict__ psum, int64_t nchunks) {
+    __shared__ double red[8];
+    const int64_t c = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double nl[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t n = c * LOGNUM_CHUNK + j * 256 + threadIdx.x;
+        ok[j] = n < N;
+        nl[j] = ok[j] ? -logden[n] : 0.0;
+    }
+    for (int64_t k = 0; k < K; ++k) {
+        const double ak = anum[k];
+        double v[4];
+        double m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = c * LOGNUM_CHUNK + j * 256 + threadIdx.x;
+            v[j] = ok[j] ? (ak + nl[j] - u[k * ld + n]) : -INFINITY;
+            m = fmax(m, v[j]);
+        }
+        m = wave_max(m);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        double s = 0.0;
+        if (m > -INFINITY) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += exp(v[j] - m);  // exp(-inf) = 0 for masked samples
+        }
+        s = wave_sum(s);
+        if (lane == 0) red[4 + wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            pmax[k * nchunks + c] = m;
+            psum[k * nchunks + c] = red[4] + red[5] + red[6] + red[7];
+        }
+        __syncthreads();
+    }
+}
+
+// merge chunk partials of one state: out_max = max_c, out_sum = sum_c psum_c exp(pmax_c - out_max)
+__global__ void __launch_bounds__(256)
+k_lognum_merge(const double* __restrict__ pmax, const double* __restrict__ psum, int64_t nchunks,
+               double* __restrict__ out_max, double* __restrict__ out_sum) {
+    __shared__ double red[8];
+    const int64_t k = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double m = -INFINITY;
+    for (int64_t c = threadIdx.x; c < nchunks; c += blockDim.x) m = fmax(m, pmax[k * nchunks + c]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    double s = 0.0;
+    if (m > -INFINITY)
+        for (int64_t c = threadIdx.x; c < nchunks; c += blockDim.x) {
+            const double pm = pmax[k * nchunks + c];
+            if (pm > -INFINITY) s += psum[k * nchunks + c] * exp(pm - m);
+        }
+    s = wave_sum(s);
+    if (lane == 0) red[4 + wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out_max[k] = m;
+        out_sum[k] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_logw(const double* __restrict__ u, int64_t ld, int64_t N, const double* __restrict__ f,
+       const double* __restrict__ logden, double* __restrict__ out, int64_t ld_out) {
+    const int64_t k = blockIdx.y;
+    const double fk = f[k];
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+        out[k * ld_out + n] = fk - u[k * ld + n] - logden[n];
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256)
+k_generate_harmonic(double* __restrict__ u, int64_t ld, int64_t N, int64_t K, uint64_t seed,
+                    const double* __restrict__ O_k, const double* __restrict__ K_k,
+                    const int64_t* __restrict__ cumN, int64_t n_global0) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ng = n_global0 + n;
+        int64_t lo = 0, hi = K;  // state s with cumN[s] <= ng < cumN[s+1]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cumN[mid] <= ng) lo = mid; else hi = mid;
+        }
+        const uint64_t key = seed * 0xD1342543DE82EF95ull + 2ull * (uint64_t)ng;
+        const uint64_t r1 = splitmix64(key), r2 = splitmix64(key + 1ull);
+        const double u1 = ((double)(r1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+        const double u2 = ((double)(r2 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+        const double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+        const double x = O_k[lo] + z / sqrt(K_k[lo]);
+        for (int64_t l = 0; l < K; ++l) {
+            const double d = x - O_k[l];
+            u[l * ld + n] = 0.5 * K_k[l] * d * d;
+        }
+    }
+}
+
+// One self-consistent step on the device (single block): f'_k = f_k - log(psum_k / N_k) on sampled
+// states (mbar_solvers.py:231-242 via s_k), gauge f'[first] = 0 (:588), relative change (:627-631).
+__global__ void __launch_bounds__(256)
+k_sci_update(const double* __restrict__ psum, const double* __restrict__ Nk, const double* __restrict__ lnNk,
+             int64_t K, int64_t Kp, int first, double tol, double* __restrict__ f, double* __restrict__ aden,
+             double* __restrict__ delta_out) {
+    __shared__ double red[4];
+    __shared__ double f0new;
+    if (threadIdx.x == 0) f0new = f[first] - log(psum[first] / Nk[first]);
+    __syncthreads();
+    double dmax = 0.0;
+    const double small = tol < 1e-8 ? tol : 1e-8;
+    for (int64_t k = threadIdx.x; k < Kp; k += blockDim.x) {
+        if (k < K && Nk[k] > 0.0) {
+            const double fo = f[k];
+            const double fn = fo - log(psum[k] / Nk[k]) - f0new;
+            f[k] = fn;
+            aden[k] = fn + lnNk[k];
+            if (k != first) {
+                const double div = fabs(fn) < small ? 1.0 : fabs(fn);
+                const double d = fabs(fn - fo) / div;
+                dmax = (d > dmax || d != d) ? d : dmax;  // propagate NaN
+            }
+        } else {
+            aden[k] = -INFINITY;
+        }
+    }
+    // NaN-propagating max
+    double m = dmax;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const double o = __shfl_xor(m, s);
+        m = (o > m || o != o) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int w = 1; w < 4; ++w) r = (red[w] > r || red[w] != red[w]) ? red[w] : r;
+        *delta_out = r;
+    }
+}
+
+// fp64 MFMA peak probe: 4 independent accumulators per wave, nothing else in the loop.
+__global__ void __launch_bounds__(256)
+k_mfma_peak(int iters, double* sink) {
+    v4d c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, c3, 0, 0, 0);
+    }
+    const double v = c0[0] + c1[1] + c2[2] + c3[3];
+    if (v == 12345.678) sink[threadIdx.x] = v;  // never true: keeps the loop alive
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+static int blocks_per_cu_for(size_t lds_bytes) {
+    int b = (int)((160 * 1024) / lds_bytes);
+    if (b < 1) b = 1;
+    if (b > 4) b = 4;
+    return b;
+}
+
+LaunchGeom lse_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override) {
+    LaunchGeom g;
+    g.waves = nb <= 8 ? 4 : 2;
+    g.lds_bytes = (size_t)g.waves * 2 * nb * 16 * TS * 8;
+    int64_t want = (ntiles + g.waves - 1) / g.waves;
+    int64_t cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+    if (grid_override > 0) cap = grid_override;
+    if (want < 1) want = 1;
+    g.blocks = (int)(want < cap ? want : cap);
+    g.nwaves = g.blocks * g.waves;
+    return g;
+}
+
+LaunchGeom gram_geometry(int tile_rows, int num_cu, int64_t ntiles, int64_t grid_override) {
+    LaunchGeom g;
+    g.waves = 4;
+    g.lds_bytes = (size_t)g.waves * 2 * ((size_t)tile_rows * TS * 8 + TS * 8);  // tiles + their logden slots
+    int64_t want = (ntiles + g.waves - 1) / g.waves;
+    int64_t cap = num_cu;  // one wave per SIMD: the accumulators own the register file
+    if (grid_override > 0) cap = grid_override;
+    if (want < 1) want = 1;
+    g.blocks = (int)(want < cap ? want : cap);
+    g.nwaves = g.blocks * g.waves;
+    return g;
+}
+
+template <int NB, int NF, bool DMA>
+static hipError_t launch_lse_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                               const double* aden, double* l0, double* l1, const double* dn,
+                               double* psum_part, double* obj_part) {
+    auto kern = k_lse<NB, NF, DMA>;
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TS - 1) / TS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, l0,
+                       l1, dn, psum_part, obj_part);
+    return hipGetLastError();
+}
+
+template <int NB>
+static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeom& g, const double* u,
+                                int64_t ld, int64_t N, const double* aden, double* l0, double* l1,
+                                const double* dn, double* pp, double* op) {
+    if (nf == 1)
+        return dma ? launch_lse_t<NB, 1, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
+                   : launch_lse_t<NB, 1, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
+    return dma ? launch_lse_t<NB, 2, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
+               : launch_lse_t<NB, 2, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
+}
+
+hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,
+                      int64_t ld, int64_t N, const double* aden, double* l0, double* l1, const double* dn,
+                      double* pp, double* op) {
+    switch (nb) {
+#define MBAR_CASE(NB_) \
+    case NB_: return launch_lse_nb<NB_>(s, nf, dma, g, u, ld, N, aden, l0, l1, dn, pp, op);
+        MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7)
+        MBAR_CASE(8) MBAR_CASE(12) MBAR_CASE(16)
+#undef MBAR_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int NBI, int NBJ, bool DIAG, bool DMA>
+static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                const double* ai, const double* aj, const double* logden, int64_t ri,
+                                int64_t rj, double* gp, double* pp) {
+    auto kern = k_gram<NBI, NBJ, DIAG, DMA>;
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TS - 1) / TS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, ai, aj,
+                       logden, ri, rj, gp, pp);
+    return hipGetLastError();
+}
+
+template <int NB, bool DMA>
+static hipError_t launch_gram_pair_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                     const double* anum, const double* logden, int64_t row0, double* gp,
+                                     double* pp) {
+    auto kern = k_gram_pair<NB, DMA>;
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TS - 1) / TS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(512), g.lds_bytes, s, u, ld, N, ntiles, anum, logden, row0, gp, pp);
+    return hipGetLastError();
+}
+
+hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
+                            int64_t N, const double* anum, const double* logden, int64_t row0, double* gp,
+                            double* pp) {
+    if (nb == 8)  // paired-wave variant: g.nwaves counts tile streams (4 per workgroup)
+        return dma ? launch_gram_pair_t<8, true>(s, g, u, ld, N, anum, logden, row0, gp, pp)
+                   : launch_gram_pair_t<8, false>(s, g, u, ld, N, anum, logden, row0, gp, pp);
+    switch (nb) {
+#define MBAR_CASE(NB_)                                                                                  \
+    case NB_:                                                                                           \
+        return dma ? launch_gram_t<NB_, NB_, true, true>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp) \
+                   : launch_gram_t<NB_, NB_, true, false>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp);
+        MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7)
+#undef MBAR_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gram_off(hipStream_t s, bool dma, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                           const double* ai, const double* aj, const double* logden, int64_t ri, int64_t rj,
+                           double* gp) {
+    return dma ? launch_gram_t<4, 4, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr)
+               : launch_gram_t<4, 4, false, false>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
+}
+
+static int stream_blocks(int num_cu, int64_t N) {
+    int64_t want = (N + 255) / 256;
+    int64_t cap = (int64_t)num_cu * 8;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
+                              const double* aden, double* logden, const double* dn, double* obj_part,
+                              int* blocks_out) {
+    const int blocks = stream_blocks(num_cu, N);
+    *blocks_out = blocks;
+    hipLaunchKernelGGL(k_lse_generic, dim3(blocks), dim3(256), 0, s, u, ld, N, K, aden, logden, dn, obj_part);
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
+                                 const double* anum, const double* logden, double* psum_part, int* blocks_out) {
+    int blocks = stream_blocks(num_cu, N);
+    if (blocks > 512) blocks = 512;
+    *blocks_out = blocks;
+    hipLaunchKernelGGL(k_colsum_generic, dim3(blocks, (unsigned)((K + 7) / 8)), dim3(256), 0, s, u, ld, N, K,
+                       anum, logden, psum_part);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce(hipStream_t s, const double* part, int64_t nparts, int64_t count, double* scratch,
+                         double* out) {
+    const unsigned gx = (unsigned)((count + 255) / 256);
+    if (nparts <= 32) {
+        hipLaunchKernelGGL(k_reduce, dim3(gx, 1), dim3(256), 0, s, part, nparts, count, nparts, out);
+        return hipGetLastError();
+    }
+    const int64_t chunk = 32;
+    const int64_t n1 = (nparts + chunk - 1) / chunk;
+    hipLaunchKernelGGL(k_reduce, dim3(gx, (unsigned)n1), dim3(256), 0, s, part, nparts, count, chunk, scratch);
+    hipLaunchKernelGGL(k_reduce, dim3(gx, 1), dim3(256), 0, s, (const double*)scratch, n1, count, n1, out);
+    return hipGetLastError();
+}
+
+int64_t lognum_chunks(int64_t N) { return (N + LOGNUM_CHUNK - 1) / LOGNUM_CHUNK; }
+
+hipError_t launch_lognum(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, const double* anum,
+                         const double* logden, double* pmax, double* psum, int64_t nchunks) {
+    hipLaunchKernelGGL(k_lognum, dim3((unsigned)nchunks), dim3(256), 0, s, u, ld, N, K, anum, logden, pmax, psum,
+                       nchunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_lognum_merge(hipStream_t s, const double* pmax, const double* psum, int64_t K, int64_t nchunks,
+                               double* out_max, double* out_sum) {
+    hipLaunchKernelGGL(k_lognum_merge, dim3((unsigned)K), dim3(256), 0, s, pmax, psum, nchunks, out_max, out_sum);
+    return hipGetLastError();
+}
+
+hipError_t launch_logw(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, const double* f,
+                       const double* logden, double* out, int64_t ld_out) {
+    int64_t bx = (N + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_logw, dim3((unsigned)bx, (unsigned)K), dim3(256), 0, s, u, ld, N, f, logden, out, ld_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_t N, int64_t K, uint64_t seed,
+                                    const double* O_k, const double* K_k, const int64_t* cumN,
+                                    int64_t n_global0) {
+    int64_t bx = (N + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_generate_harmonic, dim3((unsigned)bx), dim3(256), 0, s, u, ld, N, K, seed, O_k, K_k, cumN,
+                       n_global0);
+    return hipGetLastError();
+}
+
+hipError_t launch_sci_update(hipStream_t s, const double* psum, const double* Nk, const double* lnNk, int64_t K,
+                             int64_t Kp, int first_state, double tol, double* f, double* aden, double* delta_out) {
+    hipLaunchKernelGGL(k_sci_update, dim3(1), dim3(256), 0, s, psum, Nk, lnNk, K, Kp, first_state, tol, f, aden,
+                       delta_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink) {
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, s, iters, sink);
+    return hipGetLastError();
+}
+
+}  // namespace mbar

@@ -1,0 +1,244 @@
+"""Device-resident reduced-potential matrix: the Python face of one ``mbar_ctx`` (include/mbar_hip.h).
+
+A :class:`DeviceMatrix` holds this rank's column shard of ``u_kn`` in HBM for as long as the object
+lives, so the many sweeps of a solve touch PCIe only with K-sized vectors.  It can be passed to every
+function of :mod:`pymbar_amd.mbar_solvers` in place of the numpy ``u_kn`` (they upload a temporary
+one when handed a numpy array).  The reference keeps ``u_kn`` in host RAM and re-sends it on every
+jitted call (pymbar/mbar_solvers.py:255-257).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class DeviceMatrix:
+    """(K x N_local) fp64 matrix on one MI355X plus the solver state attached to it."""
+
+    def __init__(self, K, N_local, device=None):
+        _lib.require_device()
+        self._lib = _lib.load_library()
+        self.K = int(K)
+        self.N_local = int(N_local)
+        if device is None:
+            import os
+
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, _lib.device_count())
+        self.device = int(device)
+        self._ctx = C.c_void_p()
+        rc = self._lib.mbar_ctx_create(C.byref(self._ctx), self.device, self.K, self.N_local)
+        if rc != _lib.MBAR_OK:
+            raise _lib.MbarHipError(rc, _lib.last_error(None))
+        self._Nk = None
+        self._cb = None  # keeps the host all-reduce callback alive
+        self.nranks = 1
+        self.rank = 0
+        self.allreduce_kind = "none"
+
+    # ---- construction ---------------------------------------------------------------------------
+    @classmethod
+    def from_host(cls, u_kn, device=None, columns=None):
+        """Upload a host ``u_kn`` (K, N) -- or only its ``columns=(n0, n1)`` slice (this rank's shard)."""
+        u_kn = np.asarray(u_kn)
+        if u_kn.ndim != 2:
+            raise ValueError("u_kn must be 2-D (K, N)")
+        if u_kn.dtype != np.float64 or not u_kn.flags.c_contiguous:
+            u_kn = np.ascontiguousarray(u_kn, dtype=np.float64)
+        K, N = u_kn.shape
+        n0, n1 = (0, N) if columns is None else columns
+        dm = cls(K, n1 - n0, device=device)
+        dm._check(dm._lib.mbar_ctx_upload_u(dm._ctx, _dptr(u_kn), N, n0, n1 - n0, 0))
+        return dm
+
+    @classmethod
+    def harmonic(cls, O_k, K_k, N_k_global, seed=0, n_global0=0, N_local=None, device=None):
+        """Generate the synthetic harmonic ladder of SURVEY.md 8(d) directly in HBM."""
+        O_k = np.ascontiguousarray(O_k, dtype=np.float64)
+        K_k = np.ascontiguousarray(K_k, dtype=np.float64)
+        N_k_global = np.ascontiguousarray(N_k_global, dtype=np.int64)
+        K = len(O_k)
+        if N_local is None:
+            N_local = int(N_k_global.sum()) - n_global0
+        dm = cls(K, N_local, device=device)
+        dm._check(dm._lib.mbar_ctx_generate_harmonic(
+            dm._ctx, C.c_uint64(seed), _dptr(O_k), _dptr(K_k),
+            N_k_global.ctypes.data_as(C.POINTER(C.c_int64)), n_global0))
+        return dm
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != _lib.MBAR_OK:
+            raise _lib.MbarHipError(rc, _lib.last_error(self._ctx))
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.mbar_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def shape(self):
+        return (self.K, self.N_local)
+
+    def set_option(self, key, value):
+        self._check(self._lib.mbar_ctx_set_option(self._ctx, key.encode(), int(value)))
+
+    def synchronize(self):
+        self._check(self._lib.mbar_ctx_synchronize(self._ctx))
+
+    def to_host(self):
+        out = np.empty((self.K, self.N_local), dtype=np.float64)
+        self._check(self._lib.mbar_ctx_download_u(self._ctx, _dptr(out), self.N_local))
+        return out
+
+    def set_Nk(self, N_k):
+        """GLOBAL sample counts (any numeric dtype; zeros allowed)."""
+        Nk = np.ascontiguousarray(N_k, dtype=np.float64)
+        if Nk.shape != (self.K,):
+            raise ValueError(f"N_k must have shape ({self.K},)")
+        if self._Nk is None or not np.array_equal(Nk, self._Nk):
+            self._check(self._lib.mbar_ctx_set_Nk(self._ctx, _dptr(Nk)))
+            self._Nk = Nk.copy()
+
+    # ---- multi-GPU --------------------------------------------------------------------------------
+    def comm_init_rccl(self, unique_id, rank, nranks):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.mbar_ctx_comm_init(self._ctx, buf, rank, nranks))
+        self.rank, self.nranks, self.allreduce_kind = rank, nranks, "rccl"
+
+    def set_host_allreduce(self, fn, rank, nranks):
+        """``fn(array, op)`` must all-reduce the float64 numpy ``array`` in place (op 'sum'|'max')."""
+
+        def _cb(ptr, count, op, _user):
+            try:
+                arr = np.ctypeslib.as_array(ptr, shape=(count,))
+                fn(arr, "sum" if op == 0 else "max")
+                return 0
+            except Exception:  # pragma: no cover
+                return 1
+
+        self._cb = _lib.ALLREDUCE_FN(_cb)
+        self._check(self._lib.mbar_ctx_set_host_allreduce(self._ctx, self._cb, None, rank, nranks))
+        self.rank, self.nranks, self.allreduce_kind = rank, nranks, "host"
+
+    # ---- L1 ---------------------------------------------------------------------------------------
+    def eval(self, f, gram=False, use_offset=False):
+        """One fused sweep for 1 or 2 free-energy vectors.  Returns ``(psum, sumlogden, gram)`` with
+        ``psum[i, k] = sum_n N_k W_nk(f_i)``, ``sumlogden[i] = sum_n logden_n(f_i)`` and, if asked,
+        ``gram = sum_n p p^T`` at ``f[0]`` (all summed over ranks)."""
+        f = np.ascontiguousarray(np.atleast_2d(np.asarray(f, dtype=np.float64)))
+        nf = f.shape[0]
+        if f.shape[1] != self.K or nf not in (1, 2):
+            raise ValueError("f must be (K,) or (1|2, K)")
+        psum = np.empty((nf, self.K), dtype=np.float64)
+        sld = np.empty(nf, dtype=np.float64)
+        G = np.empty((self.K, self.K), dtype=np.float64) if gram else None
+        flags = (_lib.EVAL_GRAM if gram else 0) | (_lib.EVAL_USE_OFFSET if use_offset else 0)
+        self._check(self._lib.mbar_eval(self._ctx, _dptr(f), nf, flags, _dptr(psum), _dptr(sld),
+                                        _dptr(G) if gram else None))
+        return psum, sld, G
+
+    def set_objective_offset(self, f0):
+        if f0 is None:
+            self._check(self._lib.mbar_ctx_set_objective_offset(self._ctx, None))
+        else:
+            f0 = np.ascontiguousarray(f0, dtype=np.float64)
+            self._check(self._lib.mbar_ctx_set_objective_offset(self._ctx, _dptr(f0)))
+
+    def lognum(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        out = np.empty(self.K, dtype=np.float64)
+        self._check(self._lib.mbar_lognum(self._ctx, _dptr(f), _dptr(out)))
+        return out
+
+    def logden(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        out = np.empty(self.N_local, dtype=np.float64)
+        self._check(self._lib.mbar_logden(self._ctx, _dptr(f), _dptr(out)))
+        return out
+
+    def logw_kn(self, f):
+        """``log W`` of this shard as a C-ordered (K, N_local) array; its ``.T`` is the reference's
+        F-ordered (N, K) ``Log_W_nk``."""
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        out = np.empty((self.K, self.N_local), dtype=np.float64)
+        self._check(self._lib.mbar_logw(self._ctx, _dptr(f), _dptr(out), self.N_local))
+        return out
+
+    def gram_w(self, f):
+        """``(W^T W, sum_n W_nk)`` over all states (MFMA), summed over ranks."""
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        G = np.empty((self.K, self.K), dtype=np.float64)
+        ws = np.empty(self.K, dtype=np.float64)
+        self._check(self._lib.mbar_gram_w(self._ctx, _dptr(f), _dptr(G), _dptr(ws)))
+        return G, ws
+
+    # ---- solver loops -----------------------------------------------------------------------------
+    def solve_adaptive(self, f, tol=1e-12, maxiter=10000, min_sc_iter=2, gamma=1.0, check_convergence=True,
+                       history_rows=0):
+        f = np.array(f, dtype=np.float64)
+        res = _lib.SolveResult()
+        hist = np.zeros((max(1, history_rows), 4), dtype=np.float64)
+        self._check(self._lib.mbar_solve_adaptive(self._ctx, _dptr(f), tol, int(maxiter), int(min_sc_iter),
+                                                  float(gamma), 1 if check_convergence else 0, _dptr(hist),
+                                                  int(history_rows), C.byref(res)))
+        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_ if k != "reserved"}
+        out["success"] = bool(res.success)
+        out["history"] = hist[: min(history_rows, res.iterations)]
+        return f, out
+
+    def solve_sci(self, f, tol=1e-12, maxiter=10000, check_convergence=True):
+        f = np.array(f, dtype=np.float64)
+        res = _lib.SolveResult()
+        self._check(self._lib.mbar_solve_sci(self._ctx, _dptr(f), tol, int(maxiter),
+                                             1 if check_convergence else 0, C.byref(res)))
+        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_ if k != "reserved"}
+        out["success"] = bool(res.success)
+        return f, out
+
+    # ---- measurement ------------------------------------------------------------------------------
+    def timing(self):
+        """{class: (total_ms, launches)} of HIP-event timed kernels since the last reset."""
+        out = {}
+        for name, which in (("lse", _lib.TIMER_LSE), ("gram", _lib.TIMER_GRAM), ("reduce", _lib.TIMER_REDUCE),
+                            ("other", _lib.TIMER_OTHER)):
+            ms = C.c_double(0.0)
+            n = C.c_int64(0)
+            self._check(self._lib.mbar_ctx_timing(self._ctx, which, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def timing_reset(self):
+        self._check(self._lib.mbar_ctx_timing_reset(self._ctx))
+
+    def mfma_f64_peak(self):
+        t = C.c_double(0.0)
+        self._check(self._lib.mbar_mfma_f64_peak(self._ctx, C.byref(t)))
+        return t.value
+
+
+def device_info(device=0):
+    lib = _lib.load_library()
+    name = C.create_string_buffer(256)
+    cu = C.c_int(0)
+    mem = C.c_int64(0)
+    rc = lib.mbar_device_info(device, name, 256, C.byref(cu), C.byref(mem))
+    if rc != _lib.MBAR_OK:
+        raise _lib.BackendUnavailable(_lib.last_error(None))
+    return dict(name=name.value.decode(), compute_units=cu.value, total_mem_bytes=mem.value)

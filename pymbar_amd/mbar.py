@@ -1,0 +1,296 @@
+"""``MBAR(u_kn, N_k, solver_protocol=...)`` on the MI355X solver path.
+
+Host-side mirror of the part of ``pymbar.mbar.MBAR`` that touches the hot path (SURVEY.md 3.1,
+3.4): construction = solve (pymbar/mbar.py:85-465), ``Log_W_nk`` / ``W_nk`` (:455-478),
+``compute_effective_sample_number`` (:495-560), ``compute_overlap`` (:563-617) and
+``compute_free_energy_differences`` with the asymptotic covariance ``Theta`` (:620-729, :1687-1864).
+The reduced-potential matrix is uploaded once and stays resident; ``W^T W`` is contracted on the
+fp64 matrix cores and only K x K linear algebra (eigh / pinv) runs on the host.
+
+Not mirrored here (out of the hot-path scope): ``compute_expectations*``,
+``compute_perturbed_free_energies``, ``compute_entropy_and_enthalpy``, BAR initialisation.
+"""
+import copy
+import logging
+
+import numpy as np
+
+from . import mbar_solvers
+from .mbar_solvers import (BOOTSTRAP_SOLVER_PROTOCOL, DEFAULT_SOLVER_PROTOCOL, JAX_SOLVER_PROTOCOL,
+                           ROBUST_SOLVER_PROTOCOL)
+from .utils import ParameterError, check_w_sums, kln_to_kn
+
+logger = logging.getLogger(__name__)
+
+
+def _resolve_protocol(protocol, default, robust, maximum_iterations, verbose, pname):
+    """Protocol resolution of pymbar/mbar.py:370-406, on a private copy (the reference mutates the
+    module-level constants in place, which leaks options between MBAR objects)."""
+    if protocol is None or protocol == "default":
+        protocol = default
+    elif protocol == "robust":
+        protocol = robust
+    elif protocol == "jax":
+        protocol = JAX_SOLVER_PROTOCOL
+    else:
+        for solver in protocol:
+            if not isinstance(solver, dict):
+                logger.warning(f"{pname} is not 'robust','default' or a tuple/list dictionaries, setting to 'default'")
+                protocol = default
+                break
+    protocol = copy.deepcopy(tuple(protocol))
+    for solver in protocol:
+        solver.setdefault("options", dict())
+        if solver["options"] is None:
+            solver["options"] = dict()
+        solver.setdefault("continuation", None)
+        opts = solver["options"]
+        if "maxiter" not in opts or maximum_iterations > opts["maxiter"]:
+            opts["maxiter"] = maximum_iterations
+        opts.setdefault("verbose", verbose)
+    return protocol
+
+
+class MBAR:
+    """Multistate Bennett acceptance ratio estimator; free energies are solved on construction.
+
+    Parameters follow pymbar/mbar.py:85-99.  ``u_kn`` is (K, N) [or (K, L, N_max) ``u_kln``];
+    ``N_k`` (K,) may contain zeros.  Extra keyword: ``device`` selects the GPU."""
+
+    def __init__(self, u_kn, N_k, maximum_iterations=10000, relative_tolerance=1.0e-7, verbose=False,
+                 initial_f_k=None, solver_protocol=None, initialize="zeros", x_kindices=None, n_bootstraps=0,
+                 bootstrap_solver_protocol=None, rseed=None, device=None):
+        from .device import DeviceMatrix
+
+        self.N_k = np.array(N_k, dtype=np.int64)
+        self.N = int(np.sum(self.N_k))
+        if len(np.shape(u_kn)) == 3:
+            u_kn = kln_to_kn(u_kn, N_k=self.N_k)
+        self.u_kn = np.array(u_kn, dtype=np.float64)
+        K, N = self.u_kn.shape
+        if verbose:
+            logger.info("K (total states) = {:d}, total samples = {:d}".format(K, N))
+        if np.sum(self.N_k) != N:
+            raise ParameterError(
+                "The sum of all N_k must equal the total number of samples (length of second dimension of u_kn.")
+        self.K, self.N = K, N
+        if x_kindices is not None:
+            self.x_kindices = x_kindices
+        else:
+            self.x_kindices = np.repeat(np.arange(K, dtype=np.int64), self.N_k)
+        self.verbose = verbose
+        if rseed is None:
+            rseed = np.random.randint(np.iinfo(np.int32).max)
+        self.rng = np.random.default_rng(rseed)
+
+        # same-energy state detection on <= 50 random samples, verbose only (mbar.py:273-317); the random
+        # draw happens regardless of verbosity so that bootstraps are reproducible under rseed
+        self.samestates = []
+        maxpoint = min(50, self.N)
+        indices = self.rng.choice(np.arange(self.N), maxpoint)
+        if self.verbose:
+            sub = self.u_kn[:, indices]
+            for k in range(K):
+                for l in range(k):
+                    d = sub[k] - sub[l]
+                    if np.dot(d, d) < relative_tolerance:
+                        self.samestates += [[k, l], [l, k]]
+                        logger.warning(f"States {l:d} and {k:d} have the same energies on the dataset. They are "
+                                       "therefore likely to to be the same thermodynamic state.")
+            logger.info("N_k = ")
+            logger.info(self.N_k)
+
+        self.states_with_samples = np.where(self.N_k != 0)[0].astype(np.int64)
+        self.K_nonzero = self.states_with_samples.size
+        if verbose:
+            logger.info("There are {:d} states with samples.".format(self.K_nonzero))
+
+        self.f_k = np.zeros([K], dtype=np.float64)
+        if initial_f_k is not None:
+            initial_f_k = np.array(initial_f_k, dtype=np.float64)
+            if initial_f_k.shape != self.f_k.shape:
+                raise ParameterError("initial_f_k must be a {:d}-dimensional np array.".format(K))
+            self.f_k = initial_f_k - initial_f_k[0]
+        else:
+            self._initializeFreeEnergies(verbose, method=initialize)
+
+        solver_protocol = _resolve_protocol(solver_protocol, DEFAULT_SOLVER_PROTOCOL, ROBUST_SOLVER_PROTOCOL,
+                                            maximum_iterations, verbose, "solver_protocol")
+        bootstrap_solver_protocol = _resolve_protocol(bootstrap_solver_protocol, BOOTSTRAP_SOLVER_PROTOCOL,
+                                                      ROBUST_SOLVER_PROTOCOL, maximum_iterations, verbose,
+                                                      "bootstrap_solver_protocol")
+
+        # the matrix goes to HBM once and stays there for the lifetime of the object
+        self._dm = DeviceMatrix.from_host(self.u_kn, device=device)
+        self.f_k = mbar_solvers.solve_mbar_for_all_states(self._dm, self.N_k, self.f_k, self.states_with_samples,
+                                                          solver_protocol)
+
+        self.n_bootstraps = 0
+        if n_bootstraps > 0:
+            self.n_bootstraps = n_bootstraps
+            self.f_k_boots = np.zeros([n_bootstraps, K])
+            self.bootstrap_rints = np.zeros([n_bootstraps, self.N], int)
+            for b in range(n_bootstraps):
+                rints = np.zeros(self.N, int)
+                for k in range(K):
+                    k_indices = np.where(self.x_kindices == k)[0]
+                    rints[k_indices] = k_indices[self.rng.integers(int(self.N_k[k]), size=int(self.N_k[k]))]
+                with DeviceMatrix.from_host(self.u_kn[:, rints], device=device) as dmb:
+                    self.f_k_boots[b, :] = mbar_solvers.solve_mbar_for_all_states(
+                        dmb, self.N_k, self.f_k.copy(), self.states_with_samples, bootstrap_solver_protocol)
+                self.bootstrap_rints[b, :] = rints
+        elif n_bootstraps < 0:
+            logger.warning("n_bootstraps must be an integer >= 0")
+
+        self._Log_W_nk = None
+        if self.verbose:
+            logger.info("Final dimensionless free energies")
+            logger.info("f_k = ")
+            logger.info(self.f_k)
+            logger.info("MBAR initialization complete.")
+
+    # ---- weights ----------------------------------------------------------------------------------
+    @property
+    def Log_W_nk(self):
+        """(N, K) log weights (mbar.py:455), computed on the device on first access and then cached
+        (the reference materialises them eagerly in the constructor)."""
+        if self._Log_W_nk is None:
+            self._Log_W_nk = mbar_solvers.mbar_log_W_nk(self._dm, self.N_k, self.f_k)
+        return self._Log_W_nk
+
+    @property
+    def W_nk(self):
+        return np.exp(self.Log_W_nk)
+
+    def weights(self):
+        return self.W_nk
+
+    def close(self):
+        """Release the device copy of ``u_kn``."""
+        if getattr(self, "_dm", None) is not None:
+            self._dm.close()
+            self._dm = None
+
+    def _gram_w(self):
+        self._dm.set_Nk(self.N_k)
+        return self._dm.gram_w(self.f_k)
+
+    def compute_effective_sample_number(self, verbose=False):
+        """Kish effective sample number ``1 / sum_n W_nk^2`` per state (mbar.py:495-560): the diagonal of
+        ``W^T W``."""
+        G, _ = self._gram_w()
+        N_eff = 1.0 / np.diag(G)
+        if verbose:
+            for k in range(self.K):
+                logger.info("Effective number of sample in state {:d} is {:10.3f}".format(k, N_eff[k]))
+                logger.info("Efficiency for state {:d} is {:6f}/{:d} = {:10.4f}".format(k, N_eff[k], self.N, N_eff[k] / self.N))
+        return N_eff
+
+    def compute_overlap(self):
+        """Overlap matrix ``O = N_k * (W^T W)``, its eigenvalues and ``1 - second largest`` (mbar.py:563-617)."""
+        G, _ = self._gram_w()
+        O = self.N_k * G
+        eigenvals = np.sort(np.linalg.eigvals(O))[::-1]
+        return dict(scalar=1 - eigenvals[1], eigenvalues=eigenvals, matrix=O)
+
+    # ---- free energy differences --------------------------------------------------------------------
+    def compute_free_energy_differences(self, compute_uncertainty=True, uncertainty_method=None, warning_cutoff=1.0e-10,
+                                        return_theta=False):
+        """``Delta_f[i, j] = f_j - f_i`` and its asymptotic (or bootstrap) uncertainty (mbar.py:620-729)."""
+        Deltaf_ij = np.array(self.f_k - np.vstack(self.f_k))
+        self._zerosamestates(Deltaf_ij)
+        result_vals = dict(Delta_f=Deltaf_ij)
+        if uncertainty_method == "bootstrap" and (self.n_bootstraps is None or self.n_bootstraps <= 0):
+            raise ParameterError("Cannot request bootstrap sampling of free energy differences without any bootstraps.")
+        Theta_ij = None
+        if (compute_uncertainty and uncertainty_method != "bootstrap") or return_theta:
+            Theta_ij = self._computeAsymptoticCovarianceMatrix(None, self.N_k, method=uncertainty_method)
+        if compute_uncertainty:
+            if uncertainty_method == "bootstrap":
+                diffm = self.f_k_boots[:, np.newaxis, :] - self.f_k_boots[:, :, np.newaxis]
+                result_vals["dDelta_f"] = np.std(diffm, axis=0)
+            else:
+                dDeltaf_ij = np.array(self._ErrorOfDifferences(Theta_ij, warning_cutoff=warning_cutoff))
+                self._zerosamestates(dDeltaf_ij)
+                result_vals["dDelta_f"] = dDeltaf_ij
+        if return_theta:
+            result_vals["Theta"] = Theta_ij
+        return result_vals
+
+    # ---- private -----------------------------------------------------------------------------------
+    def _ErrorOfDifferences(self, cov, warning_cutoff=1.0e-10):
+        """``sqrt(cov_ii + cov_jj - 2 cov_ij)``; small negative squares are zeroed (mbar.py:1687-1715)."""
+        diag = cov.diagonal()
+        d2 = diag + np.vstack(diag) - 2 * cov
+        cutoff = -abs(warning_cutoff)
+        if np.any(d2 < 0.0):
+            if np.any(d2 < cutoff):
+                logger.warning("A squared uncertainty is negative. Largest Magnitude = {0:f}".format(abs(np.min(d2[d2 < cutoff]))))
+            else:
+                d2[np.logical_and(0 > d2, d2 > cutoff)] = 0.0
+        return np.sqrt(np.array(d2))
+
+    @staticmethod
+    def _pseudoinverse(A, tol=1.0e-10):
+        return np.linalg.pinv(A, rcond=tol)
+
+    def _zerosamestates(self, A):
+        for pair in self.samestates:
+            A[pair[0], pair[1]] = 0
+            A[pair[1], pair[0]] = 0
+
+    def _computeAsymptoticCovarianceMatrix(self, W, N_k, method=None):
+        """Asymptotic covariance ``Theta`` (mbar.py:1756-1864).  ``W`` may be ``None``: ``W^T W`` and the
+        column sums then come straight from the device (methods "svd-ew" and "approximate"); "svd"
+        needs the explicit (N, K) matrix."""
+        if method is None or method == "bootstrap":
+            method = "svd-ew"
+        N_k = np.asarray(N_k)
+        K = N_k.size
+        if method not in ("approximate", "svd", "svd-ew"):
+            raise ParameterError(f"Method {method} unrecognized.")
+        if W is None and method != "svd":
+            G, wsum = self._gram_w()
+            check_w_sums(wsum, 0.0)
+        else:
+            if W is None:
+                W = self.W_nk
+            N, Kw = W.shape
+            if Kw != K:
+                raise ParameterError("W must be NxK, where N_k is a K-dimensional array.")
+            if np.sum(N_k) != N:
+                raise ParameterError("W must be NxK, where N = sum_k N_k.")
+            from .utils import check_w_normalized
+
+            check_w_normalized(W, N_k)
+            G = W.T @ W
+        if method == "approximate":
+            return G
+        Ndiag = np.diag(N_k)
+        ident = np.identity(K, dtype=np.float64)
+        if method == "svd":
+            _, S, Vt = np.linalg.svd(W, full_matrices=False)
+            Sigma, V = np.diag(S), Vt.T
+        else:
+            S2, V = np.linalg.eigh(G)
+            S2[np.where(S2 < 0.0)] = 0.0
+            Sigma = np.diag(np.sqrt(S2))
+        return V @ Sigma @ self._pseudoinverse(ident - Sigma @ V.T @ Ndiag @ V @ Sigma) @ Sigma @ V.T
+
+    def _initializeFreeEnergies(self, verbose=False, method="zeros"):
+        """Initial guess (mbar.py:1868-1917): zeros or the per-state mean reduced potential."""
+        if method == "zeros":
+            self.f_k[:] = 0.0
+        elif method == "mean-reduced-potential":
+            means = np.zeros([self.K], float)
+            for k in self.states_with_samples:
+                means[k] = self.u_kn[k, 0 : self.N_k[k]].mean()
+            if np.max(np.abs(means)) < 0.000001:
+                logger.warning("Warning: All mean reduced potentials are close to zero.")
+            self.f_k = means
+        elif method == "BAR":
+            raise ParameterError("initialize='BAR' is outside the MI355X hot-path scope (SURVEY.md 8f rank 4); "
+                                 "use 'zeros' or 'mean-reduced-potential'")
+        else:
+            raise ParameterError("Method " + method + " unrecognized.")
+        self.f_k[:] = self.f_k[:] - self.f_k[0]

@@ -1,0 +1,108 @@
+"""Helpers shared by the solver mirror and the MBAR class (host side, numpy only).
+
+Behavioural mirror of the pieces of pymbar/utils.py that the solver path imports
+(pymbar/mbar_solvers.py:10): ``ensure_type`` (utils.py:117-232), ``check_w_normalized``
+(utils.py:340-393), ``kln_to_kn`` (utils.py:41-76) and the exception classes (utils.py:401-422).
+"""
+import warnings
+
+import numpy as np
+
+
+class ParameterError(Exception):
+    """An error in the input parameters has been detected."""
+
+
+class ConvergenceError(Exception):
+    """Convergence could not be achieved."""
+
+
+class DataError(Exception):
+    """Data is inconsistent."""
+
+
+class TypeCastPerformanceWarning(RuntimeWarning):
+    pass
+
+
+def ensure_type(val, dtype, ndim, name, length=None, can_be_none=False, shape=None, warn_on_cast=True,
+                add_newaxis_on_deficient_ndim=False):
+    """Check dtype / ndim / shape of an array, casting (with a warning) when needed; the result is
+    always C-contiguous.  Same contract and error types as pymbar/utils.py:117-232."""
+    if can_be_none and val is None:
+        return None
+    if not isinstance(val, np.ndarray):
+        if add_newaxis_on_deficient_ndim and ndim == 1 and np.isscalar(val):
+            val = np.array([val])
+        else:
+            raise TypeError(f"{name} must be numpy array.  You supplied type {type(val)}")
+    if warn_on_cast and val.dtype != dtype:
+        warnings.warn(f"Casting {name} dtype={val.dtype} to {dtype} ", TypeCastPerformanceWarning)
+    if val.ndim != ndim:
+        if add_newaxis_on_deficient_ndim and val.ndim + 1 == ndim:
+            val = val[np.newaxis, ...]
+        else:
+            raise ValueError(f"{name} must be ndim {ndim}. You supplied {val.ndim}")
+    val = np.ascontiguousarray(val, dtype=dtype)
+    if length is not None and len(val) != length:
+        raise ValueError(f"{name} must be length {length}. You supplied {len(val)}.")
+    if shape is not None:
+        want = str(shape).replace("None", "Any")
+        if len(shape) != val.ndim or any(b is not None and a != b for a, b in zip(val.shape, shape)):
+            raise ValueError(f"{name} must be shape {want}. You supplied  {val.shape}")
+    return val
+
+
+def check_w_normalized(W, N_k, tolerance=1.0e-4):
+    """``sum_n W_nk = 1`` and ``sum_k N_k W_nk = 1`` within ``tolerance`` else ParameterError
+    (pymbar/utils.py:340-393)."""
+    N, K = W.shape
+    column_sums = np.sum(W, axis=0)
+    bad = np.abs(column_sums - 1) > tolerance
+    if np.any(bad):
+        first = int(np.arange(K)[bad][0])
+        raise ParameterError(
+            f"Warning: Should have \\sum_n W_nk = 1. Actual column sum for state {first:d} was "
+            f"{column_sums[first]:f}. {int(np.sum(bad)):d} other columns have similar problems. \n"
+            "This generally indicates the free energies are not converged.")
+    row_sums = np.sum(W * N_k, axis=1)
+    bad = np.abs(row_sums - 1) > tolerance
+    if np.any(bad):
+        first = int(np.arange(N)[bad][0])
+        raise ParameterError(
+            f"Warning: Should have \\sum__k N_k W_nk = 1. Actual row sum for state {first:d} was "
+            f"{row_sums[first]:f}. {int(np.sum(bad)):d} other columns have similar problems. \n"
+            "This generally indicates the free energies are not converged.")
+
+
+def check_w_sums(column_sums, row_sum_dev, tolerance=1.0e-4):
+    """Device-side variant of :func:`check_w_normalized`: takes the per-state sums ``sum_n W_nk``
+    and the largest per-sample deviation ``max_n |sum_k N_k W_nk - 1|`` computed on the GPU."""
+    column_sums = np.asarray(column_sums)
+    bad = np.abs(column_sums - 1) > tolerance
+    if np.any(bad):
+        first = int(np.where(bad)[0][0])
+        raise ParameterError(
+            f"Warning: Should have \\sum_n W_nk = 1. Actual column sum for state {first:d} was "
+            f"{column_sums[first]:f}. {int(np.sum(bad)):d} other columns have similar problems. \n"
+            "This generally indicates the free energies are not converged.")
+    if row_sum_dev > tolerance:
+        raise ParameterError("Warning: Should have \\sum__k N_k W_nk = 1.")
+
+
+def kln_to_kn(kln, N_k=None, cleanup=False):
+    """(K, L, N_max) -> (L, N_total) concatenation of the first N_k[k] samples of each k
+    (pymbar/utils.py:41-76)."""
+    K, L, N_max = np.shape(kln)
+    if N_k is None:
+        N_k = N_max * np.ones([K], dtype=np.int64)
+    N = int(np.sum(N_k))
+    kn = np.zeros([L, N], dtype=np.float64)
+    i = 0
+    for k in range(K):
+        if N_k[k] > 0:
+            kn[:, i : i + N_k[k]] = kln[k, :, 0 : N_k[k]]
+            i += N_k[k]
+    if cleanup:
+        del kln
+    return kn

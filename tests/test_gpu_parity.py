@@ -1,0 +1,329 @@
+"""Parity of the gfx950 path (through the C ABI, include/mbar_hip.h) with the CPU oracle and with the
+reference's golden fixtures.  Everything here needs a real MI355X: run with ``-m gpu``.
+
+Tolerances (BASELINE.json: Deltaf_ij within 1e-8 relative, fp64): L1 quantities are compared at
+1e-10 relative or tighter -- they differ from the oracle only by summation order and by the ulp-level
+difference between the device exp/log and libm; solutions at 1e-9 absolute."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mbar_oracle as oracle  # noqa: E402
+from pymbar_amd import mbar_solvers as ms  # noqa: E402
+from pymbar_amd import testsystems as ts  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def DM():
+    from pymbar_amd.device import DeviceMatrix
+
+    return DeviceMatrix
+
+
+def random_problem(K, N, seed, unsampled=(), spread=1.0):
+    rng = np.random.RandomState(seed)
+    O_k = np.linspace(0.0, 3.0, K) * spread
+    K_k = np.linspace(1.0, 2.5, K)
+    N_k = rng.multinomial(N, np.ones(K) / K) if K > 1 else np.array([N])
+    for k in unsampled:
+        N_k[0] += N_k[k]
+        N_k[k] = 0
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn(O_k, K_k, N_k, seed=seed)
+    f = ts.harmonic_free_energies(K_k) + 0.2 * rng.standard_normal(K)
+    f[0] = 0.0
+    return u_kn, N_k, f
+
+
+def check_l1(dm, u_kn, N_k, f, tag=""):
+    Nf = N_k.astype(float)
+    dm.set_Nk(N_k)
+    psum, sld, gram = dm.eval(f, gram=True)
+    part = oracle.shard_partials(u_kn, N_k, f, want_gram=True)
+    scale = max(1.0, Nf.max())
+    np.testing.assert_allclose(psum[0], part["psum"], rtol=1e-11, atol=1e-11 * scale, err_msg=tag + " psum")
+    np.testing.assert_allclose(sld[0], part["sumlogden"], rtol=1e-12, atol=1e-9, err_msg=tag + " sumlogden")
+    np.testing.assert_allclose(gram, part["gram"], rtol=1e-10, atol=1e-12 * scale, err_msg=tag + " gram")
+    assert np.array_equal(gram, gram.T)
+    np.testing.assert_allclose(ms.mbar_gradient(dm, N_k, f), oracle.mbar_gradient(u_kn, N_k, f), rtol=1e-9,
+                               atol=1e-10 * scale, err_msg=tag + " gradient")
+    np.testing.assert_allclose(ms.mbar_hessian(dm, N_k, f), oracle.mbar_hessian(u_kn, N_k, f), rtol=1e-9,
+                               atol=1e-11 * scale, err_msg=tag + " hessian")
+    np.testing.assert_allclose(ms.self_consistent_update(dm, N_k, f), oracle.self_consistent_update(u_kn, N_k, f),
+                               rtol=1e-12, atol=1e-11, err_msg=tag + " sci")
+    np.testing.assert_allclose(dm.logden(f), oracle.log_denominator(u_kn, N_k, f), rtol=1e-13, atol=1e-12,
+                               err_msg=tag + " logden")
+    # two candidates in one sweep == two single sweeps
+    f2 = f + 0.05 * np.cos(np.arange(len(f)))
+    f2[0] = 0
+    ps2, sl2, _ = dm.eval(np.stack([f, f2]))
+    np.testing.assert_allclose(ps2[0], psum[0], rtol=1e-13, atol=1e-13 * scale)
+    np.testing.assert_allclose(ps2[1], oracle.shard_partials(u_kn, N_k, f2)["psum"], rtol=1e-11, atol=1e-11 * scale,
+                               err_msg=tag + " psum(second f)")
+
+
+@pytest.mark.parametrize("K,N", [(1, 40), (2, 7), (3, 16), (5, 5000), (16, 1000), (17, 999), (32, 4096), (40, 2001),
+                                 (64, 3000), (100, 1500), (112, 800), (128, 2048), (128, 33)])
+@pytest.mark.parametrize("staging", [0, 1])
+def test_l1_parity_fast_path(DM, K, N, staging):
+    u_kn, N_k, f = random_problem(K, N, seed=K * 1000 + N)
+    with DM.from_host(u_kn) as dm:
+        dm.set_option("staging", staging)
+        check_l1(dm, u_kn, N_k, f, tag=f"K={K} N={N} staging={staging}")
+        np.testing.assert_array_equal(dm.to_host(), u_kn)
+
+
+@pytest.mark.parametrize("K,N", [(129, 1000), (160, 700), (192, 1200), (200, 513), (256, 600)])
+def test_l1_parity_paneled_gram(DM, K, N):
+    """128 < K <= 256: 2-wave evaluation kernel + 64-state Gram panels (diagonal and off-diagonal launches)."""
+    u_kn, N_k, f = random_problem(K, N, seed=K + N)
+    with DM.from_host(u_kn) as dm:
+        check_l1(dm, u_kn, N_k, f, tag=f"K={K} N={N}")
+
+
+@pytest.mark.parametrize("K,N,force", [(300, 900, 0), (321, 400, 0), (40, 2001, 1), (128, 640, 1)])
+def test_l1_parity_generic_path(DM, K, N, force):
+    """K > 256 (and the forced fallback for small K): layout-agnostic kernels + paneled Gram."""
+    u_kn, N_k, f = random_problem(K, N, seed=7 * K + N)
+    with DM.from_host(u_kn) as dm:
+        dm.set_option("force_generic", force)
+        check_l1(dm, u_kn, N_k, f, tag=f"K={K} N={N} generic")
+
+
+def test_unsampled_states_and_logw(DM):
+    u_kn, N_k, f = random_problem(24, 3000, seed=5, unsampled=(3, 17, 23))
+    with DM.from_host(u_kn) as dm:
+        check_l1(dm, u_kn, N_k, f, tag="unsampled")
+        logW = ms.mbar_log_W_nk(dm, N_k, f)
+        assert logW.shape == (3000, 24) and logW.flags.f_contiguous
+        np.testing.assert_allclose(logW, oracle.mbar_log_W_nk(u_kn, N_k, f), rtol=1e-13, atol=1e-12)
+        G, wsum = dm.gram_w(f)
+        W = oracle.mbar_W_nk(u_kn, N_k, f)
+        np.testing.assert_allclose(G, W.T @ W, rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(wsum, W.sum(0), rtol=1e-11)
+        # masked subset (mbar_solvers.py:253-257)
+        sws = np.where(N_k > 0)[0]
+        np.testing.assert_allclose(ms.self_consistent_update(dm, N_k, f, states_with_samples=sws),
+                                   oracle.self_consistent_update(u_kn[sws], N_k[sws], f[sws]), rtol=1e-12, atol=1e-11)
+
+
+def test_invariances_and_extreme_energies(DM):
+    """Per-sample shifts leave g, H, W unchanged (mbar_solvers.py:727-734); huge energy gaps neither overflow
+    nor produce NaN (the reference relies on logsumexp for this)."""
+    u_kn, N_k, f = random_problem(20, 2000, seed=11)
+    shift = 1.0e4 * np.sin(np.arange(2000))
+    big = u_kn.copy()
+    big[7] += 3000.0  # a state nobody overlaps with
+    big[:, ::5] += 800.0
+    with DM.from_host(u_kn) as a, DM.from_host(u_kn + shift) as b, DM.from_host(big) as c:
+        for dm in (a, b, c):
+            dm.set_Nk(N_k)
+        pa, sa, ga = a.eval(f, gram=True)
+        pb, sb, gb = b.eval(f, gram=True)
+        np.testing.assert_allclose(pb, pa, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(gb, ga, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(sb[0] - sa[0], -shift.sum(), rtol=1e-10)
+        pc, sc, gc = c.eval(f, gram=True)
+        assert np.all(np.isfinite(pc)) and np.all(np.isfinite(gc)) and np.isfinite(sc[0])
+        part = oracle.shard_partials(big, N_k, f, want_gram=True)
+        np.testing.assert_allclose(pc[0], part["psum"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(ms.self_consistent_update(c, N_k, f), oracle.self_consistent_update(big, N_k, f),
+                                   rtol=1e-11, atol=1e-10)
+        # far-off f: still finite and equal to the oracle
+        f_bad = f + 50.0 * np.cos(np.arange(20))
+        f_bad[0] = 0
+        pbad, _, _ = a.eval(f_bad)
+        np.testing.assert_allclose(pbad[0], oracle.shard_partials(u_kn, N_k, f_bad)["psum"], rtol=1e-10, atol=1e-9)
+
+
+def test_objective_offset_matches_preconditioned_objective(DM):
+    u_kn, N_k, f = random_problem(12, 1500, seed=21)
+    with DM.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        dm.set_objective_offset(f)
+        f2 = f + 0.01 * np.sin(np.arange(12))
+        _, sld, _ = dm.eval(f2, use_offset=True)
+        pre = oracle.precondition_u_kn(u_kn, N_k, f)
+        want = oracle.mbar_objective(pre, N_k, f2)
+        got = sld[0] + np.dot(N_k, f) - np.dot(N_k, f2)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+        dm.set_objective_offset(None)
+        np.testing.assert_allclose(ms.precondition_u_kn(dm, N_k, f), pre, rtol=1e-12, atol=1e-10)
+
+
+# ---- golden fixtures produced by the reference -------------------------------------------------
+def test_golden_config1_l1_and_adaptive(DM, golden):
+    g = golden("config1_ho_K5_N5000.npz")
+    u_kn, N_k, f = g["u_kn"], g["N_k"], g["f_eval"]
+    with DM.from_host(u_kn) as dm:
+        np.testing.assert_allclose(ms.mbar_gradient(dm, N_k, f), g["gradient"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(ms.self_consistent_update(dm, N_k, f), g["sci"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(ms.mbar_objective(dm, N_k, f), g["objective"], rtol=1e-12)
+        np.testing.assert_allclose(ms.mbar_hessian(dm, N_k, f), g["hessian"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(np.exp(ms.mbar_log_W_nk(dm, N_k, f)).sum(0), g["logW_colsum"], rtol=1e-11)
+        fa, res = ms.solve_mbar_once(dm, N_k, np.zeros(5), method="adaptive", tol=1e-12, options=dict(min_sc_iter=0))
+        assert res["success"] and res["iterations"] == int(g["adaptive_iters"])
+        np.testing.assert_allclose(fa, g["f_adaptive"], rtol=1e-10, atol=1e-11)
+        # reference test_mbar_solvers.py:34-41 properties at the solution
+        np.testing.assert_allclose(ms.mbar_gradient(dm, N_k, fa), 0, atol=1e-8)
+        np.testing.assert_allclose(ms.self_consistent_update(dm, N_k, fa), fa, atol=1e-10)
+        W = ms.mbar_W_nk(dm, N_k, fa)
+        np.testing.assert_allclose(W.sum(0), 1, atol=1e-10)
+        np.testing.assert_allclose(W @ N_k, 1, atol=1e-10)
+
+
+@pytest.mark.parametrize("method", ["adaptive", "hybr", "lm", "L-BFGS-B", "BFGS", "Newton-CG", "trust-ncg", "dogleg",
+                                    "trust-exact", "trust-krylov", "self-consistent-iteration"])
+def test_golden_config1_every_method(DM, golden, method):
+    g = golden("config1_ho_K5_N5000.npz")
+    with DM.from_host(g["u_kn"]) as dm:
+        f, res = ms.solve_mbar_once(dm, g["N_k"], np.zeros(5), method=method, tol=1e-12, options=dict())
+    np.testing.assert_allclose(f, g["f_k"], atol=1e-7)
+
+
+def test_golden_mbar_class_config1_and_unsampled(golden):
+    import pymbar_amd
+
+    g = golden("config1_ho_K5_N5000.npz")
+    mbar = pymbar_amd.MBAR(g["u_kn"], g["N_k"])
+    np.testing.assert_allclose(mbar.f_k, g["f_k"], atol=1e-10)
+    for method, tag in (("svd-ew", "svd_ew"), ("svd", "svd"), ("approximate", "approximate")):
+        r = mbar.compute_free_energy_differences(uncertainty_method=method, return_theta=True)
+        np.testing.assert_allclose(r["Delta_f"], g["Delta_f"], atol=1e-10)
+        np.testing.assert_allclose(r["dDelta_f"], g["dDelta_f_" + tag], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(r["Theta"], g["Theta_" + tag], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mbar.compute_overlap()["matrix"], g["overlap_matrix"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(mbar.compute_effective_sample_number(), g["N_eff"], rtol=1e-8)
+    mbar.close()
+    g = golden("ho_unsampled_K4_N2300.npz")
+    for proto in (None, "robust"):
+        mbar = pymbar_amd.MBAR(g["u_kn"], g["N_k"], solver_protocol=proto)
+        np.testing.assert_allclose(mbar.f_k, g["f_k"], rtol=1e-8, atol=1e-9)
+        r = mbar.compute_free_energy_differences()
+        np.testing.assert_allclose(r["dDelta_f"], g["dDelta_f_svd_ew"], rtol=1e-7, atol=1e-9)
+        mbar.close()
+
+
+def test_golden_oscillators_and_ladder(DM, golden):
+    g = golden("osc_K50_N5000.npz")
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn(np.linspace(1, 5, 50), np.linspace(1, 3, 50), [100] * 50, seed=7)
+    with DM.from_host(u_kn) as dm:
+        np.testing.assert_allclose(ms.mbar_gradient(dm, N_k, g["f_eval"]), g["gradient"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(ms.mbar_hessian(dm, N_k, g["f_eval"]), g["hessian"], rtol=1e-9, atol=1e-9)
+        f, res = ms.solve_mbar_once(dm, N_k, np.zeros(50), method="adaptive", tol=1e-12, options=dict(min_sc_iter=0))
+        assert res["iterations"] == int(g["adaptive_iters"])
+        np.testing.assert_allclose(f, g["f_adaptive"], rtol=1e-9, atol=1e-10)
+    g = golden("ladder_K32_N32000.npz")
+    x_n, u_kn, N_k, s_n, O_k, K_k = ts.config2(seed=0, K=32, N=32000)
+    with DM.from_host(u_kn) as dm:
+        f, res = ms.solve_mbar_once(dm, N_k, np.zeros(32), method="adaptive", tol=1e-12, options=dict(min_sc_iter=0))
+        assert res["iterations"] == int(g["adaptive_iters"]) and abs(res["nr_iter"] - int(g["adaptive_nr"])) <= 1
+        np.testing.assert_allclose(f, g["f_adaptive"], rtol=1e-9, atol=1e-10)
+        f2, res2 = ms.solve_mbar_once(dm, N_k, np.zeros(32), method="adaptive", tol=1e-12, options=dict())
+        assert res2["iterations"] == int(g["adaptive_iters_msc2"])
+        fs, rs = ms.solve_mbar_once(dm, N_k, np.zeros(32), method="self-consistent-iteration", tol=1e-12)
+        assert rs["success"] and abs(rs["iterations"] - int(g["sci_iters"])) <= 1
+        np.testing.assert_allclose(fs, g["f_sci"], rtol=1e-9, atol=1e-10)
+
+
+def test_golden_config5_alchemical_shape(golden):
+    """BASELINE.json config 5: K=40, N=95000, two unsampled states; Delta_f within 1e-8 relative of the
+    reference, dDelta_f (svd-ew covariance) likewise."""
+    import pymbar_amd
+
+    g = golden("config5_alch_K40_N95000.npz")
+    x_n, u_kn, N_k, s_n, O_k, K_k = ts.config5(seed=0)
+    mbar = pymbar_amd.MBAR(u_kn, N_k)
+    r = mbar.compute_free_energy_differences()
+    rel = np.abs(r["Delta_f"] - g["Delta_f"]) / np.maximum(np.abs(g["Delta_f"]), 1e-3)
+    assert rel.max() < 1e-8, rel.max()
+    np.testing.assert_allclose(r["dDelta_f"], g["dDelta_f_svd_ew"], rtol=1e-7, atol=1e-10)
+    mbar2 = pymbar_amd.MBAR(u_kn, N_k, solver_protocol=(dict(method="adaptive", options=dict(min_sc_iter=0)),))
+    np.testing.assert_allclose(mbar2.f_k, g["f_k_adaptive_protocol"], rtol=1e-8, atol=1e-9)
+    mbar.close()
+    mbar2.close()
+
+
+# ---- device generator, sharding, full size ---------------------------------------------------------
+def test_device_generator_is_shard_invariant_and_matches_oracle(DM):
+    O_k, K_k, N_k = ts.config3_params(K=32, N=64000)
+    with DM.harmonic(O_k, K_k, N_k, seed=3) as whole:
+        u = whole.to_host()
+        assert np.all(np.isfinite(u)) and u.min() >= 0
+        n_half = 32000 + 16
+        with DM.harmonic(O_k, K_k, N_k, seed=3, n_global0=0, N_local=n_half) as a, \
+                DM.harmonic(O_k, K_k, N_k, seed=3, n_global0=n_half, N_local=64000 - n_half) as b:
+            np.testing.assert_array_equal(np.concatenate([a.to_host(), b.to_host()], axis=1), u)
+            f = ts.harmonic_free_energies(K_k) + 0.01
+            f[0] = 0
+            for dm in (whole, a, b):
+                dm.set_Nk(N_k)
+            pw, sw, gw = whole.eval(f, gram=True)
+            pa, sa, ga = a.eval(f, gram=True)
+            pb, sb, gb = b.eval(f, gram=True)
+            np.testing.assert_allclose(pa + pb, pw, rtol=1e-12)
+            np.testing.assert_allclose(ga + gb, gw, rtol=1e-11, atol=1e-12)
+            np.testing.assert_allclose(sa + sb, sw, rtol=1e-13)
+        # statistics of the generated ladder: MBAR on it recovers the analytical free energies
+        f_sol, res = ms.solve_mbar_once(whole, N_k, np.zeros(32), method="adaptive", tol=1e-12, options=dict(min_sc_iter=0))
+        assert res["success"]
+        assert np.max(np.abs(f_sol - ts.harmonic_free_energies(K_k))) < 0.05
+        np.testing.assert_allclose(f_sol, oracle.solve_mbar_once_adaptive(u, N_k, np.zeros(32), min_sc_iter=0)[0],
+                                   rtol=1e-9, atol=1e-10)
+
+
+def test_config2_sci_on_device(DM):
+    """BASELINE.json config 2: K=32, N=1e6, pure self-consistent iteration, checked against a short oracle run
+    on the downloaded matrix (same bits) and against the fixed-point property."""
+    O_k, K_k, N_k = ts.config3_params(K=32, N=1_000_000)
+    with DM.harmonic(O_k, K_k, N_k, seed=0) as dm:
+        f, res = ms.solve_mbar_once(dm, N_k, np.zeros(32), method="self-consistent-iteration", tol=1e-12)
+        assert res["success"] and 50 < res["iterations"] < 200
+        np.testing.assert_allclose(ms.self_consistent_update(dm, N_k, f) - ms.self_consistent_update(dm, N_k, f)[0], f,
+                                   atol=1e-10)
+        fa, ra = ms.solve_mbar_once(dm, N_k, np.zeros(32), method="adaptive", tol=1e-12, options=dict(min_sc_iter=0))
+        np.testing.assert_allclose(f, fa, atol=1e-9)
+        assert np.max(np.abs(fa - ts.harmonic_free_energies(K_k))) < 0.02
+        u_sub = dm.to_host()[:, :50000]
+    # oracle on the first 50k columns vs a device context holding the same columns
+    Nk_sub = np.bincount(np.searchsorted(np.cumsum(N_k), np.arange(50000), side="right"), minlength=32)
+    with DM.from_host(u_sub) as sub:
+        check_l1(sub, u_sub, Nk_sub + 1, f, tag="config2 sub-block")
+
+
+def test_config3_full_size_properties(DM):
+    """BASELINE.json config 3 (K=128, N=1e7) at full size: size-independent properties of the solution."""
+    K, N = 128, 10_000_000
+    O_k, K_k, N_k = ts.config3_params(K=K, N=N)
+    with DM.harmonic(O_k, K_k, N_k, seed=0) as dm:
+        f, res = ms.solve_mbar_once(dm, N_k, np.zeros(K), method="adaptive", tol=1e-12, options=dict(min_sc_iter=0))
+        assert res["success"] and res["iterations"] <= 12
+        dm.set_Nk(N_k)
+        psum, sld, gram = dm.eval(f, gram=True)
+        g = psum[0] - N_k
+        H = np.diag(psum[0]) - gram
+        assert abs(psum[0].sum() - N) < 1e-6 * N ** 0.5          # sum_k p_nk = 1 for every sample
+        assert np.max(np.abs(g)) < 1e-6                           # gradient vanishes at the solution
+        assert np.max(np.abs(H @ np.ones(K))) < 1e-6              # null vector 1 (H rows sum to 0)
+        assert np.array_equal(gram, gram.T)
+        ev = np.linalg.eigvalsh(H)
+        assert ev[0] > -1e-6 and ev[1] > 0                        # PSD with a single zero mode
+        fs = ms.self_consistent_update(dm, N_k, f)
+        np.testing.assert_allclose(fs - fs[0], f, atol=1e-10)     # SCI fixed point (test_mbar_solvers.py:39-41)
+        assert np.max(np.abs(f - ts.harmonic_free_energies(K_k))) < 0.02
+    # oracle on a 100k-column block of the same bits (a full download is 10 GB; regenerate the first block
+    # through the shard-invariant generator instead)
+    with DM.harmonic(O_k, K_k, N_k, seed=0, n_global0=0, N_local=100_000) as sub:
+        u_sub = sub.to_host()
+        sub.set_Nk(N_k)
+        ps, sl, gs = sub.eval(f, gram=True)
+        part = oracle.shard_partials(u_sub, N_k, f, want_gram=True)
+        np.testing.assert_allclose(ps[0], part["psum"], rtol=1e-11, atol=1e-9)
+        np.testing.assert_allclose(gs, part["gram"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(sl[0], part["sumlogden"], rtol=1e-13)
+
+
+def test_mfma_peak_probe_is_sane(DM):
+    with DM.from_host(np.zeros((4, 64))) as dm:
+        t = dm.mfma_f64_peak()
+    assert 20.0 < t < 200.0, t

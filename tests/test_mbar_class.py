@@ -1,0 +1,94 @@
+"""MBAR class (pymbar_amd/mbar.py) on the CPU stand-in: API behaviour of pymbar/tests/test_mbar.py that
+touches the solver path, checked against the reference's outputs in tests/golden/."""
+import numpy as np
+import pytest
+
+import pymbar_amd
+import pymbar_amd.device
+from pymbar_amd import testsystems as ts
+from pymbar_amd.utils import ParameterError
+from tests.cpu_standin import OracleMatrix
+
+
+@pytest.fixture(autouse=True)
+def standin(monkeypatch):
+    monkeypatch.setattr(pymbar_amd.device, "DeviceMatrix", OracleMatrix)
+
+
+def test_config1_free_energy_differences(golden):
+    g = golden("config1_ho_K5_N5000.npz")
+    mbar = pymbar_amd.MBAR(g["u_kn"], g["N_k"])
+    np.testing.assert_allclose(mbar.f_k, g["f_k"], atol=1e-10)
+    for method, tag in ((None, "svd_ew"), ("svd-ew", "svd_ew"), ("svd", "svd"), ("approximate", "approximate")):
+        r = mbar.compute_free_energy_differences(uncertainty_method=method, return_theta=True)
+        np.testing.assert_allclose(r["Delta_f"], g["Delta_f"], atol=1e-10)
+        np.testing.assert_allclose(r["dDelta_f"], g["dDelta_f_" + tag], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(r["Theta"], g["Theta_" + tag], rtol=1e-6, atol=1e-9)
+    ov = mbar.compute_overlap()
+    np.testing.assert_allclose(ov["matrix"], g["overlap_matrix"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(np.real(ov["scalar"]), g["overlap_scalar"], rtol=1e-8)
+    np.testing.assert_allclose(ov["matrix"].sum(1), 1.0, atol=1e-8)  # test_mbar.py:451-463
+    np.testing.assert_allclose(mbar.compute_effective_sample_number(), g["N_eff"], rtol=1e-8)
+    # weights: columns sum to one (test_mbar.py:466-472), layout like the reference
+    W = mbar.weights()
+    assert W.shape == (5000, 5)
+    np.testing.assert_allclose(W.sum(0), 1.0, atol=1e-8)
+    np.testing.assert_allclose(W @ g["N_k"], 1.0, atol=1e-10)
+
+
+def test_unsampled_state_and_protocols(golden):
+    g = golden("ho_unsampled_K4_N2300.npz")
+    for proto in (None, "default", "robust", (dict(method="adaptive"),), (dict(method="L-BFGS-B", tol=1e-13),)):
+        mbar = pymbar_amd.MBAR(g["u_kn"], g["N_k"], solver_protocol=proto)
+        np.testing.assert_allclose(mbar.f_k, g["f_k"], rtol=1e-6, atol=1e-7)
+    mbar = pymbar_amd.MBAR(g["u_kn"], g["N_k"])
+    r = mbar.compute_free_energy_differences()
+    np.testing.assert_allclose(r["dDelta_f"], g["dDelta_f_svd_ew"], rtol=1e-7, atol=1e-9)
+
+
+def test_input_validation_and_options(golden):
+    g = golden("config1_ho_K5_N5000.npz")
+    u, N_k = g["u_kn"], g["N_k"]
+    with pytest.raises(ParameterError):
+        pymbar_amd.MBAR(u, N_k + 1)
+    with pytest.raises(ParameterError):  # test_mbar.py:127-130
+        pymbar_amd.MBAR(u, N_k, initial_f_k=np.zeros(4))
+    with pytest.raises(ParameterError):
+        pymbar_amd.MBAR(u, N_k, initialize="nonsense")
+    m0 = pymbar_amd.MBAR(u, N_k)
+    for init in ("zeros", "mean-reduced-potential"):  # test_mbar.py:203-214
+        m = pymbar_amd.MBAR(u, N_k, initialize=init)
+        np.testing.assert_allclose(m.f_k, m0.f_k, atol=1e-9)
+    m = pymbar_amd.MBAR(u, N_k, initial_f_k=m0.f_k + 3.0)  # gauge shift is removed
+    np.testing.assert_allclose(m.f_k, m0.f_k, atol=1e-9)
+    with pytest.raises(ParameterError):
+        m0.compute_free_energy_differences(uncertainty_method="bootstrap")
+    with pytest.raises(ParameterError):
+        m0.compute_free_energy_differences(uncertainty_method="bad")
+    # module-level protocols are not mutated (the reference leaks options: SURVEY appendix A.3)
+    assert "options" not in pymbar_amd.mbar_solvers.DEFAULT_SOLVER_PROTOCOL[0]
+
+
+def test_u_kln_input_and_x_kindices():
+    O_k, K_k = [0.0, 1.0, 2.0], [1.0, 2.0, 4.0]
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn(O_k, K_k, [40, 50, 60], seed=2)
+    u_kln = np.zeros((3, 3, 60))
+    start = 0
+    for k, n in enumerate(N_k):
+        u_kln[k, :, :n] = u_kn[:, start : start + n]
+        start += n
+    a = pymbar_amd.MBAR(u_kn, N_k)
+    b = pymbar_amd.MBAR(u_kln, N_k)
+    np.testing.assert_allclose(a.f_k, b.f_k, atol=1e-12)
+
+
+def test_bootstrap_is_deterministic_under_rseed():
+    # reference tests/test_mbar.py:533-545: same seed, bit-identical bootstrap free energies
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn([0.0, 1.0, 2.0], [1.0, 2.0, 4.0], [60, 50, 40], seed=4)
+    a = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=5, rseed=123)
+    b = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=5, rseed=123)
+    assert np.array_equal(a.f_k_boots, b.f_k_boots)
+    r = a.compute_free_energy_differences(uncertainty_method="bootstrap")
+    assert r["dDelta_f"].shape == (3, 3) and np.all(np.diag(r["dDelta_f"]) == 0)
+    ra = a.compute_free_energy_differences()
+    assert np.all(np.abs(r["dDelta_f"] - ra["dDelta_f"]) < 0.2)
