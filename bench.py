@@ -31,6 +31,25 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public spec (fp64 matrix); MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
+def pmc_traffic(kernel_prefix, K, n_loc):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_fetch_write.json,
+    newest round first), corrected as MI355X_MICROARCH.md prescribes (gfx950: FETCH_SIZE x 2).  None if no
+    profile of this exact workload is committed -- PMC collection needs its own rocprofv3 run."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") != {"K": K, "N_per_gpu": n_loc}:
+            continue
+        for name, v in d["kernels"].items():
+            if kernel_prefix in name and "FETCH_SIZE_KB_mean_per_launch" in v:
+                return (2.0 * v["FETCH_SIZE_KB_mean_per_launch"] + v.get("WRITE_SIZE_KB_mean_per_launch", 0.0)) * 1024.0
+    return None
+
+
 def cpu_baseline(dm_factory, K, N_full, n_sample, seed):
     """Time ONE adaptive iteration of the CPU oracle (the numpy/scipy restatement of the reference's numpy
     path: Hessian + SCI update + two gradients + lstsq, mbar_solvers.py:581-594) on the first ``n_sample``
@@ -190,14 +209,14 @@ def main():
             "roofline": {
                 "kernel": "k_gram_pair<8> (fp64 MFMA W^T W)" if K == 128 else "k_gram",
                 "bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("k_gram", K, n_loc),
                 "avg_launch_ms": gram_avg, "launches": gram_n, "algorithmic_flop_per_launch": flops,
                 "measured_mfma_f64_peak_tflops": mfma_peak,
             },
             "roofline_lse": {
                 "kernel": "k_lse (log-sum-exp + per-state sums, 2 candidates per sweep)",
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("k_lse<8, 2", K, n_loc),
                 "avg_launch_ms": lse_avg, "launches": lse_n, "algorithmic_bytes_per_launch": bytes_pass,
             },
             "cpu_baseline": cpu,

@@ -596,7 +596,7 @@ int mbar_device_info(int device, char* name, int name_len, int* compute_units, i
     hipError_t e = hipGetDeviceProperties(&p, device);
     if (e != hipSuccess) return fail(nullptr, MBAR_ERR_NODEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
     if (name && name_len > 0) {
-        std::snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+        std::snprintf(name, (size_t)name_len, "%s (%s)", p.name[0] ? p.name : "AMD Instinct MI355X", p.gcnArchName);
     }
     if (compute_units) *compute_units = p.multiProcessorCount;
     if (total_mem_bytes) *total_mem_bytes = (int64_t)p.totalGlobalMem;

@@ -750,18 +750,21 @@ k_sci_update(const double* __restrict__ psum, const double* __restrict__ Nk, con
     }
 }
 
-// fp64 MFMA peak probe: 4 independent accumulators per wave, nothing else in the loop.
+// fp64 MFMA peak probe: 4 independent accumulators per wave, nothing else in the loop
+// (same kernel as tools/mfma_peak.hip; 64 cycles per instruction per SIMD on gfx950).
 __global__ void __launch_bounds__(256)
 k_mfma_peak(int iters, double* sink) {
-    v4d c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    v4d c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = v4d{0.0, 0.0, 0.0, 0.0};
     const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int i = 0; i < iters; ++i) {
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, c3, 0, 0, 0);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[i], 0, 0, 0);
     }
-    const double v = c0[0] + c1[1] + c2[2] + c3[3];
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v += c[i][0] + c[i][3];
     if (v == 12345.678) sink[threadIdx.x] = v;  // never true: keeps the loop alive
 }
 
