@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="columns for the CPU baseline (0 = skip)")
     ap.add_argument("--staging", type=int, default=0)
+    ap.add_argument("--lse-variant", type=int, default=0)
+    ap.add_argument("--gram-variant", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +138,8 @@ def main():
     info = device_info(local_rank)
     dm = DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=rank * n_loc, N_local=n_loc, device=local_rank)
     dm.set_option("staging", args.staging)
+    dm.set_option("lse_variant", args.lse_variant)
+    dm.set_option("gram_variant", args.gram_variant)
     dm.set_Nk(N_k)
     allreduce = "none"
     if world > 1:
@@ -207,7 +211,7 @@ def main():
                 "allreduce": allreduce, "device": info["name"], "solver_iterations_per_sec": it_per_s,
             },
             "roofline": {
-                "kernel": "k_gram_pair<8> (fp64 MFMA W^T W)" if K == 128 else "k_gram",
+                "kernel": ("k_gram_xchg<8>" if args.gram_variant == 0 else "k_gram_pair<8>") + " (fp64 MFMA W^T W)" if K == 128 else "k_gram",
                 "bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("k_gram", K, n_loc),
                 "avg_launch_ms": gram_avg, "launches": gram_n, "algorithmic_flop_per_launch": flops,

@@ -71,6 +71,7 @@ struct mbar_ctx {
     hipStream_t stream = nullptr;
     int64_t K = 0, Kp = 0, N = 0, ld = 0;
     bool have_Nk = false;
+    bool u_checked = false, u_poison = false;  // NaN / -inf entries found in the matrix
     std::vector<double> Nk, lnNk;   // K
     std::vector<int> sampled;       // indices with N_k > 0
     // device
@@ -90,6 +91,7 @@ struct mbar_ctx {
     double* f_hist = nullptr;       // SCI f history [batch][Kp]
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1;
+    int64_t opt_lse_variant = 0, opt_gram_variant = 0;
     // comm
     ncclComm_t comm = nullptr;
     mbar_allreduce_fn host_reduce = nullptr;
@@ -167,6 +169,10 @@ int sync_stream(mbar_ctx* c) {
     return MBAR_OK;
 }
 
+// Scan the matrix once after it changed; a NaN or -inf entry poisons every reduced output (reference
+// behaviour: logsumexp over all samples propagates it into every f_k).
+int refresh_poison(mbar_ctx* c);
+
 // ---- device buffer helpers -------------------------------------------------------------------
 int ensure(mbar_ctx* c, double** p, size_t* have, size_t want) {
     if (*have >= want) return MBAR_OK;
@@ -186,6 +192,25 @@ inline double* d_lnNk(mbar_ctx* c) { return c->small + 5 * c->Kp; }          // 
 inline double* d_delta(mbar_ctx* c) { return c->small + 6 * c->Kp; }         // [256]
 inline double* d_misc(mbar_ctx* c) { return c->small + 6 * c->Kp + 256; }    // [4*Kp]
 inline size_t small_doubles(int64_t Kp) { return (size_t)(10 * Kp + 256); }
+
+int refresh_poison(mbar_ctx* c) {
+    if (c->u_checked) return MBAR_OK;
+    int* dflags = reinterpret_cast<int*>(d_delta(c) + 255);
+    HIPCHK(c, hipMemsetAsync(dflags, 0, sizeof(int), c->stream));
+    HIPCHK(c, launch_check_u(c->stream, c->u, c->ld, c->N, c->K, dflags));
+    int h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, dflags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->u_poison = h != 0;
+    c->u_checked = true;
+    return MBAR_OK;
+}
+bool f_is_finite(const mbar_ctx* c, const double* f, int nf) {
+    for (int i = 0; i < nf; ++i)
+        for (int64_t k = 0; k < c->K; ++k)
+            if (c->Nk[k] > 0.0 && !std::isfinite(f[(size_t)i * c->K + k])) return false;
+    return true;
+}
 
 // ---- collectives -------------------------------------------------------------------------------
 int allreduce_dev(mbar_ctx* c, double* dev, int64_t count, int op) {
@@ -243,7 +268,7 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
     if (use_fast(c)) {
         const int nb = (int)(rows / 16);
         const int64_t ntiles = (c->N + TS - 1) / TS;
-        LaunchGeom g = lse_geometry(nb, c->num_cu, ntiles, c->opt_grid);
+        LaunchGeom g = lse_geometry(nb, nf, c->num_cu, ntiles, c->opt_grid, (int)c->opt_lse_variant);
         const size_t rec = (size_t)nf * rows;
         int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rec + nf));
         if (rc) return rc;
@@ -332,10 +357,10 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
     const bool dma = c->opt_staging == 0;
     for (const auto& it : plan.items) {
         const int tile_rows = it.diag ? it.nb * 16 : 128;
-        LaunchGeom g = gram_geometry(tile_rows, c->num_cu, ntiles, c->opt_grid);
+        LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid, (int)c->opt_gram_variant);
         const size_t rec = (size_t)it.nblk * 256;
         const size_t prec = it.diag ? (size_t)it.nb * 16 : 0;
-        int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rec + prec));
+        int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec + (size_t)g.psum_records * prec);
         if (rc) return rc;
         rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * rec);
         if (rc) return rc;
@@ -354,7 +379,7 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
             ScopedTimer t(c, MBAR_TIMER_REDUCE);
             HIPCHK(c, launch_reduce(c->stream, gp, g.nwaves, (int64_t)rec, c->scratch, c->red + red_off + it.off * 256));
             if (it.diag)
-                HIPCHK(c, launch_reduce(c->stream, pp, g.nwaves, (int64_t)prec, c->scratch, c->red + ps_off + it.ri));
+                HIPCHK(c, launch_reduce(c->stream, pp, g.psum_records, (int64_t)prec, c->scratch, c->red + ps_off + it.ri));
         }
     }
     return MBAR_OK;
@@ -411,6 +436,18 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
     const bool want_gram = (flags & MBAR_EVAL_GRAM) != 0;
     const bool use_off = (flags & MBAR_EVAL_USE_OFFSET) != 0;
     if (use_off && !c->dn) return fail(c, MBAR_ERR_STATE, "objective offset requested but not set");
+    {
+        int prc = refresh_poison(c);
+        if (prc) return prc;
+        if (c->u_poison || !f_is_finite(c, f, nf)) {
+            const double qnan = std::numeric_limits<double>::quiet_NaN();
+            if (psum) std::fill(psum, psum + (size_t)nf * c->K, qnan);
+            if (sumlogden) std::fill(sumlogden, sumlogden + nf, qnan);
+            if (want_gram && gram) std::fill(gram, gram + (size_t)c->K * c->K, qnan);
+            c->error = c->u_poison ? "u_kn contains NaN or -inf: all sums are NaN" : "f_k is not finite: all sums are NaN";
+            return MBAR_OK;
+        }
+    }
     const int64_t rows = lse_rows(c);
     GramPlan plan;
     if (want_gram) plan = gram_plan(c->Kp);
@@ -689,6 +726,8 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "force_generic") c->opt_force_generic = value;
     else if (k == "check_finite") c->opt_check_finite = value;
     else if (k == "timing") c->opt_timing = value;
+    else if (k == "lse_variant") c->opt_lse_variant = value;
+    else if (k == "gram_variant") c->opt_gram_variant = value;
     else if (k == "sci_batch") c->opt_sci_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;
@@ -704,6 +743,7 @@ int mbar_ctx_upload_u(mbar_ctx* c, const double* u_host, int64_t ld_host, int64_
     HIPCHK(c, hipMemcpy2DAsync(c->u + col0_dev, (size_t)c->ld * sizeof(double), u_host + col0_host,
                                (size_t)ld_host * sizeof(double), (size_t)ncols * sizeof(double), (size_t)c->K,
                                hipMemcpyHostToDevice, c->stream));
+    c->u_checked = false;
     return sync_stream(c);
 }
 
@@ -732,6 +772,7 @@ int mbar_ctx_generate_harmonic(mbar_ctx* c, uint64_t seed, const double* O_k, co
         ScopedTimer t(c, MBAR_TIMER_OTHER);
         HIPCHK(c, launch_generate_harmonic(c->stream, c->u, c->ld, c->N, c->K, seed, dO, dK, dC, n_global0));
     }
+    c->u_checked = false;
     return sync_stream(c);
 }
 
@@ -827,6 +868,10 @@ int mbar_logden(mbar_ctx* c, const double* f, double* out_n) {
     HIPCHK(c, hipSetDevice(c->device));
     int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
+    if (c->u_poison || !f_is_finite(c, f, 1)) {
+        std::fill(out_n, out_n + c->N, std::numeric_limits<double>::quiet_NaN());
+        return MBAR_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(out_n, c->logden[0], (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return sync_stream(c);
 }
@@ -836,6 +881,10 @@ int mbar_lognum(mbar_ctx* c, const double* f, double* lognum) {
     HIPCHK(c, hipSetDevice(c->device));
     int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
+    if (c->u_poison || !f_is_finite(c, f, 1)) {
+        std::fill(lognum, lognum + c->K, std::numeric_limits<double>::quiet_NaN());
+        return MBAR_OK;
+    }
     const int64_t nch = lognum_chunks(c->N);
     rc = ensure(c, &c->lognum_part, &c->lognum_part_doubles, (size_t)2 * c->K * nch + 2 * c->K);
     if (rc) return rc;
@@ -878,6 +927,10 @@ int mbar_logw(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out) {
     HIPCHK(c, hipSetDevice(c->device));
     int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
+    if (c->u_poison || !f_is_finite(c, f, 1)) {
+        for (int64_t k = 0; k < c->K; ++k) std::fill(out_kn + k * ld_out, out_kn + k * ld_out + c->N, std::numeric_limits<double>::quiet_NaN());
+        return MBAR_OK;
+    }
     // stream the result through a device staging buffer in row blocks to bound extra memory
     const int64_t rows_per = std::max<int64_t>(1, std::min<int64_t>(c->K, (int64_t)((256ull << 20) / ((size_t)c->ld * 8))));
     double* stage = nullptr;
@@ -906,6 +959,11 @@ int mbar_gram_w(mbar_ctx* c, const double* f, double* gramW, double* wsum) {
     HIPCHK(c, hipSetDevice(c->device));
     int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
+    if (c->u_poison || !f_is_finite(c, f, 1)) {
+        if (gramW) std::fill(gramW, gramW + (size_t)c->K * c->K, std::numeric_limits<double>::quiet_NaN());
+        if (wsum) std::fill(wsum, wsum + c->K, std::numeric_limits<double>::quiet_NaN());
+        return MBAR_OK;
+    }
     GramPlan plan = gram_plan(c->Kp);
     const size_t n_gram = plan.total_blocks * 256, total = n_gram + (size_t)c->Kp;
     rc = ensure_red(c, total);
@@ -1062,6 +1120,18 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     const int first = c->sampled[0];
     mbar_solve_result res;
     std::memset(&res, 0, sizeof(res));
+    {
+        int prc = refresh_poison(c);
+        if (prc) return prc;
+        if (c->u_poison || !f_is_finite(c, f_inout, 1)) {  // NaN in, NaN out; isnan(max_delta) counts as converged (:636)
+            for (int64_t k = 0; k < K; ++k)
+                if (c->Nk[k] > 0.0) f_inout[k] = std::numeric_limits<double>::quiet_NaN();
+            res.success = 1;
+            res.max_delta = std::numeric_limits<double>::quiet_NaN();
+            if (result) *result = res;
+            return MBAR_OK;
+        }
+    }
     const int64_t rows = lse_rows(c);
     const int64_t batch = c->opt_sci_batch;
     if (!c->f_hist) HIPCHK(c, hipMalloc((void**)&c->f_hist, (size_t)256 * Kp * sizeof(double)));

@@ -25,15 +25,18 @@ inline int lse_nb_for(int64_t Kp) {
 }
 
 struct LaunchGeom {
-    int blocks;       // grid size
-    int waves;        // waves per block
-    int nwaves;       // blocks * waves = number of per-wave partial records
+    int blocks;        // grid size
+    int waves;         // waves per block
+    int nwaves;        // number of partial records of the main output (per wave, or per tile stream)
+    int psum_records;  // number of partial records of the per-state sums (Gram kernels)
+    int variant;       // kernel variant chosen (see lse_geometry / gram_geometry)
     size_t lds_bytes;
 };
 
 // ---- evaluation pass -------------------------------------------------------------------------
 // psum_part: [nwaves][nf][16*nb], obj_part: [nwaves][nf]; logden0/1 may be null (not stored).
-LaunchGeom lse_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
+// variant 0: paired waves for nb >= 6 (two waves share a tile stream), 1: always one tile stream per wave
+LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant);
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g,
                       const double* u, int64_t ld, int64_t N, const double* aden /*[nf][16nb]*/,
                       double* logden0, double* logden1, const double* dn,
@@ -43,7 +46,9 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
 // Diagonal panel: states [row0, row0+16nb) against themselves, nblk = nb(nb+1)/2 blocks, block b
 // enumerates (I,J) with I<=J in row-major order.  Off-diagonal panel pair: nbi x nbj blocks.
 // gram_part: [nwaves][nblk][256], psum_part: [nwaves][16*nb] (diag only; may be null for off-diag).
-LaunchGeom gram_geometry(int tile_rows, int num_cu, int64_t ntiles, int64_t grid_override);
+// nb8_variant (full 128-state diagonal panel only): 0 = paired waves with operand exchange, 1 = paired waves
+// that both compute every operand
+LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, int64_t grid_override, int nb8_variant);
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u,
                             int64_t ld, int64_t N, const double* anum /*indexed from row0*/,
                             const double* logden, int64_t row0, double* gram_part, double* psum_part);
@@ -72,6 +77,8 @@ hipError_t launch_lognum_merge(hipStream_t s, const double* pmax, const double* 
                                int64_t nchunks, double* out_max /*[K]*/, double* out_sum /*[K]*/);
 hipError_t launch_logw(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K,
                        const double* f, const double* logden, double* out, int64_t ld_out);
+// flags |= 1 if any u[k][n] is NaN, |= 2 if any is -inf (k < K, n < N)
+hipError_t launch_check_u(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, int* flags);
 hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_t N, int64_t K,
                                     uint64_t seed, const double* O_k, const double* K_k,
                                     const int64_t* cumN /*[K+1]*/, int64_t n_global0);

@@ -61,6 +61,40 @@ __device__ __forceinline__ double wave_max(double x) {
     return x;
 }
 
+// exp(x) built for instruction count (gfx950 issues an fp64 VALU op every ~5.5 cycles per SIMD and fp64 MFMA
+// does not overlap with VALU, so every instruction here is kernel time):
+//   t = max(x log2 e, -1100);  k = rint(t);  r = t - k in [-1/2, 1/2];  2^r by a degree-11 near-minimax
+//   polynomial (tools/gen_exp2_poly.py, 1.6e-17 relative);  result = ldexp(poly, k).
+// 17 VALU instructions against ~27 for the library exp.  < 1 ulp for |x| <~ 20 (tools/exp2test.c); the relative
+// error grows like |x| 1.6e-16 beyond that, where the value itself is < 2e-9.  exp(-inf) = 0 through the clamp,
+// overflow gives inf through ldexp; NaN arguments are laundered to 0 by the clamp, which is why NaN / -inf
+// entries of u_kn and non-finite f_k are detected at the boundary instead (mbar_capi.cpp).
+__device__ __forceinline__ double exp_fast(double x) {
+    const double t = fmax(x * 0x1.71547652b82fep+0, -1100.0);
+    const double k = __builtin_rint(t);
+    const double r = t - k;
+    double p = 0x1.ea93555555555p-32;
+    p = fma(p, r, 0x1.e624faaaaaaabp-28);
+    p = fma(p, r, 0x1.b524773555555p-24);
+    p = fma(p, r, 0x1.62bfc14000000p-20);
+    p = fma(p, r, 0x1.ffcbfca9a0000p-17);
+    p = fma(p, r, 0x1.43091311d9600p-13);
+    p = fma(p, r, 0x1.5d87fe7896208p-10);
+    p = fma(p, r, 0x1.3b2ab6fb9edc8p-7);
+    p = fma(p, r, 0x1.c6b08d704a11ep-5);
+    p = fma(p, r, 0x1.ebfbdff82c5b0p-3);
+    p = fma(p, r, 0x1.62e42fefa39efp-1);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+// 1 / s for s > 0: hardware estimate + two Newton steps (the divide expansion costs twice as many instructions)
+__device__ __forceinline__ double recip_fast(double s) {
+    double r = __builtin_amdgcn_rcp(s);
+    r = fma(fma(-s, r, 1.0), r, r);
+    r = fma(fma(-s, r, 1.0), r, r);
+    return r;
+}
+
 // Stage one wave tile (ROWS state rows x 16 samples starting at column n0) into `dst`.
 // DMA instruction j fills LDS bytes [1024 j, 1024 j + 1024): lane l -> row 8j + (l >> 3),
 // positions 2(l & 7), 2(l & 7)+1 of that row, which hold samples (pos - (row & 14)) & 15.
@@ -207,9 +241,9 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                 m = row16_max(m);
                 double s = 0.0;
 #pragma unroll
-                for (int I = 0; I < NB; ++I) { x[I] = exp(x[I] - m); s += x[I]; }
+                for (int I = 0; I < NB; ++I) { x[I] = exp_fast(x[I] - m); s += x[I]; }
                 s = row16_sum(s);
-                const double r = valid ? 1.0 / s : 0.0;
+                const double r = valid ? recip_fast(s) : 0.0;
 #pragma unroll
                 for (int I = 0; I < NB; ++I) acc[f][I] = fma(x[I], r, acc[f][I]);
                 if ((ks & 3) == g) { mm[f] = m; ss[f] = s; }
@@ -244,6 +278,133 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         const double o = wave_sum(obj[f]);
         if (lane == 0) obj_part[gw * NF + f] = o;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass, paired-wave variant for wide panels (NB >= 6), where one 16-sample tile is 12-32 KB
+// and LDS (not registers) would limit the unpaired kernel to one wave per SIMD.  Two waves share each
+// tile stream (workgroup = STREAMS streams x 2 halves, one barrier per tile):
+//   NF == 2: half h evaluates candidate f_h on all four 4-sample groups,
+//   NF == 1: half h evaluates groups {2h, 2h+1}.
+// Each wave therefore carries the register footprint of a single-f kernel and two waves fit per SIMD.
+// Partial record of half h of stream gs: index 2 gs + h (for NF == 2 this is the [stream][f] layout).
+// ---------------------------------------------------------------------------------------------
+template <int NB, int NF, bool DMA, int HALF, int STREAMS>
+__device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+                                              const double* __restrict__ aden, double* __restrict__ logden_out,
+                                              const double* __restrict__ dn, double* __restrict__ psum_part,
+                                              double* __restrict__ obj_part, char* smem, int lane, int stream) {
+    constexpr int ROWS = NB * 16;
+    constexpr int TILE_BYTES = ROWS * TS * 8;
+    constexpr int NDMA = ROWS / 8;
+    constexpr int G0 = NF == 2 ? 0 : 2 * HALF, G1 = NF == 2 ? GROUPS : 2 * HALF + 2;
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem + stream * (2 * TILE_BYTES);
+    const int64_t gs = (int64_t)blockIdx.x * STREAMS + stream;
+    const int64_t S = (int64_t)gridDim.x * STREAMS;
+    const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
+    const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;  // block-uniform trip count
+    const RowIdentity rows{0};
+
+    double a[NB], acc[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        a[I] = aden[(NF == 2 ? HALF : 0) * ROWS + 16 * I + ks];
+        acc[I] = 0.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) settle(a[I]);
+    double obj = 0.0;
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    auto stage_mine = [&](int64_t tile, char* dst) {
+#pragma unroll
+        for (int j = HALF; j < NDMA; j += 2) {
+            const int tr = 8 * j + (lane >> 3);
+            const int pp = 2 * (lane & 7);
+            const int smp = (pp - (tr & 14)) & 15;
+            const double* src = u + rows(tr) * ld + tile * TS + smp;
+            if constexpr (DMA) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+            } else {
+                *reinterpret_cast<double2*>(dst + j * 1024 + lane * 16) = *reinterpret_cast<const double2*>(src);
+            }
+        }
+    };
+
+    int64_t t = gs;
+    int cur = 0;
+    if (t < ntiles) stage_mine(t, buf);
+    for (int64_t it = 0; it < niter; ++it, t += S) {
+        wait_vm<0>();
+        __syncthreads();
+        const bool active = t < ntiles;
+        char* cbuf = buf + cur * TILE_BYTES;
+        if (active && t + S < ntiles) stage_mine(t + S, buf + (cur ^ 1) * TILE_BYTES);
+        if (active) {
+            double mm = 0.0, ss = 1.0;
+#pragma unroll
+            for (int g = G0; g < G1; ++g) {
+                double x[NB];
+                double m = -INFINITY;
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
+                    x[I] = a[I] - uv;
+                    m = fmax(m, x[I]);
+                }
+                const bool valid = (t * TS + 4 * g + ns) < N;
+                m = row16_max(m);
+                double sm = 0.0;
+#pragma unroll
+                for (int I = 0; I < NB; ++I) { x[I] = exp_fast(x[I] - m); sm += x[I]; }
+                sm = row16_sum(sm);
+                const double r = valid ? recip_fast(sm) : 0.0;
+#pragma unroll
+                for (int I = 0; I < NB; ++I) acc[I] = fma(x[I], r, acc[I]);
+                if ((ks & 3) == g) { mm = m; ss = sm; }
+            }
+            const int64_t n = t * TS + 4 * (ks & 3) + ns;
+            const bool writer = (ks >= G0) && (ks < G1) && (n < N);
+            const double ldv = mm + log(ss);
+            if (writer) {
+                if (logden_out) logden_out[n] = ldv;
+                obj += dn ? (ldv - dn[n]) : ldv;
+            }
+        }
+        cur ^= 1;
+    }
+    const int64_t rec = 2 * gs + HALF;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        double v = acc[I];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) psum_part[rec * ROWS + 16 * I + lane] = v;
+    }
+    const double o = wave_sum(obj);
+    if (lane == 0) obj_part[rec] = o;
+}
+
+template <int NB, int NF, bool DMA>
+__global__ void __launch_bounds__(NB <= 8 ? 512 : 256, 2)
+k_lse_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+           const double* __restrict__ aden, double* __restrict__ logden0, double* __restrict__ logden1,
+           const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STREAMS = NB <= 8 ? 4 : 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stream = wave % STREAMS;
+    if (wave / STREAMS == 0)
+        lse_pair_body<NB, NF, DMA, 0, STREAMS>(u, ld, N, ntiles, aden, logden0, dn, psum_part, obj_part, smem, lane, stream);
+    else
+        lse_pair_body<NB, NF, DMA, 1, STREAMS>(u, ld, N, ntiles, aden, NF == 2 ? logden1 : logden0, dn, psum_part,
+                                               obj_part, smem, lane, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -324,12 +485,12 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const bool valid = (t * TS + 4 * g + ns) < N;
+            const double lde = valid ? ldc[g] : INFINITY;  // padded samples: exp(-inf) = 0
             double p[NBT];
 #pragma unroll
             for (int I = 0; I < NBT; ++I) {
                 const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
-                const double e = exp(a[I] - uv - ldc[g]);
-                p[I] = valid ? e : 0.0;
+                p[I] = exp_fast((a[I] - lde) - uv);
                 ps[I] += p[I];
             }
             if constexpr (DIAG) {
@@ -463,12 +624,12 @@ __device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g) {
                 const bool valid = (t * TS + 4 * g + ns) < N;
+                const double lde = valid ? ldc[g] : INFINITY;
                 double p[NB];
 #pragma unroll
                 for (int I = 0; I < NB; ++I) {
                     const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
-                    const double e = exp(a[I] - uv - ldc[g]);
-                    p[I] = valid ? e : 0.0;
+                    p[I] = exp_fast((a[I] - lde) - uv);
                 }
 #pragma unroll
                 for (int I = 0; I < NB / 2; ++I) ps[I] += p[HALF * (NB / 2) + I];
@@ -508,6 +669,143 @@ k_gram_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         gram_pair_body<NB, DMA, 0>(u, ld, N, ntiles, anum, logden, row0, gram_part, psum_part, smem, lane, stream);
     else
         gram_pair_body<NB, DMA, 1>(u, ld, N, ntiles, anum, logden, row0, gram_part, psum_part, smem, lane, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram pass, paired waves with operand exchange (default for a full 128-state panel).
+// Measured on gfx950: VALU work does not overlap with v_mfma_f64 even across waves of a SIMD (the fp64
+// matrix op occupies the vector ALU), so every exp the two waves of a stream compute twice costs real
+// time.  Here half h computes p only for groups {2h, 2h+1} (16 exp per tile instead of 32), publishes
+// them in LDS in operand order ([group][I][lane], conflict-free ds_write/ds_read_b64) and reads the
+// partner's; each wave still owns every other upper-triangular block.  The u tile is single-buffered:
+// it is dead once both waves have read their groups (barrier 2), and the DMA of the next tile then
+// overlaps the MFMA phase.
+//   [wait own DMA] [barrier 1] [read u, exp, write p] [barrier 2] [DMA next tile] [read partner p, MFMA]
+// Partial records: gram per stream (each half writes its own blocks), psum per wave (2 gs + h).
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool DMA, int HALF>
+__device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+                                               const double* __restrict__ anum, const double* __restrict__ logden,
+                                               int64_t row0, double* __restrict__ gram_part,
+                                               double* __restrict__ psum_part, char* smem, int lane, int stream) {
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int L_BYTES = TS * 8;
+    constexpr int P_BYTES = GROUPS * NB * 64 * 8;
+    constexpr int STREAM_BYTES = U_BYTES + L_BYTES + P_BYTES;
+    constexpr int NDMA = ROWS / 8;
+    constexpr int NBLK = NB * (NB + 1) / 2;
+    constexpr int NMINE = HALF == 0 ? (NBLK + 1) / 2 : NBLK / 2;
+    constexpr int STREAMS = 4;
+    constexpr int G0 = 2 * HALF, P0 = 2 * (1 - HALF);  // own groups G0, G0+1; partner's P0, P0+1
+    const int ks = lane & 15, ns = lane >> 4;
+    char* ubuf = smem + stream * STREAM_BYTES;
+    char* lbuf = ubuf + U_BYTES;
+    char* pbuf = lbuf + L_BYTES;
+    const int64_t gs = (int64_t)blockIdx.x * STREAMS + stream;
+    const int64_t S = (int64_t)gridDim.x * STREAMS;
+    const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
+    const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;
+    const RowIdentity rows{row0};
+
+    double a[NB], ps[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) { a[I] = anum[16 * I + ks]; ps[I] = 0.0; }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) settle(a[I]);
+    v4d acc[NMINE];
+#pragma unroll
+    for (int b = 0; b < NMINE; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    const int rd_base = ks * (TS * 8);
+    int pos[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) pos[gi] = ((4 * (G0 + gi) + ns + (ks & 14)) & 15) * 8;
+
+    auto stage_mine = [&](int64_t tile) {
+#pragma unroll
+        for (int j = HALF; j < NDMA; j += 2) {
+            const int tr = 8 * j + (lane >> 3);
+            const int pp = 2 * (lane & 7);
+            const int smp = (pp - (tr & 14)) & 15;
+            const double* src = u + rows(tr) * ld + tile * TS + smp;
+            if constexpr (DMA) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ubuf + j * 1024), 16, 0, 0);
+            } else {
+                *reinterpret_cast<double2*>(ubuf + j * 1024 + lane * 16) = *reinterpret_cast<const double2*>(src);
+            }
+        }
+        if constexpr (HALF == 0) stage_vec16<DMA>(logden, tile * TS, lbuf, lane);
+    };
+
+    int64_t t = gs;
+    if (t < ntiles) stage_mine(t);
+    for (int64_t it = 0; it < niter; ++it, t += S) {
+        wait_vm<0>();
+        __syncthreads();  // barrier 1: tile landed; everybody is done with the previous tile's operands
+        const bool active = t < ntiles;
+        double p_own[2][NB];
+        if (active) {
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int g = G0 + gi;
+                const bool valid = (t * TS + 4 * g + ns) < N;
+                const double ldc = valid ? *reinterpret_cast<const double*>(lbuf + (4 * g + ns) * 8) : INFINITY;
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    const double uv = *reinterpret_cast<const double*>(ubuf + I * (16 * TS * 8) + rd_base + pos[gi]);
+                    p_own[gi][I] = exp_fast((a[I] - ldc) - uv);
+                    ps[I] += p_own[gi][I];
+                    *reinterpret_cast<double*>(pbuf + ((g * NB + I) * 64 + lane) * 8) = p_own[gi][I];
+                }
+            }
+        }
+        __syncthreads();  // barrier 2: operands published, u tile dead
+        if (active && t + S < ntiles) stage_mine(t + S);
+        if (active) {
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) gram_half_group<NB, HALF, NMINE>(p_own[gi], acc);
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                double pp[NB];
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+                    pp[I] = *reinterpret_cast<const double*>(pbuf + (((P0 + gi) * NB + I) * 64 + lane) * 8);
+                gram_half_group<NB, HALF, NMINE>(pp, acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < NMINE; ++sl) {
+        const int b = 2 * sl + HALF;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gram_part[((gs * NBLK + b) * 4 + r) * 64 + lane] = acc[sl][r];
+    }
+    if (psum_part) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = ps[I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(2 * gs + HALF) * ROWS + 16 * I + lane] = v;
+        }
+    }
+}
+
+template <int NB, bool DMA>
+__global__ void __launch_bounds__(512, 2)
+k_gram_xchg(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+            const double* __restrict__ anum, const double* __restrict__ logden, int64_t row0,
+            double* __restrict__ gram_part, double* __restrict__ psum_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stream = wave & 3;
+    if ((wave >> 2) == 0)
+        gram_xchg_body<NB, DMA, 0>(u, ld, N, ntiles, anum, logden, row0, gram_part, psum_part, smem, lane, stream);
+    else
+        gram_xchg_body<NB, DMA, 1>(u, ld, N, ntiles, anum, logden, row0, gram_part, psum_part, smem, lane, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -676,6 +974,21 @@ k_logw(const double* __restrict__ u, int64_t ld, int64_t N, const double* __rest
         out[k * ld_out + n] = fk - u[k * ld + n] - logden[n];
 }
 
+// Boundary check of the matrix: bit 0 = some entry is NaN, bit 1 = some entry is -inf (+inf is legal: such a
+// sample simply has zero weight in that state).  The fast exp of the sweeps launders NaN, so a poisoned matrix
+// is flagged here once and every reduced output is then reported as NaN, like the reference would compute.
+__global__ void __launch_bounds__(256)
+k_check_u(const double* __restrict__ u, int64_t ld, int64_t N, int* __restrict__ flags) {
+    const int64_t k = blockIdx.y;
+    int f = 0;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const double v = u[k * ld + n];
+        if (v != v) f |= 1;
+        if (v == -INFINITY) f |= 2;
+    }
+    if (f) atomicOr(flags, f);
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -778,29 +1091,53 @@ static int blocks_per_cu_for(size_t lds_bytes) {
     return b;
 }
 
-LaunchGeom lse_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override) {
+LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant) {
     LaunchGeom g;
-    g.waves = nb <= 8 ? 4 : 2;
-    g.lds_bytes = (size_t)g.waves * 2 * nb * 16 * TS * 8;
-    int64_t want = (ntiles + g.waves - 1) / g.waves;
-    int64_t cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
-    if (grid_override > 0) cap = grid_override;
-    if (want < 1) want = 1;
-    g.blocks = (int)(want < cap ? want : cap);
-    g.nwaves = g.blocks * g.waves;
+    const size_t tile = (size_t)nb * 16 * TS * 8;
+    g.variant = (nb >= 6 && variant == 0) ? 0 : 1;
+    int64_t cap;
+    if (g.variant == 0) {  // paired: STREAMS tile streams x 2 waves
+        const int streams = nb <= 8 ? 4 : 2;
+        g.waves = 2 * streams;
+        g.lds_bytes = (size_t)streams * 2 * tile;
+        int64_t want = (ntiles + streams - 1) / streams;
+        cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+        if (grid_override > 0) cap = grid_override;
+        if (want < 1) want = 1;
+        g.blocks = (int)(want < cap ? want : cap);
+        g.nwaves = g.blocks * streams * (nf == 2 ? 1 : 2);
+    } else {
+        g.waves = nb <= 8 ? 4 : 2;
+        g.lds_bytes = (size_t)g.waves * 2 * tile;
+        int64_t want = (ntiles + g.waves - 1) / g.waves;
+        cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+        if (grid_override > 0) cap = grid_override;
+        if (want < 1) want = 1;
+        g.blocks = (int)(want < cap ? want : cap);
+        g.nwaves = g.blocks * g.waves;
+    }
+    g.psum_records = g.nwaves;
     return g;
 }
 
-LaunchGeom gram_geometry(int tile_rows, int num_cu, int64_t ntiles, int64_t grid_override) {
+LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, int64_t grid_override, int nb8_variant) {
     LaunchGeom g;
     g.waves = 4;
-    g.lds_bytes = (size_t)g.waves * 2 * ((size_t)tile_rows * TS * 8 + TS * 8);  // tiles + their logden slots
-    int64_t want = (ntiles + g.waves - 1) / g.waves;
-    int64_t cap = num_cu;  // one wave per SIMD: the accumulators own the register file
+    g.variant = -1;
+    const size_t tile = (size_t)tile_rows * TS * 8 + TS * 8;  // u tile + its 16 logden values
+    g.lds_bytes = (size_t)4 * 2 * tile;
+    if (diag && tile_rows == 128) {
+        g.variant = nb8_variant == 1 ? 1 : 0;
+        g.waves = 8;
+        if (g.variant == 0) g.lds_bytes = (size_t)4 * (tile + (size_t)GROUPS * 8 * 64 * 8);  // single u buffer + operand buffer
+    }
+    int64_t want = (ntiles + 3) / 4;
+    int64_t cap = num_cu;  // the accumulators own the register file: one workgroup per CU
     if (grid_override > 0) cap = grid_override;
     if (want < 1) want = 1;
     g.blocks = (int)(want < cap ? want : cap);
-    g.nwaves = g.blocks * g.waves;
+    g.nwaves = g.blocks * 4;  // per wave (k_gram) or per tile stream (paired kernels)
+    g.psum_records = g.variant == 0 ? 2 * g.nwaves : g.nwaves;
     return g;
 }
 
@@ -820,10 +1157,35 @@ static hipError_t launch_lse_t(hipStream_t s, const LaunchGeom& g, const double*
     return hipGetLastError();
 }
 
+template <int NB, int NF, bool DMA>
+static hipError_t launch_lse_pair_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                    const double* aden, double* l0, double* l1, const double* dn,
+                                    double* psum_part, double* obj_part) {
+    auto kern = k_lse_pair<NB, NF, DMA>;
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TS - 1) / TS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, l0,
+                       l1, dn, psum_part, obj_part);
+    return hipGetLastError();
+}
+
 template <int NB>
 static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeom& g, const double* u,
                                 int64_t ld, int64_t N, const double* aden, double* l0, double* l1,
                                 const double* dn, double* pp, double* op) {
+    if constexpr (NB >= 6) {
+        if (g.variant == 0) {
+            if (nf == 1)
+                return dma ? launch_lse_pair_t<NB, 1, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
+                           : launch_lse_pair_t<NB, 1, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
+            return dma ? launch_lse_pair_t<NB, 2, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
+                       : launch_lse_pair_t<NB, 2, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
+        }
+    }
     if (nf == 1)
         return dma ? launch_lse_t<NB, 1, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
                    : launch_lse_t<NB, 1, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
@@ -875,12 +1237,31 @@ static hipError_t launch_gram_pair_t(hipStream_t s, const LaunchGeom& g, const d
     return hipGetLastError();
 }
 
+template <int NB, bool DMA>
+static hipError_t launch_gram_xchg_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                     const double* anum, const double* logden, int64_t row0, double* gp,
+                                     double* pp) {
+    auto kern = k_gram_xchg<NB, DMA>;
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TS - 1) / TS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(512), g.lds_bytes, s, u, ld, N, ntiles, anum, logden, row0, gp, pp);
+    return hipGetLastError();
+}
+
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
                             int64_t N, const double* anum, const double* logden, int64_t row0, double* gp,
                             double* pp) {
-    if (nb == 8)  // paired-wave variant: g.nwaves counts tile streams (4 per workgroup)
+    if (nb == 8) {  // paired-wave variants: g.nwaves counts tile streams (4 per workgroup)
+        if (g.variant == 0)
+            return dma ? launch_gram_xchg_t<8, true>(s, g, u, ld, N, anum, logden, row0, gp, pp)
+                       : launch_gram_xchg_t<8, false>(s, g, u, ld, N, anum, logden, row0, gp, pp);
         return dma ? launch_gram_pair_t<8, true>(s, g, u, ld, N, anum, logden, row0, gp, pp)
                    : launch_gram_pair_t<8, false>(s, g, u, ld, N, anum, logden, row0, gp, pp);
+    }
     switch (nb) {
 #define MBAR_CASE(NB_)                                                                                  \
     case NB_:                                                                                           \
@@ -960,6 +1341,14 @@ hipError_t launch_logw(hipStream_t s, const double* u, int64_t ld, int64_t N, in
     if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(k_logw, dim3((unsigned)bx, (unsigned)K), dim3(256), 0, s, u, ld, N, f, logden, out, ld_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_check_u(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, int* flags) {
+    int64_t bx = (N + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_check_u, dim3((unsigned)bx, (unsigned)K), dim3(256), 0, s, u, ld, N, flags);
     return hipGetLastError();
 }
 

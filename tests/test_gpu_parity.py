@@ -73,6 +73,30 @@ def test_l1_parity_fast_path(DM, K, N, staging):
         np.testing.assert_array_equal(dm.to_host(), u_kn)
 
 
+@pytest.mark.parametrize("K,N", [(96, 1500), (100, 777), (112, 800), (128, 2048), (128, 100000), (192, 1200), (256, 600)])
+@pytest.mark.parametrize("lse_variant,gram_variant,staging", [(0, 0, 0), (0, 0, 1), (1, 1, 0), (1, 0, 0), (0, 1, 1)])
+def test_l1_parity_kernel_variants(DM, K, N, lse_variant, gram_variant, staging):
+    """Wide panels (NB >= 6) have two implementations of each sweep: paired waves sharing a tile stream
+    (default) and one stream per wave; the full 128-state Gram panel has the operand-exchange (default) and
+    the duplicate-operand pairing.  All must agree with the oracle."""
+    u_kn, N_k, f = random_problem(K, N, seed=3 * K + N)
+    N_k = np.maximum(N_k, 1)  # every state sampled (N_k only acts as a weight vector here)
+    with DM.from_host(u_kn) as dm:
+        dm.set_option("lse_variant", lse_variant)
+        dm.set_option("gram_variant", gram_variant)
+        dm.set_option("staging", staging)
+        check_l1(dm, u_kn, N_k, f, tag=f"K={K} N={N} lse_variant={lse_variant} gram_variant={gram_variant} staging={staging}")
+        fs, rs = ms.solve_mbar_once(dm, N_k, np.zeros(K), method="self-consistent-iteration", tol=1e-10,
+                                    options=dict(maxiter=3))
+        f_ref = np.zeros(K)
+        for _ in range(3):
+            f_ref = oracle.self_consistent_update(u_kn, N_k, f_ref)
+            f_ref -= f_ref[0]
+        # states without samples are not touched by the device SCI loop
+        sampled = N_k > 0
+        np.testing.assert_allclose(fs[sampled] - fs[sampled][0], f_ref[sampled] - f_ref[sampled][0], rtol=1e-10, atol=1e-10)
+
+
 @pytest.mark.parametrize("K,N", [(129, 1000), (160, 700), (192, 1200), (200, 513), (256, 600)])
 def test_l1_parity_paneled_gram(DM, K, N):
     """128 < K <= 256: 2-wave evaluation kernel + 64-state Gram panels (diagonal and off-diagonal launches)."""
@@ -134,6 +158,33 @@ def test_invariances_and_extreme_energies(DM):
         f_bad[0] = 0
         pbad, _, _ = a.eval(f_bad)
         np.testing.assert_allclose(pbad[0], oracle.shard_partials(u_kn, N_k, f_bad)["psum"], rtol=1e-10, atol=1e-9)
+
+
+def test_nan_and_infinite_energies(DM):
+    """+inf energies are legal (zero weight, logsumexp semantics); a NaN or -inf entry poisons every sum, as it
+    does in the reference where the per-state log-sum-exp runs over all samples."""
+    u_kn, N_k, f = random_problem(10, 900, seed=31)
+    u_inf = u_kn.copy()
+    u_inf[3, ::7] = np.inf
+    u_inf[0, 5] = np.inf
+    with DM.from_host(u_inf) as dm:
+        check_l1(dm, u_inf, N_k, f, tag="+inf entries")
+    with np.errstate(all="ignore"):
+        for bad in (np.nan, -np.inf):
+            u_bad = u_kn.copy()
+            u_bad[4, 123] = bad
+            # (what scipy's logsumexp does with a NaN term depends on its version; here the whole matrix is poisoned)
+            with DM.from_host(u_bad) as dm:
+                assert not np.any(np.isfinite(ms.mbar_gradient(dm, N_k, f)))
+                assert not np.any(np.isfinite(ms.self_consistent_update(dm, N_k, f)))
+                assert not np.any(np.isfinite(ms.mbar_hessian(dm, N_k, f)))
+                fa, res = ms.solve_mbar_once(dm, N_k, np.zeros(10), method="adaptive", options=dict(maxiter=5))
+                assert not np.any(np.isfinite(fa[1:]))
+        with DM.from_host(u_kn) as dm:
+            f_nan = f.copy()
+            f_nan[2] = np.nan
+            assert not np.any(np.isfinite(ms.mbar_gradient(dm, N_k, f_nan)))
+            np.testing.assert_allclose(ms.mbar_gradient(dm, N_k, f), oracle.mbar_gradient(u_kn, N_k, f), rtol=1e-9, atol=1e-9)
 
 
 def test_objective_offset_matches_preconditioned_objective(DM):
