@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="columns for the CPU baseline (0 = skip)")
     ap.add_argument("--staging", type=int, default=0)
-    ap.add_argument("--lse-variant", type=int, default=0)
+    ap.add_argument("--lse-variant", type=int, default=1)
     ap.add_argument("--gram-variant", type=int, default=0)
     args = ap.parse_args()
 
@@ -218,7 +218,7 @@ def main():
                 "measured_mfma_f64_peak_tflops": mfma_peak,
             },
             "roofline_lse": {
-                "kernel": "k_lse (log-sum-exp + per-state sums, 2 candidates per sweep)",
+                "kernel": "k_lse<8,2> (log-sum-exp + per-state sums, 2 candidates per sweep, one exp per element)",
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("k_lse<8, 2", K, n_loc),
                 "avg_launch_ms": lse_avg, "launches": lse_n, "algorithmic_bytes_per_launch": bytes_pass,

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -91,7 +92,7 @@ struct mbar_ctx {
     double* f_hist = nullptr;       // SCI f history [batch][Kp]
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1;
-    int64_t opt_lse_variant = 0, opt_gram_variant = 0;
+    int64_t opt_lse_variant = 1, opt_gram_variant = 0;  // measured best: independent-wave LSE sweep, operand-exchange Gram
     // comm
     ncclComm_t comm = nullptr;
     mbar_allreduce_fn host_reduce = nullptr;
@@ -350,27 +351,26 @@ GramPlan gram_plan(int64_t Kp) {
 }
 
 // Gram pass with operand exp(anum_k - u_kn - logden_n); anum (device) has Kp entries.
-// Results: gram blocks at red + red_off (plan order), per-state operand sums at red + ps_off (Kp).
-int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, size_t ps_off,
-             const GramPlan& plan) {
+// Results: gram blocks at red + red_off (plan order).  The per-state operand sums are not accumulated on the
+// device: rows of p sum to one (sum_k p_nk = 1, resp. sum_k N_k W_nk = 1), so they are column sums of the
+// reduced Gram matrix (gram_operand_sums below).
+int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan) {
     const int64_t ntiles = (c->N + TS - 1) / TS;
     const bool dma = c->opt_staging == 0;
     for (const auto& it : plan.items) {
         const int tile_rows = it.diag ? it.nb * 16 : 128;
         LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid, (int)c->opt_gram_variant);
         const size_t rec = (size_t)it.nblk * 256;
-        const size_t prec = it.diag ? (size_t)it.nb * 16 : 0;
-        int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec + (size_t)g.psum_records * prec);
+        int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
         if (rc) return rc;
         rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * rec);
         if (rc) return rc;
         double* gp = c->part;
-        double* pp = c->part + (size_t)g.nwaves * rec;
         {
             ScopedTimer t(c, MBAR_TIMER_GRAM);
             if (it.diag)
                 HIPCHK(c, launch_gram_diag(c->stream, it.nb, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, logden,
-                                           it.ri, gp, pp));
+                                           it.ri, gp, nullptr));
             else
                 HIPCHK(c, launch_gram_off(c->stream, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
                                           logden, it.ri, it.rj, gp));
@@ -378,11 +378,19 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
         {
             ScopedTimer t(c, MBAR_TIMER_REDUCE);
             HIPCHK(c, launch_reduce(c->stream, gp, g.nwaves, (int64_t)rec, c->scratch, c->red + red_off + it.off * 256));
-            if (it.diag)
-                HIPCHK(c, launch_reduce(c->stream, pp, g.psum_records, (int64_t)prec, c->scratch, c->red + ps_off + it.ri));
         }
     }
     return MBAR_OK;
+}
+
+// out_j = sum_k w_k G[k][j]  (w = 1: operand sums of the p-mode Gram; w = N_k: sum_n W_nj of the W-mode Gram)
+void gram_operand_sums(const double* G, int64_t K, const double* w, double* out) {
+    for (int64_t j = 0; j < K; ++j) out[j] = 0.0;
+    for (int64_t k = 0; k < K; ++k) {
+        const double wk = w ? w[k] : 1.0;
+        if (wk == 0.0) continue;
+        for (int64_t j = 0; j < K; ++j) out[j] += wk * G[k * K + j];
+    }
 }
 
 // Scatter reduced blocks (host copy) into a dense symmetric K x K matrix.
@@ -453,13 +461,35 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
     if (want_gram) plan = gram_plan(c->Kp);
     const size_t n_ps = (size_t)nf * rows, n_obj = nf;
     const size_t off_gram = n_ps + n_obj, n_gram = plan.total_blocks * 256;
-    const size_t off_gps = off_gram + n_gram, n_gps = want_gram ? (size_t)c->Kp : 0;
-    const size_t total = off_gps + n_gps;
+    const size_t total = off_gram + n_gram;
     int rc = ensure_red(c, total);
     if (rc) return rc;
-    // aden -> device
+    // aden -> device.  The fused kernels evaluate a second candidate from the first one's exponentials through
+    // the per-state ratio c_k = exp(a'_k - a_k) (row 1); if the two candidates are so far apart that the ratio
+    // could over/underflow against the shared shift, fall back to two single-candidate sweeps.
     std::vector<double> h((size_t)nf * rows);
     for (int i = 0; i < nf; ++i) build_aden(c, f + (size_t)i * c->K, h.data() + (size_t)i * rows, rows);
+    bool split = false;
+    if (nf == 2 && use_fast(c)) {
+        double dmax = 0.0;
+        for (int64_t k = 0; k < rows; ++k) {
+            const double a0 = h[k], a1 = h[rows + k];
+            const double d = (std::isinf(a0) && std::isinf(a1)) ? 0.0 : a1 - a0;
+            dmax = std::max(dmax, std::fabs(d));
+            h[rows + k] = std::exp(d);
+        }
+        split = !(dmax < 300.0);
+    }
+    if (split) {
+        std::vector<double> ps((size_t)2 * c->K), sl(2);
+        int rc2 = eval_core(c, f, 1, flags, ld0, nullptr, ps.data(), &sl[0], gram);
+        if (rc2) return rc2;
+        rc2 = eval_core(c, f + c->K, 1, flags & ~MBAR_EVAL_GRAM, ld1, nullptr, ps.data() + c->K, &sl[1], nullptr);
+        if (rc2) return rc2;
+        if (psum) std::copy(ps.begin(), ps.end(), psum);
+        if (sumlogden) std::copy(sl.begin(), sl.end(), sumlogden);
+        return MBAR_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(d_aden(c), h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // h goes out of scope below; tiny copy
     rc = run_lse(c, nf, rows, ld0, ld1, use_off);
@@ -470,7 +500,7 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
         build_aden(c, f, an.data(), c->Kp);
         HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        rc = run_gram(c, d_anum(c), ld0, off_gram, off_gps, plan);
+        rc = run_gram(c, d_anum(c), ld0, off_gram, plan);
         if (rc) return rc;
     }
     rc = allreduce_dev(c, c->red, (int64_t)total, 0);
@@ -965,26 +995,29 @@ int mbar_gram_w(mbar_ctx* c, const double* f, double* gramW, double* wsum) {
         return MBAR_OK;
     }
     GramPlan plan = gram_plan(c->Kp);
-    const size_t n_gram = plan.total_blocks * 256, total = n_gram + (size_t)c->Kp;
+    const size_t n_gram = plan.total_blocks * 256, total = n_gram;
     rc = ensure_red(c, total);
     if (rc) return rc;
     std::vector<double> an((size_t)c->Kp, -std::numeric_limits<double>::infinity());
     for (int64_t k = 0; k < c->K; ++k) an[k] = f[k];
     HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    rc = run_gram(c, d_anum(c), c->logden[0], 0, n_gram, plan);
+    rc = run_gram(c, d_anum(c), c->logden[0], 0, plan);
     if (rc) return rc;
     rc = allreduce_dev(c, c->red, (int64_t)total, 0);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     rc = sync_stream(c);
     if (rc) return rc;
-    if (gramW) {
-        std::fill(gramW, gramW + (size_t)c->K * c->K, 0.0);
-        unpack_gram(plan, c->hred, c->K, gramW);
+    std::vector<double> Gtmp;
+    double* G = gramW;
+    if (!G) {
+        Gtmp.assign((size_t)c->K * c->K, 0.0);
+        G = Gtmp.data();
     }
-    if (wsum)
-        for (int64_t k = 0; k < c->K; ++k) wsum[k] = c->hred[n_gram + k];
+    std::fill(G, G + (size_t)c->K * c->K, 0.0);
+    unpack_gram(plan, c->hred, c->K, G);
+    if (wsum) gram_operand_sums(G, c->K, c->Nk.data(), wsum);  // sum_n W_nj = sum_k N_k (W^T W)_kj
     return MBAR_OK;
 }
 
@@ -1008,17 +1041,20 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     double max_delta = std::numeric_limits<double>::quiet_NaN();
     bool done = false;
     const GramPlan plan = gram_plan(c->Kp);
+    const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
+    double tA = 0, tH = 0, tB = 0, tC = 0;
     for (int64_t it = 0; it < maxiter && !done; ++it) {
         // ---- pass A: Gram at f with the known logden -> Hessian (mbar_solvers.py:581) ----
+        const double t_a0 = now_ms();
         {
-            const size_t n_gram = plan.total_blocks * 256, total = n_gram + (size_t)c->Kp;
+            const size_t n_gram = plan.total_blocks * 256, total = n_gram;
             rc = ensure_red(c, total);
             if (rc) return rc;
             std::vector<double> an((size_t)c->Kp);
             build_aden(c, f.data(), an.data(), c->Kp);
             HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            rc = run_gram(c, d_anum(c), c->logden[cur], 0, n_gram, plan);
+            rc = run_gram(c, d_anum(c), c->logden[cur], 0, plan);
             if (rc) return rc;
             rc = allreduce_dev(c, c->red, (int64_t)total, 0);
             if (rc) return rc;
@@ -1027,6 +1063,7 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
             if (rc) return rc;
             unpack_gram(plan, c->hred, K, gram.data());
         }
+        const double t_a1 = now_ms();
         for (int i = 0; i < m; ++i) {
             const int ki = c->sampled[i];
             g[i] = psum[ki] - c->Nk[ki];
@@ -1046,9 +1083,12 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
         const double shift = f_sci[first];
         for (int i = 0; i < m; ++i) f_sci[c->sampled[i]] -= shift;  // :588
         // ---- pass B: both candidates in one sweep (:589-594) ----
+        const double t_b0 = now_ms();
         const int sA = (cur + 1) % 3, sB = (cur + 2) % 3;
         rc = eval_core(c, cand.data(), 2, 0, c->logden[sA], c->logden[sB], psum2.data(), nullptr, nullptr);
         if (rc) return rc;
+        const double t_b1 = now_ms();
+        tA += t_a1 - t_a0; tH += t_b0 - t_a1; tB += t_b1 - t_b0;
         double gn_sci = 0.0, gn_nr = 0.0;
         for (int i = 0; i < m; ++i) {
             const int k = c->sampled[i];
@@ -1105,6 +1145,11 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     res.gnorm = std::sqrt(gn);
     res.max_delta = max_delta;
     res.wall_ms = now_ms() - t0;
+    if (dbg && res.iterations > 0)
+        std::fprintf(stderr, "[mbar] adaptive: %lld it, per it: passA %.3f ms, host solve %.3f ms, passB %.3f ms, total %.3f ms\n",
+                     (long long)res.iterations, tA / res.iterations, tH / res.iterations, tB / res.iterations,
+                     res.wall_ms / res.iterations);
+    (void)tC;
     std::copy(f.begin(), f.end(), f_inout);
     if (result) *result = res;
     return MBAR_OK;

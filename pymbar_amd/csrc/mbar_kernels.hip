@@ -61,31 +61,45 @@ __device__ __forceinline__ double wave_max(double x) {
     return x;
 }
 
-// exp(x) built for instruction count (gfx950 issues an fp64 VALU op every ~5.5 cycles per SIMD and fp64 MFMA
-// does not overlap with VALU, so every instruction here is kernel time):
-//   t = max(x log2 e, -1100);  k = rint(t);  r = t - k in [-1/2, 1/2];  2^r by a degree-11 near-minimax
-//   polynomial (tools/gen_exp2_poly.py, 1.6e-17 relative);  result = ldexp(poly, k).
-// 17 VALU instructions against ~27 for the library exp.  < 1 ulp for |x| <~ 20 (tools/exp2test.c); the relative
-// error grows like |x| 1.6e-16 beyond that, where the value itself is < 2e-9.  exp(-inf) = 0 through the clamp,
-// overflow gives inf through ldexp; NaN arguments are laundered to 0 by the clamp, which is why NaN / -inf
-// entries of u_kn and non-finite f_k are detected at the boundary instead (mbar_capi.cpp).
-__device__ __forceinline__ double exp_fast(double x) {
-    const double t = fmax(x * 0x1.71547652b82fep+0, -1100.0);
-    const double k = __builtin_rint(t);
-    const double r = t - k;
-    double p = 0x1.ea93555555555p-32;
-    p = fma(p, r, 0x1.e624faaaaaaabp-28);
-    p = fma(p, r, 0x1.b524773555555p-24);
-    p = fma(p, r, 0x1.62bfc14000000p-20);
-    p = fma(p, r, 0x1.ffcbfca9a0000p-17);
-    p = fma(p, r, 0x1.43091311d9600p-13);
-    p = fma(p, r, 0x1.5d87fe7896208p-10);
-    p = fma(p, r, 0x1.3b2ab6fb9edc8p-7);
-    p = fma(p, r, 0x1.c6b08d704a11ep-5);
-    p = fma(p, r, 0x1.ebfbdff82c5b0p-3);
-    p = fma(p, r, 0x1.62e42fefa39efp-1);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)k);
+// exp built for instruction count (gfx950 issues one fp64 VALU op per ~5.6 cycles per SIMD and fp64 MFMA does
+// not overlap with VALU -- profiles/r1_*microbench.txt -- so every fp64 instruction here is kernel time).
+// 2^(t/32) for t = 32 x log2(e):   s = rint(max(t, -35200));  z = t - s in [-1/2, 1/2];
+//   j = s & 31, q = s >> 5;   result = ldexp(T[j] * P(z), q),  T[j] = 2^(j/32) from a 256-byte LDS table
+//   (one 64-bank row: conflict-free for any lane pattern), P = degree-6 near-minimax polynomial of 2^(z/32)
+//   (tools/gen_exp2_table.py).  12 fp64 instructions (the library exp needs ~25), max error 1.9 ulp, mean
+//   0.4 ulp (tools/exp2tab_test.c).  exp(-inf) = 0 through the clamp, overflow gives inf through ldexp; NaN
+//   arguments are laundered to 0 by the clamp, which is why NaN / -inf entries of u_kn and non-finite f_k are
+//   detected at the boundary instead (mbar_capi.cpp).
+constexpr double LOG2E = 0x1.71547652b82fep+0, LN2 = 0x1.62e42fefa39efp-1;
+constexpr double LOG2E_32 = 32.0 * LOG2E, LN2_OVER_32 = LN2 / 32.0;
+constexpr int EXP_TABLE_BYTES = 256;
+__device__ const double EXP2_TABLE[32] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
+// every thread block copies the table into its LDS once (tbl must be 256-byte aligned); callers barrier after
+__device__ __forceinline__ void exp_table_init(char* tbl) {
+    if (threadIdx.x < 32) reinterpret_cast<double*>(tbl)[threadIdx.x] = EXP2_TABLE[threadIdx.x];
+}
+__device__ __forceinline__ double exp2s_fast(double t32, const char* tbl) {  // 2^(t32 / 32)
+    const double t = fmax(t32, -35200.0);
+    const double s = __builtin_rint(t);
+    const double z = t - s;
+    const int si = (int)s;
+    const double T = *reinterpret_cast<const double*>(tbl + ((si & 31) << 3));
+    double p = 0x1.4412492492492p-43;
+    p = fma(p, z, 0x1.5d88592492492p-35);
+    p = fma(p, z, 0x1.3b2ab695b6db7p-27);
+    p = fma(p, z, 0x1.c6b08d7038492p-20);
+    p = fma(p, z, 0x1.ebfbdff82c7f7p-13);
+    p = fma(p, z, 0x1.62e42fefa39efp-6);
+    p = fma(p, z, 1.0);
+    return ldexp(T * p, si >> 5);
 }
 // 1 / s for s > 0: hardware estimate + two Newton steps (the divide expansion costs twice as many instructions)
 __device__ __forceinline__ double recip_fast(double s) {
@@ -95,29 +109,172 @@ __device__ __forceinline__ double recip_fast(double s) {
     return r;
 }
 
+// In-lane reductions over the NB registers of a sample as a pairwise tree (dependent depth log2 NB instead of NB:
+// with one or two waves per SIMD the chain latency of fp64 ops is exposed).
+template <int NB>
+__device__ __forceinline__ double tree_max(const double (&x)[NB]) {
+    double t[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) t[i] = x[i];
+#pragma unroll
+    for (int n = NB; n > 1; n -= n / 2) {
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) t[i] = fmax(t[i], t[n - 1 - i]);
+    }
+    return t[0];
+}
+template <int NB>
+__device__ __forceinline__ double tree_sum(const double (&x)[NB]) {
+    double t[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) t[i] = x[i];
+#pragma unroll
+    for (int n = NB; n > 1; n -= n / 2) {
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) t[i] += t[n - 1 - i];
+    }
+    return t[0];
+}
+// 16-lane all-reduce of two independent values at once (the two dependency chains interleave)
+__device__ __forceinline__ void row16_max2(double& a, double& b) {
+    a = fmax(a, dpp_move<0xB1>(a));   b = fmax(b, dpp_move<0xB1>(b));
+    a = fmax(a, dpp_move<0x4E>(a));   b = fmax(b, dpp_move<0x4E>(b));
+    a = fmax(a, dpp_move<0x141>(a));  b = fmax(b, dpp_move<0x141>(b));
+    a = fmax(a, dpp_move<0x140>(a));  b = fmax(b, dpp_move<0x140>(b));
+}
+__device__ __forceinline__ void row16_sum2(double& a, double& b) {
+    a += dpp_move<0xB1>(a);   b += dpp_move<0xB1>(b);
+    a += dpp_move<0x4E>(a);   b += dpp_move<0x4E>(b);
+    a += dpp_move<0x141>(a);  b += dpp_move<0x141>(b);
+    a += dpp_move<0x140>(a);  b += dpp_move<0x140>(b);
+}
+// Log-sum-exp step for TWO 4-sample groups of a tile at once (independent chains interleaved):
+//   x = a - u;  m2 = 32 log2(e) max_k x;  e = 2^((32 log2(e) x - m2)/32);  s = sum_k e;  acc[0] += e / s
+// A second candidate f' costs no second exp: exp(a'_k - u_kn - m) = e_kn * c_k with the per-state constant
+// c_k = exp(a'_k - a_k), so  e' = e c,  s' = sum_k e',  acc[1] += e' / s'  (3 fp64 ops per element instead of ~20).
+// logden_f = m2 ln2/32 + log s_f for both candidates (same shift m2).
+template <int NB, int NF>
+__device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl, int rd0, int rd1,
+                                               const double (&a)[NB], const double (&c)[NB], double (&acc)[NF][NB],
+                                               bool valid0, bool valid1, double& m2_0, double& m2_1,
+                                               double (&s0)[NF], double (&s1)[NF]) {
+    double x0[NB], x1[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        x0[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
+        x1[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd1);
+    }
+    double m0 = tree_max<NB>(x0), m1 = tree_max<NB>(x1);
+    row16_max2(m0, m1);
+    m2_0 = m0 * LOG2E_32;
+    m2_1 = m1 * LOG2E_32;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        x0[I] = exp2s_fast(fma(x0[I], LOG2E_32, -m2_0), tbl);
+        x1[I] = exp2s_fast(fma(x1[I], LOG2E_32, -m2_1), tbl);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        if (f == 1) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I) { x0[I] *= c[I]; x1[I] *= c[I]; }
+        }
+        s0[f] = tree_sum<NB>(x0);
+        s1[f] = tree_sum<NB>(x1);
+        row16_sum2(s0[f], s1[f]);
+        const double r0 = valid0 ? recip_fast(s0[f]) : 0.0, r1 = valid1 ? recip_fast(s1[f]) : 0.0;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[f][I] = fma(x1[I], r1, fma(x0[I], r0, acc[f][I]));
+    }
+}
+
+// Single-group version for wide panels (NB > 8), where two groups in flight would spill registers.
+template <int NB, int NF>
+__device__ __forceinline__ void lse_one_group(const char* cbuf, const char* tbl, int rd0, const double (&a)[NB],
+                                              const double (&c)[NB], double (&acc)[NF][NB], bool valid0, double& m2_0,
+                                              double (&s0)[NF]) {
+    double x0[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) x0[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
+    m2_0 = row16_max(tree_max<NB>(x0)) * LOG2E_32;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) x0[I] = exp2s_fast(fma(x0[I], LOG2E_32, -m2_0), tbl);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        if (f == 1) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I) x0[I] *= c[I];
+        }
+        s0[f] = row16_sum(tree_sum<NB>(x0));
+        const double r0 = valid0 ? recip_fast(s0[f]) : 0.0;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[f][I] = fma(x0[I], r0, acc[f][I]);
+    }
+}
+// Two consecutive groups g, g+1 of a tile; (mm, ss[]) capture the (shift, sums) of the sample this lane will write.
+template <int NB, int NF>
+__device__ __forceinline__ void lse_group_pair(const char* cbuf, const char* tbl, int rd_base, const int (&pos)[GROUPS],
+                                               int g, const double (&a)[NB], const double (&c)[NB],
+                                               double (&acc)[NF][NB], int64_t n_first, int64_t N, int ks, int ns,
+                                               double& mm, double (&ss)[NF]) {
+    double m2a, m2b, sa[NF], sb[NF];
+    const bool va = (n_first + 4 * g + ns) < N, vb = (n_first + 4 * (g + 1) + ns) < N;
+    if constexpr (NB <= 8) {
+        lse_two_groups<NB, NF>(cbuf, tbl, rd_base + pos[g], rd_base + pos[g + 1], a, c, acc, va, vb, m2a, m2b, sa, sb);
+    } else {
+        lse_one_group<NB, NF>(cbuf, tbl, rd_base + pos[g], a, c, acc, va, m2a, sa);
+        lse_one_group<NB, NF>(cbuf, tbl, rd_base + pos[g + 1], a, c, acc, vb, m2b, sb);
+    }
+    if ((ks & 3) == g) {
+        mm = m2a;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ss[f] = sa[f];
+    }
+    if ((ks & 3) == g + 1) {
+        mm = m2b;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ss[f] = sb[f];
+    }
+}
+
 // Stage one wave tile (ROWS state rows x 16 samples starting at column n0) into `dst`.
 // DMA instruction j fills LDS bytes [1024 j, 1024 j + 1024): lane l -> row 8j + (l >> 3),
 // positions 2(l & 7), 2(l & 7)+1 of that row, which hold samples (pos - (row & 14)) & 15.
-// rowmap(tile_row) gives the global row.
-template <int ROWS, bool DMA, typename RowMap>
-__device__ __forceinline__ void stage_tile(const double* __restrict__ u, int64_t ld, int64_t n0,
-                                           char* dst, int lane, RowMap rowmap) {
+// The per-lane part of the source address depends on j only through its parity (row & 14 = ((l >> 3) & 6) |
+// 8 (j & 1)), so it is two loop-invariant 32-bit byte offsets (StageOffsets) added to a wave-uniform base:
+// the DMA is issued as `global_load_lds_dwordx4 voff, s[base]` with no per-instruction VALU address math.
+// rowmap(tile_row) gives the global row (8-row groups never straddle a panel).
+struct StageOffsets {
+    uint32_t off[2];
+};
+__device__ __forceinline__ StageOffsets make_stage_offsets(int64_t ld, int lane) {
+    StageOffsets so;
+    const int r = lane >> 3, pos = 2 * (lane & 7);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int smp = (pos - ((r & 6) | (par << 3))) & 15;
+        so.off[par] = (uint32_t)(((int64_t)r * ld + smp) * 8);
+    }
+    return so;
+}
+template <bool DMA>
+__device__ __forceinline__ void stage_piece(const double* __restrict__ ubase /*wave-uniform*/, uint32_t voff,
+                                            char* dst /*wave-uniform*/, int lane) {
+    const char* src = reinterpret_cast<const char*>(ubase) + voff;
+    if constexpr (DMA) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    } else {
+        *reinterpret_cast<double2*>(dst + lane * 16) = *reinterpret_cast<const double2*>(src);
+    }
+}
+template <int ROWS, bool DMA, int J0, int JSTEP, typename RowMap>
+__device__ __forceinline__ void stage_tile(const double* __restrict__ u, int64_t ld, int64_t n0, char* dst, int lane,
+                                           const StageOffsets& so, RowMap rowmap) {
     constexpr int NDMA = ROWS / 8;
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) {
-        const int tr = 8 * j + (lane >> 3);
-        const int pos = 2 * (lane & 7);
-        const int smp = (pos - (tr & 14)) & 15;
-        const double* src = u + rowmap(tr) * ld + n0 + smp;
-        if constexpr (DMA) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + j * 1024),
-                                             16, 0, 0);
-        } else {
-            const double2 v = *reinterpret_cast<const double2*>(src);
-            *reinterpret_cast<double2*>(dst + j * 1024 + lane * 16) = v;
-        }
-    }
+    for (int j = J0; j < NDMA; j += JSTEP)
+        stage_piece<DMA>(u + rowmap(8 * j) * ld + n0, so.off[j & 1], dst + j * 1024, lane);
 }
 
 // Stage the 16 per-sample values v[n0 .. n0+16) (128 bytes) behind a tile: lanes 0..7 move 16 bytes each.
@@ -125,15 +282,7 @@ __device__ __forceinline__ void stage_tile(const double* __restrict__ u, int64_t
 // prefetch with an s_waitcnt vmcnt(0) at the first use of the loaded register.
 template <bool DMA>
 __device__ __forceinline__ void stage_vec16(const double* __restrict__ v, int64_t n0, char* dst, int lane) {
-    if (lane < 8) {
-        const double* src = v + n0 + 2 * lane;
-        if constexpr (DMA) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        } else {
-            *reinterpret_cast<double2*>(dst + lane * 16) = *reinterpret_cast<const double2*>(src);
-        }
-    }
+    if (lane < 8) stage_piece<DMA>(v + n0, (uint32_t)(lane * 16), dst, lane);
 }
 
 // Pin a loaded value into its register *now*: the compiler must place the s_waitcnt for the load here
@@ -158,12 +307,13 @@ struct RowTwoPanels {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Evaluation pass: per-sample log-sum-exp over states + per-state sums of p_nk, for NF vectors f.
-//   aden[f][k] = f_k + ln N_k (-inf for unsampled / padded states)
+// Evaluation pass: per-sample log-sum-exp over states + per-state sums of p_nk, for NF candidates f.
+//   aden[0][k] = f_k + ln N_k of the first candidate (-inf for unsampled / padded states)
+//   aden[1][k] = c_k = exp(aden'_k - aden_k) of the second candidate relative to the first (NF == 2)
 //   logden_n   = log sum_k exp(aden_k - u_kn)                    (mbar_solvers.py:238)
 //   p_nk       = exp(aden_k - u_kn - logden_n),  psum_k = sum_n p_nk   (= N_k sum_n W_nk)
-// One exp per matrix element per f: e = exp(x - max) is kept in registers and normalised by the
-// reciprocal of its sum.
+// One exp per matrix element in total: e = exp(x - max) is kept in registers, normalised by the reciprocal of
+// its sum, and re-used for the second candidate through the per-state ratio c_k.
 // ---------------------------------------------------------------------------------------------
 template <int NB, int NF, bool DMA>
 __global__ void __launch_bounds__(256)
@@ -178,25 +328,32 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
     const int ks = lane & 15, ns = lane >> 4;
-    char* buf = smem + wave * (2 * TILE_BYTES);
+    char* tbl = smem;  // exp table in the first 256 bytes, tiles behind it
+    exp_table_init(tbl);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
     const RowIdentity rows{0};
+    const StageOffsets so = make_stage_offsets(ld, lane);
 
-    double a[NF][NB], acc[NF][NB], obj[NF];
+    double a[NB], c[NB], acc[NF][NB], obj[NF];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        a[I] = aden[16 * I + ks];
+        c[I] = NF == 2 ? aden[ROWS + 16 * I + ks] : 1.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        settle(a[I]);
+        if (NF == 2) settle(c[I]);
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         obj[f] = 0.0;
 #pragma unroll
-        for (int I = 0; I < NB; ++I) {
-            a[f][I] = aden[f * ROWS + 16 * I + ks];
-            acc[f][I] = 0.0;
-        }
+        for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
     }
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int I = 0; I < NB; ++I) settle(a[f][I]);
     const int rd_base = ks * (TS * 8);
     int pos[GROUPS];
 #pragma unroll
@@ -205,57 +362,36 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     int64_t t = gw;
     int cur = 0;
     if constexpr (DMA) {
-        if (t < ntiles) stage_tile<ROWS, true>(u, ld, t * TS, buf, lane, rows);
+        if (t < ntiles) stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
     }
     for (; t < ntiles; t += W) {
         char* cbuf = buf + cur * TILE_BYTES;
         if constexpr (DMA) {
             const int64_t tn = t + W;
             if (tn < ntiles) {
-                stage_tile<ROWS, true>(u, ld, tn * TS, buf + (cur ^ 1) * TILE_BYTES, lane, rows);
+                stage_tile<ROWS, true, 0, 1>(u, ld, tn * TS, buf + (cur ^ 1) * TILE_BYTES, lane, so, rows);
                 wait_vm<NDMA>();
             } else {
                 wait_vm<0>();
             }
         } else {
-            stage_tile<ROWS, false>(u, ld, t * TS, cbuf, lane, rows);
+            stage_tile<ROWS, false, 0, 1>(u, ld, t * TS, cbuf, lane, so, rows);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        double mm[NF], ss[NF];
+        double mm = 0.0, ss[NF];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) { mm[f] = 0.0; ss[f] = 1.0; }
+        for (int f = 0; f < NF; ++f) ss[f] = 1.0;
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g) {
-            double uv[NB];
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-                uv[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
-            const bool valid = (t * TS + 4 * g + ns) < N;
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                double x[NB];
-                double m = -INFINITY;
-#pragma unroll
-                for (int I = 0; I < NB; ++I) { x[I] = a[f][I] - uv[I]; m = fmax(m, x[I]); }
-                m = row16_max(m);
-                double s = 0.0;
-#pragma unroll
-                for (int I = 0; I < NB; ++I) { x[I] = exp_fast(x[I] - m); s += x[I]; }
-                s = row16_sum(s);
-                const double r = valid ? recip_fast(s) : 0.0;
-#pragma unroll
-                for (int I = 0; I < NB; ++I) acc[f][I] = fma(x[I], r, acc[f][I]);
-                if ((ks & 3) == g) { mm[f] = m; ss[f] = s; }
-            }
-        }
-        // lanes with (ks & 3) == g hold (max, sum) of sample 4 g + ns: one log per tile
+        for (int g = 0; g < GROUPS; g += 2)
+            lse_group_pair<NB, NF>(cbuf, tbl, rd_base, pos, g, a, c, acc, t * TS, N, ks, ns, mm, ss);
+        // lanes with (ks & 3) == g hold (shift, sums) of sample 4 g + ns: one log per candidate per tile
         {
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
             const bool writer = (ks < 4) && (n < N);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const double ldv = mm[f] + log(ss[f]);
+                const double ldv = fma(mm, LN2_OVER_32, log(ss[f]));
                 if (writer) {
                     double* out = f == 0 ? logden0 : logden1;
                     if (out) out[n] = ldv;
@@ -283,57 +419,52 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // ---------------------------------------------------------------------------------------------
 // Evaluation pass, paired-wave variant for wide panels (NB >= 6), where one 16-sample tile is 12-32 KB
 // and LDS (not registers) would limit the unpaired kernel to one wave per SIMD.  Two waves share each
-// tile stream (workgroup = STREAMS streams x 2 halves, one barrier per tile):
-//   NF == 2: half h evaluates candidate f_h on all four 4-sample groups,
-//   NF == 1: half h evaluates groups {2h, 2h+1}.
-// Each wave therefore carries the register footprint of a single-f kernel and two waves fit per SIMD.
-// Partial record of half h of stream gs: index 2 gs + h (for NF == 2 this is the [stream][f] layout).
+// tile stream (workgroup = STREAMS streams x 2 halves, one barrier per tile); half h evaluates the 4-sample
+// groups {2h, 2h+1} of every tile for all NF candidates.  Partial record of half h of stream gs: 2 gs + h.
 // ---------------------------------------------------------------------------------------------
 template <int NB, int NF, bool DMA, int HALF, int STREAMS>
 __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
-                                              const double* __restrict__ aden, double* __restrict__ logden_out,
-                                              const double* __restrict__ dn, double* __restrict__ psum_part,
-                                              double* __restrict__ obj_part, char* smem, int lane, int stream) {
+                                              const double* __restrict__ aden, double* __restrict__ logden0,
+                                              double* __restrict__ logden1, const double* __restrict__ dn,
+                                              double* __restrict__ psum_part, double* __restrict__ obj_part,
+                                              char* smem, int lane, int stream) {
     constexpr int ROWS = NB * 16;
     constexpr int TILE_BYTES = ROWS * TS * 8;
-    constexpr int NDMA = ROWS / 8;
-    constexpr int G0 = NF == 2 ? 0 : 2 * HALF, G1 = NF == 2 ? GROUPS : 2 * HALF + 2;
+    constexpr int G0 = 2 * HALF;
     const int ks = lane & 15, ns = lane >> 4;
-    char* buf = smem + stream * (2 * TILE_BYTES);
+    const char* tbl = smem;  // initialised by the kernel prologue
+    char* buf = smem + EXP_TABLE_BYTES + stream * (2 * TILE_BYTES);
     const int64_t gs = (int64_t)blockIdx.x * STREAMS + stream;
     const int64_t S = (int64_t)gridDim.x * STREAMS;
     const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
     const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;  // block-uniform trip count
     const RowIdentity rows{0};
+    const StageOffsets so = make_stage_offsets(ld, lane);
 
-    double a[NB], acc[NB];
+    double a[NB], c[NB], acc[NF][NB], obj[NF];
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
-        a[I] = aden[(NF == 2 ? HALF : 0) * ROWS + 16 * I + ks];
-        acc[I] = 0.0;
+        a[I] = aden[16 * I + ks];
+        c[I] = NF == 2 ? aden[ROWS + 16 * I + ks] : 1.0;
     }
 #pragma unroll
-    for (int I = 0; I < NB; ++I) settle(a[I]);
-    double obj = 0.0;
+    for (int I = 0; I < NB; ++I) {
+        settle(a[I]);
+        if (NF == 2) settle(c[I]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        obj[f] = 0.0;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
+    }
     const int rd_base = ks * (TS * 8);
     int pos[GROUPS];
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
 
     auto stage_mine = [&](int64_t tile, char* dst) {
-#pragma unroll
-        for (int j = HALF; j < NDMA; j += 2) {
-            const int tr = 8 * j + (lane >> 3);
-            const int pp = 2 * (lane & 7);
-            const int smp = (pp - (tr & 14)) & 15;
-            const double* src = u + rows(tr) * ld + tile * TS + smp;
-            if constexpr (DMA) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-            } else {
-                *reinterpret_cast<double2*>(dst + j * 1024 + lane * 16) = *reinterpret_cast<const double2*>(src);
-            }
-        }
+        stage_tile<ROWS, DMA, HALF, 2>(u, ld, tile * TS, dst, lane, so, rows);
     };
 
     int64_t t = gs;
@@ -346,48 +477,37 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
         char* cbuf = buf + cur * TILE_BYTES;
         if (active && t + S < ntiles) stage_mine(t + S, buf + (cur ^ 1) * TILE_BYTES);
         if (active) {
-            double mm = 0.0, ss = 1.0;
+            double mm = 0.0, ss[NF];
 #pragma unroll
-            for (int g = G0; g < G1; ++g) {
-                double x[NB];
-                double m = -INFINITY;
-#pragma unroll
-                for (int I = 0; I < NB; ++I) {
-                    const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
-                    x[I] = a[I] - uv;
-                    m = fmax(m, x[I]);
-                }
-                const bool valid = (t * TS + 4 * g + ns) < N;
-                m = row16_max(m);
-                double sm = 0.0;
-#pragma unroll
-                for (int I = 0; I < NB; ++I) { x[I] = exp_fast(x[I] - m); sm += x[I]; }
-                sm = row16_sum(sm);
-                const double r = valid ? recip_fast(sm) : 0.0;
-#pragma unroll
-                for (int I = 0; I < NB; ++I) acc[I] = fma(x[I], r, acc[I]);
-                if ((ks & 3) == g) { mm = m; ss = sm; }
-            }
+            for (int f = 0; f < NF; ++f) ss[f] = 1.0;
+            lse_group_pair<NB, NF>(cbuf, tbl, rd_base, pos, G0, a, c, acc, t * TS, N, ks, ns, mm, ss);
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
-            const bool writer = (ks >= G0) && (ks < G1) && (n < N);
-            const double ldv = mm + log(ss);
-            if (writer) {
-                if (logden_out) logden_out[n] = ldv;
-                obj += dn ? (ldv - dn[n]) : ldv;
+            const bool writer = (ks >= G0) && (ks < G0 + 2) && (n < N);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const double ldv = fma(mm, LN2_OVER_32, log(ss[f]));
+                if (writer) {
+                    double* out = f == 0 ? logden0 : logden1;
+                    if (out) out[n] = ldv;
+                    obj[f] += dn ? (ldv - dn[n]) : ldv;
+                }
             }
         }
         cur ^= 1;
     }
     const int64_t rec = 2 * gs + HALF;
 #pragma unroll
-    for (int I = 0; I < NB; ++I) {
-        double v = acc[I];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16) psum_part[rec * ROWS + 16 * I + lane] = v;
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(rec * NF + f) * ROWS + 16 * I + lane] = v;
+        }
+        const double o = wave_sum(obj[f]);
+        if (lane == 0) obj_part[rec * NF + f] = o;
     }
-    const double o = wave_sum(obj);
-    if (lane == 0) obj_part[rec] = o;
 }
 
 template <int NB, int NF, bool DMA>
@@ -400,11 +520,14 @@ k_lse_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int stream = wave % STREAMS;
+    exp_table_init(smem);
+    __syncthreads();
     if (wave / STREAMS == 0)
-        lse_pair_body<NB, NF, DMA, 0, STREAMS>(u, ld, N, ntiles, aden, logden0, dn, psum_part, obj_part, smem, lane, stream);
+        lse_pair_body<NB, NF, DMA, 0, STREAMS>(u, ld, N, ntiles, aden, logden0, logden1, dn, psum_part, obj_part, smem,
+                                               lane, stream);
     else
-        lse_pair_body<NB, NF, DMA, 1, STREAMS>(u, ld, N, ntiles, aden, NF == 2 ? logden1 : logden0, dn, psum_part,
-                                               obj_part, smem, lane, stream);
+        lse_pair_body<NB, NF, DMA, 1, STREAMS>(u, ld, N, ntiles, aden, logden0, logden1, dn, psum_part, obj_part, smem,
+                                               lane, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -430,17 +553,18 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
     const int ks = lane & 15, ns = lane >> 4;
-    char* buf = smem + wave * (2 * TILE_BYTES);
+    char* tbl = smem;
+    exp_table_init(tbl);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
     const RowTwoPanels rows{row_i0, row_j0, DIAG ? ROWS : NBI * 16};
+    const StageOffsets so = make_stage_offsets(ld, lane);
 
-    double a[NBT], ps[NBT];
+    double a[NBT];
 #pragma unroll
-    for (int I = 0; I < NBT; ++I) {
-        a[I] = (DIAG || I < NBI) ? anum_i[16 * I + ks] : anum_j[16 * (I - NBI) + ks];
-        ps[I] = 0.0;
-    }
+    for (int I = 0; I < NBT; ++I) a[I] = (DIAG || I < NBI) ? anum_i[16 * I + ks] : anum_j[16 * (I - NBI) + ks];
 #pragma unroll
     for (int I = 0; I < NBT; ++I) settle(a[I]);
     v4d acc[NBLK];
@@ -456,7 +580,7 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     int cur = 0;
     if constexpr (DMA) {
         if (t < ntiles) {
-            stage_tile<ROWS, true>(u, ld, t * TS, buf, lane, rows);
+            stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
             stage_vec16<true>(logden, t * TS, buf + U_BYTES, lane);
         }
     }
@@ -466,14 +590,14 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             const int64_t tn = t + W;
             if (tn < ntiles) {
                 char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
-                stage_tile<ROWS, true>(u, ld, tn * TS, nbuf, lane, rows);
+                stage_tile<ROWS, true, 0, 1>(u, ld, tn * TS, nbuf, lane, so, rows);
                 stage_vec16<true>(logden, tn * TS, nbuf + U_BYTES, lane);
                 wait_vm<NDMA>();
             } else {
                 wait_vm<0>();
             }
         } else {
-            stage_tile<ROWS, false>(u, ld, t * TS, cbuf, lane, rows);
+            stage_tile<ROWS, false, 0, 1>(u, ld, t * TS, cbuf, lane, so, rows);
             stage_vec16<false>(logden, t * TS, cbuf + U_BYTES, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -490,8 +614,7 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 #pragma unroll
             for (int I = 0; I < NBT; ++I) {
                 const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
-                p[I] = exp_fast((a[I] - lde) - uv);
-                ps[I] += p[I];
+                p[I] = exp2s_fast(((a[I] - lde) - uv) * LOG2E_32, tbl);
             }
             if constexpr (DIAG) {
                 int b = 0;
@@ -517,15 +640,6 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     for (int b = 0; b < NBLK; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = acc[b][r];
-    if (psum_part) {
-#pragma unroll
-        for (int I = 0; I < NBT; ++I) {
-            double v = ps[I];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (lane < 16) psum_part[gw * ROWS + 16 * I + lane] = v;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -566,20 +680,20 @@ __device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int
     constexpr int NMINE = HALF == 0 ? (NBLK + 1) / 2 : NBLK / 2;  // blocks b with (b & 1) == HALF
     constexpr int STREAMS = 4;
     const int ks = lane & 15, ns = lane >> 4;
-    char* buf = smem + stream * (2 * TILE_BYTES);
+    const char* tbl = smem;
+    char* buf = smem + EXP_TABLE_BYTES + stream * (2 * TILE_BYTES);
     const int64_t gs = (int64_t)blockIdx.x * STREAMS + stream;   // global stream id = partial record
     const int64_t S = (int64_t)gridDim.x * STREAMS;
     const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
     const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;  // block-uniform trip count
     const RowIdentity rows{row0};
+    const StageOffsets so = make_stage_offsets(ld, lane);
 
-    double a[NB], ps[NB / 2];
+    double a[NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I) a[I] = anum[16 * I + ks];
 #pragma unroll
     for (int I = 0; I < NB; ++I) settle(a[I]);
-#pragma unroll
-    for (int I = 0; I < NB / 2; ++I) ps[I] = 0.0;
     v4d acc[NMINE];
 #pragma unroll
     for (int b = 0; b < NMINE; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -591,19 +705,7 @@ __device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int
 
     // this wave stages DMA instructions j with (j & 1) == HALF; half 0 also stages the logden slot
     auto stage_mine = [&](int64_t tile, char* dst) {
-#pragma unroll
-        for (int j = HALF; j < NDMA; j += 2) {
-            const int tr = 8 * j + (lane >> 3);
-            const int pp = 2 * (lane & 7);
-            const int smp = (pp - (tr & 14)) & 15;
-            const double* src = u + rows(tr) * ld + tile * TS + smp;
-            if constexpr (DMA) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-            } else {
-                *reinterpret_cast<double2*>(dst + j * 1024 + lane * 16) = *reinterpret_cast<const double2*>(src);
-            }
-        }
+        stage_tile<ROWS, DMA, HALF, 2>(u, ld, tile * TS, dst, lane, so, rows);
         if constexpr (HALF == 0) stage_vec16<DMA>(logden, tile * TS, dst + U_BYTES, lane);
     };
 
@@ -629,10 +731,8 @@ __device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int
 #pragma unroll
                 for (int I = 0; I < NB; ++I) {
                     const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
-                    p[I] = exp_fast((a[I] - lde) - uv);
+                    p[I] = exp2s_fast(((a[I] - lde) - uv) * LOG2E_32, tbl);
                 }
-#pragma unroll
-                for (int I = 0; I < NB / 2; ++I) ps[I] += p[HALF * (NB / 2) + I];
                 gram_half_group<NB, HALF, NMINE>(p, acc);
             }
         }
@@ -645,15 +745,6 @@ __device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) gram_part[((gs * NBLK + b) * 4 + r) * 64 + lane] = acc[sl][r];
     }
-    if (psum_part) {
-#pragma unroll
-        for (int I = 0; I < NB / 2; ++I) {
-            double v = ps[I];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (lane < 16) psum_part[gs * ROWS + 16 * (HALF * (NB / 2) + I) + lane] = v;
-        }
-    }
 }
 
 template <int NB, bool DMA>
@@ -665,6 +756,8 @@ k_gram_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int stream = wave & 3;
+    exp_table_init(smem);
+    __syncthreads();
     if ((wave >> 2) == 0)
         gram_pair_body<NB, DMA, 0>(u, ld, N, ntiles, anum, logden, row0, gram_part, psum_part, smem, lane, stream);
     else
@@ -699,7 +792,8 @@ __device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int
     constexpr int STREAMS = 4;
     constexpr int G0 = 2 * HALF, P0 = 2 * (1 - HALF);  // own groups G0, G0+1; partner's P0, P0+1
     const int ks = lane & 15, ns = lane >> 4;
-    char* ubuf = smem + stream * STREAM_BYTES;
+    const char* tbl = smem;
+    char* ubuf = smem + EXP_TABLE_BYTES + stream * STREAM_BYTES;
     char* lbuf = ubuf + U_BYTES;
     char* pbuf = lbuf + L_BYTES;
     const int64_t gs = (int64_t)blockIdx.x * STREAMS + stream;
@@ -707,10 +801,11 @@ __device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int
     const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
     const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;
     const RowIdentity rows{row0};
+    const StageOffsets so = make_stage_offsets(ld, lane);
 
-    double a[NB], ps[NB];
+    double a[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) { a[I] = anum[16 * I + ks]; ps[I] = 0.0; }
+    for (int I = 0; I < NB; ++I) a[I] = anum[16 * I + ks];
 #pragma unroll
     for (int I = 0; I < NB; ++I) settle(a[I]);
     v4d acc[NMINE];
@@ -723,19 +818,7 @@ __device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int
     for (int gi = 0; gi < 2; ++gi) pos[gi] = ((4 * (G0 + gi) + ns + (ks & 14)) & 15) * 8;
 
     auto stage_mine = [&](int64_t tile) {
-#pragma unroll
-        for (int j = HALF; j < NDMA; j += 2) {
-            const int tr = 8 * j + (lane >> 3);
-            const int pp = 2 * (lane & 7);
-            const int smp = (pp - (tr & 14)) & 15;
-            const double* src = u + rows(tr) * ld + tile * TS + smp;
-            if constexpr (DMA) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(ubuf + j * 1024), 16, 0, 0);
-            } else {
-                *reinterpret_cast<double2*>(ubuf + j * 1024 + lane * 16) = *reinterpret_cast<const double2*>(src);
-            }
-        }
+        stage_tile<ROWS, DMA, HALF, 2>(u, ld, tile * TS, ubuf, lane, so, rows);
         if constexpr (HALF == 0) stage_vec16<DMA>(logden, tile * TS, lbuf, lane);
     };
 
@@ -755,8 +838,7 @@ __device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int
 #pragma unroll
                 for (int I = 0; I < NB; ++I) {
                     const double uv = *reinterpret_cast<const double*>(ubuf + I * (16 * TS * 8) + rd_base + pos[gi]);
-                    p_own[gi][I] = exp_fast((a[I] - ldc) - uv);
-                    ps[I] += p_own[gi][I];
+                    p_own[gi][I] = exp2s_fast(((a[I] - ldc) - uv) * LOG2E_32, tbl);
                     *reinterpret_cast<double*>(pbuf + ((g * NB + I) * 64 + lane) * 8) = p_own[gi][I];
                 }
             }
@@ -782,15 +864,6 @@ __device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) gram_part[((gs * NBLK + b) * 4 + r) * 64 + lane] = acc[sl][r];
     }
-    if (psum_part) {
-#pragma unroll
-        for (int I = 0; I < NB; ++I) {
-            double v = ps[I];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (lane < 16) psum_part[(2 * gs + HALF) * ROWS + 16 * I + lane] = v;
-        }
-    }
 }
 
 template <int NB, bool DMA>
@@ -802,6 +875,8 @@ k_gram_xchg(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int stream = wave & 3;
+    exp_table_init(smem);
+    __syncthreads();
     if ((wave >> 2) == 0)
         gram_xchg_body<NB, DMA, 0>(u, ld, N, ntiles, anum, logden, row0, gram_part, psum_part, smem, lane, stream);
     else
@@ -1065,8 +1140,7 @@ k_sci_update(const double* __restrict__ psum, const double* __restrict__ Nk, con
 
 // fp64 MFMA peak probe: 4 independent accumulators per wave, nothing else in the loop
 // (same kernel as tools/mfma_peak.hip; 64 cycles per instruction per SIMD on gfx950).
-__global__ void __launch_bounds__(256)
-k_mfma_peak(int iters, double* sink) {
+__global__ void k_mfma_peak(int iters, double* sink) {
     v4d c[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) c[i] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -1094,21 +1168,21 @@ static int blocks_per_cu_for(size_t lds_bytes) {
 LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant) {
     LaunchGeom g;
     const size_t tile = (size_t)nb * 16 * TS * 8;
-    g.variant = (nb >= 6 && variant == 0) ? 0 : 1;
+    g.variant = (nb >= 6 && variant == 0 && !(nb > 8 && nf == 2)) ? 0 : 1;  // (wide two-candidate pairs would spill)
     int64_t cap;
     if (g.variant == 0) {  // paired: STREAMS tile streams x 2 waves
         const int streams = nb <= 8 ? 4 : 2;
         g.waves = 2 * streams;
-        g.lds_bytes = (size_t)streams * 2 * tile;
+        g.lds_bytes = (size_t)streams * 2 * tile + 256;
         int64_t want = (ntiles + streams - 1) / streams;
         cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
         if (grid_override > 0) cap = grid_override;
         if (want < 1) want = 1;
         g.blocks = (int)(want < cap ? want : cap);
-        g.nwaves = g.blocks * streams * (nf == 2 ? 1 : 2);
+        g.nwaves = g.blocks * streams * 2;  // one partial record per wave
     } else {
         g.waves = nb <= 8 ? 4 : 2;
-        g.lds_bytes = (size_t)g.waves * 2 * tile;
+        g.lds_bytes = (size_t)g.waves * 2 * tile + 256;
         int64_t want = (ntiles + g.waves - 1) / g.waves;
         cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
         if (grid_override > 0) cap = grid_override;
@@ -1125,11 +1199,11 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
     g.waves = 4;
     g.variant = -1;
     const size_t tile = (size_t)tile_rows * TS * 8 + TS * 8;  // u tile + its 16 logden values
-    g.lds_bytes = (size_t)4 * 2 * tile;
+    g.lds_bytes = (size_t)4 * 2 * tile + 256;
     if (diag && tile_rows == 128) {
         g.variant = nb8_variant == 1 ? 1 : 0;
         g.waves = 8;
-        if (g.variant == 0) g.lds_bytes = (size_t)4 * (tile + (size_t)GROUPS * 8 * 64 * 8);  // single u buffer + operand buffer
+        if (g.variant == 0) g.lds_bytes = (size_t)4 * (tile + (size_t)GROUPS * 8 * 64 * 8) + 256;  // single u buffer + operand buffer
     }
     int64_t want = (ntiles + 3) / 4;
     int64_t cap = num_cu;  // the accumulators own the register file: one workgroup per CU
