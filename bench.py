@@ -135,8 +135,12 @@ def main():
     N_k = N_k.copy()
     N_k[-1] += N_total - int(N_k.sum())  # keep sum(N_k) == N_total when K does not divide it
 
-    info = device_info(local_rank)
-    dm = DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=rank * n_loc, N_local=n_loc, device=local_rank)
+    from pymbar_amd import _lib
+
+    ndev = max(1, _lib.device_count())
+    dev = local_rank % ndev  # one rank per GPU under the launcher; wraps only when ranks outnumber devices (testing)
+    info = device_info(dev)
+    dm = DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=rank * n_loc, N_local=n_loc, device=dev)
     dm.set_option("staging", args.staging)
     dm.set_option("lse_variant", args.lse_variant)
     dm.set_option("gram_variant", args.gram_variant)
@@ -177,7 +181,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         def factory(n):
-            return DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=0, N_local=n, device=local_rank)
+            return DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=0, N_local=n, device=dev)
         cpu = cpu_baseline(factory, K, n_loc, min(args.cpu_sample, n_loc), args.seed)
 
     if rank == 0:

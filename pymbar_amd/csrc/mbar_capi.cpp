@@ -215,7 +215,7 @@ bool f_is_finite(const mbar_ctx* c, const double* f, int nf) {
 
 // ---- collectives -------------------------------------------------------------------------------
 int allreduce_dev(mbar_ctx* c, double* dev, int64_t count, int op) {
-    if (c->nranks <= 1) return MBAR_OK;
+    if (c->nranks <= 1 && !c->comm) return MBAR_OK;
     if (c->comm) {
         ncclResult_t r = g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax,
                                           c->comm, c->stream);
@@ -237,7 +237,7 @@ int allreduce_dev(mbar_ctx* c, double* dev, int64_t count, int op) {
     return fail(c, MBAR_ERR_STATE, "nranks > 1 but no communicator attached");
 }
 int allreduce_host(mbar_ctx* c, double* host, int64_t count, int op) {
-    if (c->nranks <= 1) return MBAR_OK;
+    if (c->nranks <= 1 && !c->comm) return MBAR_OK;
     if (c->host_reduce && !c->comm) {
         if (c->host_reduce(host, count, op, c->host_reduce_user) != 0)
             return fail(c, MBAR_ERR_COMM, "host all-reduce callback failed");
@@ -251,6 +251,15 @@ int allreduce_host(mbar_ctx* c, double* host, int64_t count, int op) {
     HIPCHK(c, hipMemcpyAsync(host, tmp, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MBAR_OK;
+}
+
+// Make rank 0's copy of a few control values authoritative on every rank (the reduced sums are bit-identical on all
+// ranks after an all-reduce, so this is insurance against a desynchronised loop exit, not a correctness need).
+int agree_with_rank0(mbar_ctx* c, double* v, int64_t count) {
+    if (c->nranks <= 1) return MBAR_OK;
+    if (c->rank != 0)
+        for (int64_t i = 0; i < count; ++i) v[i] = 0.0;
+    return allreduce_host(c, v, count, 0);
 }
 
 // ---- evaluation building blocks -----------------------------------------------------------------
@@ -1098,7 +1107,10 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
         }
         f_old = f;
         int choice;
-        if (gn_sci < gn_nr || res.sci_iter < min_sc_iter) {  // :607
+        double take_sci = (gn_sci < gn_nr || res.sci_iter < min_sc_iter) ? 1.0 : 0.0;
+        rc = agree_with_rank0(c, &take_sci, 1);
+        if (rc) return rc;
+        if (take_sci > 0.5) {  // :607
             std::copy(f_sci, f_sci + K, f.begin());
             std::copy(psum2.begin(), psum2.begin() + K, psum.begin());
             cur = sA;
@@ -1132,7 +1144,12 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
             history[4 * it + 2] = std::sqrt(gn_nr);
             history[4 * it + 3] = max_delta;
         }
-        if (check_convergence && (std::isnan(max_delta) || (max_delta < tol && max_diff < std::sqrt(tol)))) {  // :636
+        double stop = (check_convergence && (std::isnan(max_delta) || (max_delta < tol && max_diff < std::sqrt(tol)))) ? 1.0 : 0.0;  // :636
+        if (check_convergence) {
+            rc = agree_with_rank0(c, &stop, 1);
+            if (rc) return rc;
+        }
+        if (stop > 0.5) {
             res.success = 1;
             done = true;
         }
@@ -1209,14 +1226,20 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
         rc = sync_stream(c);
         if (rc) return rc;
         int64_t stop = nb;  // index within the batch of the accepted iterate
-        if (check_convergence)
+        if (check_convergence) {
             for (int64_t b = 0; b < nb; ++b)
                 if (std::isnan(hdelta[b]) || hdelta[b] < tol) {
                     stop = b + 1;
                     done = true;
-                    res.success = 1;
                     break;
                 }
+            double ctl[2] = {(double)stop, done ? 1.0 : 0.0};
+            rc = agree_with_rank0(c, ctl, 2);
+            if (rc) return rc;
+            stop = (int64_t)(ctl[0] + 0.5);
+            done = ctl[1] > 0.5;
+            if (done) res.success = 1;
+        }
         it += stop;
         last_delta = hdelta[stop - 1];
         HIPCHK(c, hipMemcpyAsync(hf.data(), c->f_hist + (size_t)(stop - 1) * Kp, Kp * sizeof(double),

@@ -392,7 +392,43 @@ def test_config3_full_size_properties(DM):
         np.testing.assert_allclose(sl[0], part["sumlogden"], rtol=1e-13)
 
 
+def test_rccl_communicator_single_rank(DM):
+    """RCCL path end to end on one GPU: dlopen librccl, ncclGetUniqueId, ncclCommInitRank(nranks=1), and every
+    reduced output going through ncclAllReduce on the compute stream.  (More ranks need more GPUs; the decomposition
+    itself is covered on CPU by tests/test_distributed_gloo.py.)"""
+    import ctypes as C
+
+    from pymbar_amd import _lib
+
+    u_kn, N_k, f = random_problem(40, 5000, seed=9)
+    with DM.from_host(u_kn) as plain, DM.from_host(u_kn) as comm:
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load_library().mbar_comm_unique_id(buf))
+        comm.comm_init_rccl(bytes(buf.raw), 0, 1)
+        assert comm.allreduce_kind == "rccl"
+        for dm in (plain, comm):
+            dm.set_Nk(N_k)
+        pa, sa, ga = plain.eval(f, gram=True)
+        pb, sb, gb = comm.eval(f, gram=True)
+        np.testing.assert_array_equal(pa, pb)
+        np.testing.assert_array_equal(ga, gb)
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(plain.lognum(f), comm.lognum(f))
+        fa, ra = plain.solve_adaptive(np.zeros(40), min_sc_iter=0)
+        fb, rb = comm.solve_adaptive(np.zeros(40), min_sc_iter=0)
+        assert ra["iterations"] == rb["iterations"] and rb["success"]
+        np.testing.assert_array_equal(fa, fb)
+        fs, rs = comm.solve_sci(np.zeros(40))
+        np.testing.assert_allclose(fs, fa, atol=1e-9)
+        # the host-callback transport gives the same numbers
+        with DM.from_host(u_kn) as host:
+            host.set_host_allreduce(lambda arr, op: None, 0, 1)
+            host.set_Nk(N_k)
+            ph, sh, gh = host.eval(f, gram=True)
+            np.testing.assert_array_equal(pa, ph)
+
+
 def test_mfma_peak_probe_is_sane(DM):
     with DM.from_host(np.zeros((4, 64))) as dm:
         t = dm.mfma_f64_peak()
-    assert 20.0 < t < 200.0, t
+    assert 60.0 < t < 90.0, t  # 64 cycles per instruction per SIMD at ~2.4 GHz = 78.6 TFLOP/s
