@@ -90,8 +90,12 @@ struct mbar_ctx {
     double* lognum_part = nullptr;
     size_t lognum_part_doubles = 0;
     double* f_hist = nullptr;       // SCI f history [batch][Kp]
+    // captured SCI batch (launch-bound loop: 3 small kernels per iteration replayed from a hipGraph)
+    hipGraphExec_t sci_graph = nullptr;
+    int64_t sci_graph_batch = 0, sci_graph_sig = 0;
+    double sci_graph_tol = 0.0;
     // options
-    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1;
+    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 0;  // measured best: independent-wave LSE sweep, operand-exchange Gram
     // comm
     ncclComm_t comm = nullptr;
@@ -747,6 +751,7 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->hred) hipHostFree(c->hred);
     if (c->lognum_part) hipFree(c->lognum_part);
     if (c->f_hist) hipFree(c->f_hist);
+    if (c->sci_graph) hipGraphExecDestroy(c->sci_graph);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -765,6 +770,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "force_generic") c->opt_force_generic = value;
     else if (k == "check_finite") c->opt_check_finite = value;
     else if (k == "timing") c->opt_timing = value;
+    else if (k == "graph") c->opt_graph = value;
     else if (k == "lse_variant") c->opt_lse_variant = value;
     else if (k == "gram_variant") c->opt_gram_variant = value;
     else if (k == "sci_batch") c->opt_sci_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
@@ -1210,17 +1216,94 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     int64_t it = 0;
     bool done = false;
     double last_delta = std::numeric_limits<double>::quiet_NaN();
+    // geometry and buffers of the fused path are fixed for the whole solve (nothing may allocate inside a capture)
+    const bool fast = use_fast(c);
+    const int nbk = (int)(rows / 16);
+    const int64_t ntiles = (c->N + TS - 1) / TS;
+    LaunchGeom g = fast ? lse_geometry(nbk, 1, c->num_cu, ntiles, c->opt_grid, (int)c->opt_lse_variant) : LaunchGeom();
+    if (fast) {
+        rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rows + 1));
+        if (rc) return rc;
+        rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 16) * (rows + 1));
+        if (rc) return rc;
+    }
+    // one SCI iteration into history slot b: sweep -> level-1 reduction -> [all-reduce] -> update (which folds the
+    // last reduction level in)
+    auto enqueue_iteration = [&](int64_t b, bool timed) -> int {
+        double* fh = c->f_hist + (size_t)b * Kp;
+        if (fast) {
+            double* psum_part = c->part;
+            double* obj_part = c->part + (size_t)g.nwaves * rows;
+            if (timed) {
+                ScopedTimer t(c, MBAR_TIMER_LSE);
+                HIPCHK(c, launch_lse(c->stream, nbk, 1, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), nullptr,
+                                     nullptr, nullptr, psum_part, obj_part));
+            } else {
+                HIPCHK(c, launch_lse(c->stream, nbk, 1, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), nullptr,
+                                     nullptr, nullptr, psum_part, obj_part));
+            }
+            const double* upd_src = psum_part;
+            int64_t upd_n = g.nwaves;
+            if (g.nwaves > 64) {
+                HIPCHK(c, launch_reduce_level1(c->stream, psum_part, g.nwaves, rows, c->scratch, &upd_n));
+                upd_src = c->scratch;
+            }
+            if (c->nranks > 1 || c->comm) {
+                HIPCHK(c, launch_reduce(c->stream, upd_src, upd_n, rows, c->scratch + (size_t)upd_n * rows, c->red));
+                int r2 = allreduce_dev(c, c->red, rows, 0);
+                if (r2) return r2;
+                upd_src = c->red;
+                upd_n = 1;
+            }
+            HIPCHK(c, launch_sci_update(c->stream, upd_src, upd_n, rows, d_Nk(c), d_lnNk(c), K, std::max(rows, Kp), first,
+                                        tol, d_f(c), d_aden(c), fh, d_delta(c) + b));
+        } else {
+            int r2 = run_lse(c, 1, rows, nullptr, nullptr, false);
+            if (r2) return r2;
+            r2 = allreduce_dev(c, c->red, rows, 0);
+            if (r2) return r2;
+            HIPCHK(c, launch_sci_update(c->stream, c->red, 1, rows, d_Nk(c), d_lnNk(c), K, std::max(rows, Kp), first, tol,
+                                        d_f(c), d_aden(c), fh, d_delta(c) + b));
+        }
+        return MBAR_OK;
+    };
+    // Launch-bound regime (a K=32, N=1e6 sweep is ~60 us): capture a whole batch into a hipGraph and replay it.
+    const bool use_graph = fast && c->opt_graph && c->nranks <= 1 && !c->comm && maxiter >= batch;  // (no per-kernel events inside a graph)
+    if (use_graph) {
+        const int64_t sig = ((int64_t)g.blocks << 32) ^ ((int64_t)g.variant << 24) ^ (c->opt_staging << 16) ^ first;
+        if (!c->sci_graph || c->sci_graph_batch != batch || c->sci_graph_sig != sig || c->sci_graph_tol != tol) {
+            if (c->sci_graph) HIPCHK(c, hipGraphExecDestroy(c->sci_graph));
+            c->sci_graph = nullptr;
+            rc = enqueue_iteration(0, false);  // eager warm-up: sets kernel attributes outside the capture
+            if (rc) return rc;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_f(c), hf.data(), Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_aden(c), ha.data(), std::max(rows, Kp) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipGraph_t graph = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int crc = MBAR_OK;
+            for (int64_t b = 0; b < batch && crc == MBAR_OK; ++b) crc = enqueue_iteration(b, false);
+            hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+            if (crc) return crc;
+            if (ee != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+            ee = hipGraphInstantiate(&c->sci_graph, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (ee != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ee));
+            c->sci_graph_batch = batch;
+            c->sci_graph_sig = sig;
+            c->sci_graph_tol = tol;
+        }
+    }
     while (it < maxiter && !done) {
         const int64_t nb = std::min(batch, maxiter - it);
-        for (int64_t b = 0; b < nb; ++b) {
-            rc = run_lse(c, 1, rows, nullptr, nullptr, false);
-            if (rc) return rc;
-            rc = allreduce_dev(c, c->red, rows, 0);
-            if (rc) return rc;
-            HIPCHK(c, launch_sci_update(c->stream, c->red, d_Nk(c), d_lnNk(c), K, std::max(rows, Kp), first, tol,
-                                        d_f(c), d_aden(c), d_delta(c) + b));
-            HIPCHK(c, hipMemcpyAsync(c->f_hist + (size_t)b * Kp, d_f(c), Kp * sizeof(double), hipMemcpyDeviceToDevice,
-                                     c->stream));
+        if (use_graph && nb == batch) {
+            HIPCHK(c, hipGraphLaunch(c->sci_graph, c->stream));
+        } else {
+            for (int64_t b = 0; b < nb; ++b) {
+                rc = enqueue_iteration(b, c->opt_timing != 0);
+                if (rc) return rc;
+            }
         }
         HIPCHK(c, hipMemcpyAsync(hdelta.data(), d_delta(c), nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         rc = sync_stream(c);

@@ -82,10 +82,13 @@ hipError_t launch_check_u(hipStream_t s, const double* u, int64_t ld, int64_t N,
 hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_t N, int64_t K,
                                     uint64_t seed, const double* O_k, const double* K_k,
                                     const int64_t* cumN /*[K+1]*/, int64_t n_global0);
-// device-resident SCI step: f' = f - log(psum/N_k) on sampled states, gauge, aden' = f' + ln N_k
-hipError_t launch_sci_update(hipStream_t s, const double* psum, const double* Nk, const double* lnNk,
-                             int64_t K, int64_t Kp, int first_state, double tol, double* f, double* aden,
-                             double* delta_out);
+// device-resident SCI step: sums `nparts` partial psum records (row pitch `rows`), then
+// f' = f - log(psum/N_k) on sampled states, gauge, aden' = f' + ln N_k; f' also goes to f_hist
+hipError_t launch_sci_update(hipStream_t s, const double* part, int64_t nparts, int64_t rows, const double* Nk,
+                             const double* lnNk, int64_t K, int64_t Kp, int first_state, double tol, double* f,
+                             double* aden, double* f_hist, double* delta_out);
+hipError_t launch_reduce_level1(hipStream_t s, const double* part, int64_t nparts, int64_t count, double* out,
+                                int64_t* nchunks);
 hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink);
 
 }  // namespace mbar

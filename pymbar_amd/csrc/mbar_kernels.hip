@@ -1095,14 +1095,36 @@ k_generate_harmonic(double* __restrict__ u, int64_t ld, int64_t N, int64_t K, ui
     }
 }
 
-// One self-consistent step on the device (single block): f'_k = f_k - log(psum_k / N_k) on sampled
-// states (mbar_solvers.py:231-242 via s_k), gauge f'[first] = 0 (:588), relative change (:627-631).
+// One self-consistent step on the device (single block): sums the `nparts` partial records of psum (the last
+// reduction level is folded in here to save a launch), then f'_k = f_k - log(psum_k / N_k) on sampled states
+// (mbar_solvers.py:231-242 via s_k), gauge f'[first] = 0 (:588), relative change (:627-631).  The new f is also
+// written to `f_hist` (the host picks the accepted iterate after a batch).
 __global__ void __launch_bounds__(256)
-k_sci_update(const double* __restrict__ psum, const double* __restrict__ Nk, const double* __restrict__ lnNk,
-             int64_t K, int64_t Kp, int first, double tol, double* __restrict__ f, double* __restrict__ aden,
-             double* __restrict__ delta_out) {
+k_sci_update(const double* __restrict__ part, int64_t nparts, int64_t rows, const double* __restrict__ Nk,
+             const double* __restrict__ lnNk, int64_t K, int64_t Kp, int first, double tol, double* __restrict__ f,
+             double* __restrict__ aden, double* __restrict__ f_hist, double* __restrict__ delta_out) {
     __shared__ double red[4];
     __shared__ double f0new;
+    extern __shared__ double psum[];  // Kp doubles, then 256 doubles of scratch
+    double* scr = psum + Kp;
+    // all 256 threads share the partial-record sum: thread (g, kk) adds records g, g + G, ... of state kk
+    for (int64_t k0 = 0; k0 < Kp; k0 += 256) {
+        const int64_t kw = Kp - k0 < 256 ? Kp - k0 : 256;   // states in this pass
+        int KW = 1;
+        while (KW < kw) KW <<= 1;                            // power of two >= kw, <= 256
+        const int G = 256 / KW, g = threadIdx.x / KW, kk = threadIdx.x % KW;
+        double sm = 0.0;
+        if (kk < kw)
+            for (int64_t p = g; p < nparts; p += G) sm += part[p * rows + k0 + kk];
+        scr[threadIdx.x] = sm;
+        __syncthreads();
+        if (threadIdx.x < kw) {
+            double tot = 0.0;
+            for (int gg = 0; gg < G; ++gg) tot += scr[gg * KW + threadIdx.x];
+            psum[k0 + threadIdx.x] = tot;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) f0new = f[first] - log(psum[first] / Nk[first]);
     __syncthreads();
     double dmax = 0.0;
@@ -1112,6 +1134,7 @@ k_sci_update(const double* __restrict__ psum, const double* __restrict__ Nk, con
             const double fo = f[k];
             const double fn = fo - log(psum[k] / Nk[k]) - f0new;
             f[k] = fn;
+            f_hist[k] = fn;
             aden[k] = fn + lnNk[k];
             if (k != first) {
                 const double div = fabs(fn) < small ? 1.0 : fabs(fn);
@@ -1120,6 +1143,7 @@ k_sci_update(const double* __restrict__ psum, const double* __restrict__ Nk, con
             }
         } else {
             aden[k] = -INFINITY;
+            f_hist[k] = k < K ? f[k] : 0.0;
         }
     }
     // NaN-propagating max
@@ -1437,10 +1461,22 @@ hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_
     return hipGetLastError();
 }
 
-hipError_t launch_sci_update(hipStream_t s, const double* psum, const double* Nk, const double* lnNk, int64_t K,
-                             int64_t Kp, int first_state, double tol, double* f, double* aden, double* delta_out) {
-    hipLaunchKernelGGL(k_sci_update, dim3(1), dim3(256), 0, s, psum, Nk, lnNk, K, Kp, first_state, tol, f, aden,
-                       delta_out);
+hipError_t launch_sci_update(hipStream_t s, const double* part, int64_t nparts, int64_t rows, const double* Nk,
+                             const double* lnNk, int64_t K, int64_t Kp, int first_state, double tol, double* f,
+                             double* aden, double* f_hist, double* delta_out) {
+    hipLaunchKernelGGL(k_sci_update, dim3(1), dim3(256), (size_t)(Kp + 256) * sizeof(double), s, part, nparts, rows, Nk, lnNk, K,
+                       Kp, first_state, tol, f, aden, f_hist, delta_out);
+    return hipGetLastError();
+}
+
+// first level only of the two-level reduction: out[c][i] = sum over the c-th chunk of 32 records; returns #chunks
+hipError_t launch_reduce_level1(hipStream_t s, const double* part, int64_t nparts, int64_t count, double* out,
+                                int64_t* nchunks) {
+    const int64_t chunk = 32;
+    const int64_t n1 = (nparts + chunk - 1) / chunk;
+    const unsigned gx = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(k_reduce, dim3(gx, (unsigned)n1), dim3(256), 0, s, part, nparts, count, chunk, out);
+    *nchunks = n1;
     return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@ for K, N in shapes:
         f0 = np.zeros(K)
         for timing in (1, 0):
             dm.set_option("timing", timing)
+            dm.set_option("graph", 0 if timing else 1)  # timing=1: eager launches with HIP events; timing=0: hipGraph batches
             dm.solve_sci(f0, maxiter=20, check_convergence=False)
             dm.synchronize()
             dm.timing_reset()
