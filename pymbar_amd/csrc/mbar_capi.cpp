@@ -181,6 +181,11 @@ int refresh_poison(mbar_ctx* c);
 // ---- device buffer helpers -------------------------------------------------------------------
 int ensure(mbar_ctx* c, double** p, size_t* have, size_t want) {
     if (*have >= want) return MBAR_OK;
+    if (c->sci_graph) {  // a captured SCI batch holds the old pointers
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGraphExecDestroy(c->sci_graph));
+        c->sci_graph = nullptr;
+    }
     if (*p) HIPCHK(c, hipFree(*p));
     *p = nullptr;
     *have = 0;
