@@ -272,7 +272,10 @@ int agree_with_rank0(mbar_ctx* c, double* v, int64_t count) {
 }
 
 // ---- evaluation building blocks -----------------------------------------------------------------
-bool use_fast(const mbar_ctx* c) { return c->K <= MAX_FAST_K && !c->opt_force_generic; }
+// The fused kernels address a tile row as (wave-uniform base) + (32-bit per-lane byte offset <= 7 ld 8 + 120).
+bool use_fast(const mbar_ctx* c) {
+    return c->K <= MAX_FAST_K && !c->opt_force_generic && (uint64_t)c->ld * 56u + 128u < (1ull << 32);
+}
 
 // Host vector a[k] = f[k] + ln N_k (-inf where N_k = 0 or k >= K), written into out[rows].
 void build_aden(const mbar_ctx* c, const double* f, double* out, int64_t rows) {
@@ -373,6 +376,9 @@ GramPlan gram_plan(int64_t Kp) {
 // device: rows of p sum to one (sum_k p_nk = 1, resp. sum_k N_k W_nk = 1), so they are column sums of the
 // reduced Gram matrix (gram_operand_sums below).
 int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan) {
+    if ((uint64_t)c->ld * 56u + 128u >= (1ull << 32))
+        return fail(c, MBAR_ERR_ARG, "Gram sweep: N_local must be below 7.6e7 samples per rank (32-bit tile offsets); "
+                                     "shard the sample axis over more ranks");
     const int64_t ntiles = (c->N + TS - 1) / TS;
     const bool dma = c->opt_staging == 0;
     for (const auto& it : plan.items) {

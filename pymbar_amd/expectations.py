@@ -1,0 +1,318 @@
+"""Expectations, perturbed free energies and entropy/enthalpy on the MI355X path.
+
+Host-side mirror of the ``Log_W_nk`` consumers of ``pymbar.MBAR``:
+``compute_expectations_inner`` (pymbar/mbar.py:732-1001), ``compute_expectations`` (:1039-1312),
+``compute_multiple_expectations`` (:1315-1439), ``compute_perturbed_free_energies`` (:1442-1521),
+``compute_entropy_and_enthalpy`` (:1524-1681), ``compute_covariance_of_sums`` (:1005-1036).
+
+The reference materialises an ``N x (K + NL + S)`` log-weight matrix on the host and runs ``logsumexp`` over
+the sample axis for every extra column.  Here every extra column is an *unsampled state* of an augmented
+reduced-potential matrix:
+
+* a new state ``l`` with potentials ``u_ln``                         ->  row ``u_ln``,
+* an observable ``A_i`` (shifted to be positive) at state ``l``      ->  row ``u_ln - log A_i``,
+
+so that, with ``N_k = 0`` for the extra rows,
+
+* their normalisers are the all-state log-space reduction the solver already uses for unsampled states
+  (``mbar_lognum``:  ``f_row = -log sum_n exp(-row_n - logden_n)``),
+* ``<A_i>_l = exp(lognum(A row) - lognum(l row))``, and
+* the covariance input ``W^T W`` of the augmented weight matrix is one MFMA Gram sweep (``mbar_gram_w``).
+
+No N x K array is formed on the host; only (K + NL + S)-sized linear algebra runs there.
+"""
+import logging
+
+import numpy as np
+
+from .utils import DataError, ParameterError, kln_to_kn, kn_to_n
+
+logger = logging.getLogger(__name__)
+
+_LOGFACTOR = 4.0 * np.finfo(np.float64).eps  # pymbar/mbar.py:827-832
+
+
+def _augmented_solve(mbar, u_kn, f_k, rows, device):
+    """Upload ``[u_kn; rows]`` with the extra rows unsampled; return (f_full, lognum, Gram W^T W or None fn)."""
+    from .device import DeviceMatrix
+
+    K = mbar.K
+    R = rows.shape[0]
+    aug = np.empty((K + R, u_kn.shape[1]), dtype=np.float64)
+    aug[:K] = u_kn
+    aug[K:] = rows
+    N_aug = np.zeros(K + R, dtype=np.float64)
+    N_aug[:K] = mbar.N_k
+    dm = DeviceMatrix.from_host(aug, device=device)
+    dm.set_Nk(N_aug)
+    f_full = np.zeros(K + R, dtype=np.float64)
+    f_full[:K] = f_k
+    lognum = dm.lognum(f_full)  # extra rows do not enter the denominator (N_k = 0)
+    f_full[K:] = -lognum[K:]
+    return dm, f_full, lognum, N_aug
+
+
+def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=None, warning_cutoff=1.0e-10,
+                               return_theta=False):
+    """Expectations of observables ``A_i`` at the states of ``u_ln`` selected by ``state_map``
+    (``[[states...],[observables...]]``, or a 1-D list of states for free energies only), with the covariance
+    ``Theta`` of the log normalisers.  Same inputs and result keys as pymbar/mbar.py:732-1001:
+    ``observables``, ``f``, ``Theta``, ``Amin`` (+ ``bootstrapped_observables`` / ``bootstrapped_f``)."""
+    state_map = np.asarray(state_map)
+    if state_map.ndim < 2:
+        state_list = np.array(state_map, dtype=int)
+        obs_list = np.zeros(0, dtype=int)
+    else:
+        state_list = np.array(state_map[0, :], dtype=int)
+        obs_list = np.array(state_map[1, :], dtype=int)
+    S = len(obs_list)
+    u_ln = np.asarray(u_ln, dtype=np.float64)
+    if u_ln.ndim == 1:
+        u_ln = u_ln.reshape(1, -1)
+    A_n = np.array(A_n, dtype=np.float64)  # private copy: shifted below
+    if A_n.ndim == 1:
+        A_n = A_n.reshape(1, -1)
+    K, N = mbar.K, mbar.N
+    L_list = np.unique(state_list)
+    NL = len(L_list)
+    col_of_state = {int(l): j for j, l in enumerate(L_list)}  # column K + j of the augmented matrix
+
+    # observables are made strictly positive so that they can live in log space (mbar.py:858-867)
+    A_used = np.unique(obs_list) if S > 0 else np.zeros(0, dtype=int)
+    A_min = np.zeros(len(A_n)) if S > 0 else np.zeros(0)
+    logfactors = np.zeros(len(A_n)) if S > 0 else np.zeros(0)
+    for i in A_used:
+        A_min[i] = np.min(A_n[i, :])
+        logfactors[i] = np.abs(_LOGFACTOR * A_min[i])
+        A_n[i, :] = A_n[i, :] - (A_min[i] - logfactors[i])
+
+    result_vals = dict()
+    bootstrap = uncertainty_method == "bootstrap"
+    n_total = mbar.n_bootstraps + 1 if bootstrap else 1
+    if bootstrap:
+        A_i_bootstrap = np.zeros([mbar.n_bootstraps, S])
+        f_bootstrap = np.zeros([mbar.n_bootstraps, len(state_list)])
+    Theta_ij = None
+    for n in range(n_total):
+        if n == 0:
+            f_k, ri, u_kn = mbar.f_k, slice(None), mbar.u_kn
+        else:
+            f_k, ri = mbar.f_k_boots[n - 1, :], mbar.bootstrap_rints[n - 1]
+            u_kn = mbar.u_kn[:, ri]
+        rows = np.empty((NL + S, N), dtype=np.float64)
+        for j, l in enumerate(L_list):
+            rows[j] = u_ln[l, ri]
+        with np.errstate(divide="ignore"):
+            for s in range(S):
+                rows[NL + s] = u_ln[state_list[s], ri] - np.log(A_n[obs_list[s], ri])
+        dm, f_full, lognum, N_aug = _augmented_solve(mbar, u_kn, f_k, rows, getattr(mbar, "_device", None))
+        try:
+            f_states = np.array([f_full[K + col_of_state[int(l)]] for l in state_list])
+            A_i = np.array([np.exp(lognum[K + NL + s] - lognum[K + col_of_state[int(state_list[s])]]) for s in range(S)])
+            if n == 0:
+                if S > 0:
+                    result_vals["observables"] = A_i + (A_min[obs_list] - logfactors[obs_list])
+                if return_theta:
+                    G, _ = dm.gram_w(f_full)
+                    Theta_ij = mbar._theta_from_gram(G, N_aug.astype(np.int64), uncertainty_method, dm=dm, f_full=f_full)
+                result_vals["f"] = f_states
+            else:
+                A_i_bootstrap[n - 1, :] = A_i + (A_min[obs_list] - logfactors[obs_list]) if S > 0 else 0.0
+                f_bootstrap[n - 1, :] = f_states
+        finally:
+            dm.close()
+    if bootstrap:
+        result_vals["bootstrapped_observables"] = A_i_bootstrap
+        result_vals["bootstrapped_f"] = f_bootstrap
+    if return_theta:
+        si = K + NL + np.arange(S)
+        li = K + np.array([col_of_state[int(l)] for l in state_list], dtype=int)
+        idx = np.concatenate((si, li)).astype(int)
+        result_vals["Theta"] = Theta_ij[np.ix_(idx, idx)]
+        if S > 0:
+            result_vals["Amin"] = A_min[obs_list] - logfactors[obs_list]
+    return result_vals
+
+
+def compute_covariance_of_sums(mbar, d_ij, K, a):
+    """Covariance of ``sum_k a_k (x_ik - x_jk)`` from the matrix of standard deviations ``d_ij`` of the
+    (nK x nK) differences (pymbar/mbar.py:1005-1036), vectorised."""
+    var = np.square(np.asarray(d_ij, dtype=np.float64))
+    a = np.asarray(a, dtype=np.float64)
+    n = len(a)
+    d2 = np.zeros([K, K], float)
+    ii = np.arange(K)
+    for k in range(n):
+        bk = var[k * K : (k + 1) * K]
+        d2 += a[k] ** 2 * bk[:, k * K : (k + 1) * K]
+        for l in range(n):
+            blk = bk[:, l * K : (l + 1) * K]                       # var[i + kK, j + lK]
+            blk_t = var[k * K : (k + 1) * K, l * K : (l + 1) * K].T   # var[j + kK, i + lK]
+            diag = blk[ii, ii]                                        # var[i + kK, i + lK]
+            d2 += a[k] * a[l] * (-diag[:, None] + blk + blk_t - diag[None, :])
+    return np.sqrt(d2)
+
+
+def _difference_covariance(inner, K):
+    """``cov(A_i, A_j)`` from the log-space Theta of (A-rows, state-rows) (mbar.py:1268-1281)."""
+    diag = np.ones(2 * K, dtype=np.float64)
+    diag[0:K] = diag[K : 2 * K] = inner["observables"] - inner["Amin"]
+    Theta = (diag[:, None] * inner["Theta"]) * diag[None, :]
+    cov = np.array(Theta[0:K, 0:K] + Theta[K : 2 * K, K : 2 * K] - Theta[0:K, K : 2 * K] - Theta[K : 2 * K, 0:K])
+    return Theta, cov
+
+
+def compute_expectations(mbar, A_n, u_kn=None, output="averages", state_dependent=False, compute_uncertainty=True,
+                         uncertainty_method=None, warning_cutoff=1.0e-10, return_theta=False):
+    """Expectation of an observable at every state of ``u_kn`` (default: the sampled states), as averages or as
+    differences between states, with uncertainties (pymbar/mbar.py:1039-1312)."""
+    if uncertainty_method == "bootstrap" and (mbar.n_bootstraps is None or mbar.n_bootstraps <= 0):
+        raise ParameterError("Cannot request bootstrap sampling of expectations without any bootstraps.")
+    dims = len(np.shape(A_n))
+    if dims > 2:
+        logger.warning("dim=3 (state_dependent) / dim=2 observables in K x N_max form are deprecated; use N-shaped inputs.")
+    if not state_dependent:
+        if dims == 2:
+            A_n = kn_to_n(A_n, N_k=mbar.N_k)
+            if u_kn is not None:
+                if len(np.shape(u_kn)) == 3:
+                    u_kn = kln_to_kn(u_kn, N_k=mbar.N_k)
+                elif len(np.shape(u_kn)) == 2:
+                    u_kn = kn_to_n(u_kn, N_k=mbar.N_k)
+    else:
+        if dims == 3:
+            A_n = kln_to_kn(A_n, N_k=mbar.N_k)
+            if u_kn is not None:
+                if len(np.shape(u_kn)) == 3:
+                    u_kn = kln_to_kn(u_kn, N_k=mbar.N_k)
+                elif len(np.shape(u_kn)) == 2:
+                    u_kn = kn_to_n(u_kn, N_k=mbar.N_k)
+    if u_kn is None:
+        u_kn = mbar.u_kn
+    K = 1 if len(np.shape(u_kn)) == 1 else np.shape(u_kn)[0]
+    state_map = np.zeros([2, K], int)
+    state_map[0, :] = np.arange(K)
+    if state_dependent:
+        state_map[1, :] = np.arange(K)
+    inner = compute_expectations_inner(mbar, A_n, u_kn, state_map, return_theta=compute_uncertainty,
+                                       uncertainty_method=uncertainty_method, warning_cutoff=warning_cutoff)
+    result_vals = dict()
+    Theta = covA_ij = None
+    if (compute_uncertainty and uncertainty_method != "bootstrap") or return_theta:
+        if "Theta" not in inner:
+            inner = compute_expectations_inner(mbar, A_n, u_kn, state_map, return_theta=True,
+                                               uncertainty_method=uncertainty_method, warning_cutoff=warning_cutoff)
+        Theta, covA_ij = _difference_covariance(inner, K)
+    if output == "averages":
+        result_vals["mu"] = inner["observables"]
+        if compute_uncertainty:
+            if uncertainty_method == "bootstrap":
+                result_vals["sigma"] = np.std(inner["bootstrapped_observables"], axis=0)
+            else:
+                result_vals["sigma"] = np.sqrt(covA_ij[0:K, 0:K].diagonal())
+    if output == "differences":
+        A_im = inner["observables"]
+        result_vals["mu"] = A_im - np.vstack(A_im)
+        if compute_uncertainty:
+            if uncertainty_method == "bootstrap":
+                Ab = inner["bootstrapped_observables"]
+                result_vals["sigma"] = np.std(Ab[:, np.newaxis, :] - Ab[:, :, np.newaxis], axis=0)
+            else:
+                result_vals["sigma"] = mbar._ErrorOfDifferences(covA_ij, warning_cutoff=warning_cutoff)
+    if return_theta:
+        result_vals["Theta"] = Theta
+    return result_vals
+
+
+def compute_multiple_expectations(mbar, A_in, u_n, compute_uncertainty=True, compute_covariance=False,
+                                  uncertainty_method=None, warning_cutoff=1.0e-10, return_theta=False):
+    """Several observables at one state ``u_n`` with uncertainties / covariances (pymbar/mbar.py:1315-1439)."""
+    A_in = np.asarray(A_in, dtype=np.float64)
+    I = A_in.shape[0]
+    if A_in.ndim == 3:
+        A_in = np.array([kn_to_n(A_in[i], N_k=mbar.N_k) for i in range(I)])
+    if len(np.shape(u_n)) == 2:
+        u_n = kn_to_n(u_n, N_k=mbar.N_k)
+    state_map = np.zeros([2, I], int)
+    state_map[1, :] = np.arange(I)
+    inner = compute_expectations_inner(mbar, A_in, u_n, state_map, return_theta=(compute_uncertainty or compute_covariance or return_theta),
+                                       uncertainty_method=uncertainty_method, warning_cutoff=warning_cutoff)
+    result_vals = dict(mu=inner["observables"])
+    if compute_uncertainty or compute_covariance or return_theta:
+        Theta, covA_ij = _difference_covariance(inner, I)
+        if compute_uncertainty:
+            result_vals["sigma"] = np.sqrt(covA_ij[0:I, 0:I].diagonal())
+        if compute_covariance:
+            result_vals["covariances"] = inner["Theta"][0:I, 0:I]
+        if return_theta:
+            result_vals["Theta"] = Theta
+    if uncertainty_method == "bootstrap":
+        if compute_uncertainty:
+            result_vals["sigma"] = np.std(inner["bootstrapped_observables"], axis=0)
+        if compute_covariance:
+            result_vals["covariances"] = np.cov(inner["bootstrapped_observables"].T)
+    return result_vals
+
+
+def compute_perturbed_free_energies(mbar, u_ln, compute_uncertainty=True, uncertainty_method=None, warning_cutoff=1.0e-10):
+    """Free energy differences among new states ``u_ln`` (L, N) (pymbar/mbar.py:1442-1521)."""
+    if len(np.shape(u_ln)) == 3:
+        u_ln = kln_to_kn(u_ln, N_k=mbar.N_k)
+    u_ln = np.asarray(u_ln, dtype=np.float64)
+    L, N = u_ln.shape
+    if N < mbar.N:
+        raise DataError("There seems to be too few samples in u_kn. You must evaluate at the new potential with all "
+                        "of the samples used originally.")
+    inner = compute_expectations_inner(mbar, np.array([0]), u_ln, np.arange(L), return_theta=compute_uncertainty,
+                                       uncertainty_method=uncertainty_method, warning_cutoff=warning_cutoff)
+    f_k = inner["f"]
+    result_vals = dict(Delta_f=f_k - np.vstack(f_k))
+    if compute_uncertainty:
+        if uncertainty_method == "bootstrap":
+            # (the reference returns the per-state spread here, not the spread of differences: mbar.py:1514)
+            result_vals["dDelta_f"] = np.std(inner["bootstrapped_f"], axis=0)
+        else:
+            result_vals["dDelta_f"] = mbar._ErrorOfDifferences(inner["Theta"], warning_cutoff=warning_cutoff)
+    return result_vals
+
+
+def compute_entropy_and_enthalpy(mbar, u_kn=None, uncertainty_method=None, verbose=False, warning_cutoff=1.0e-10):
+    """Decomposition of free energy differences into reduced enthalpy and entropy differences
+    (pymbar/mbar.py:1524-1681)."""
+    if verbose:
+        logger.info("Computing average energy and entropy by MBAR.")
+    if u_kn is not None and len(np.shape(u_kn)) == 3:
+        u_kn = kln_to_kn(u_kn, N_k=mbar.N_k)
+    if u_kn is None:
+        u_kn = mbar.u_kn
+    K, N = np.shape(u_kn)
+    state_map = np.vstack([np.arange(K), np.arange(K)])
+    inner = compute_expectations_inner(mbar, np.array(u_kn, dtype=np.float64), u_kn, state_map, return_theta=True,
+                                       uncertainty_method=uncertainty_method, warning_cutoff=warning_cutoff)
+    # covariance of (ln c_Ua, ln c_a, ln c_a again) -> u, f and s = u - f   (mbar.py:1600-1610)
+    Theta = np.zeros([3 * K, 3 * K], dtype=np.float64)
+    Theta[0 : 2 * K, 0 : 2 * K] = inner["Theta"]
+    Theta[2 * K : 3 * K, :] = Theta[K : 2 * K, :]
+    Theta[:, 2 * K : 3 * K] = Theta[:, K : 2 * K]
+    diag = np.ones(3 * K, dtype=np.float64)
+    diag[0:K] = diag[K : 2 * K] = inner["observables"] - inner["Amin"]
+    Theta = (diag[:, None] * Theta) * diag[None, :]
+    f_k = inner["f"]
+    u_k = inner["observables"]
+    s_k = u_k - f_k
+    result_vals = dict(Delta_f=f_k - np.vstack(f_k), Delta_u=u_k - np.vstack(u_k), Delta_s=s_k - np.vstack(s_k))
+    if uncertainty_method == "bootstrap":
+        fb = mbar.f_k_boots
+        ub = inner["bootstrapped_observables"]
+        sb = ub - fb
+        for name, arr in (("dDelta_f", fb), ("dDelta_u", ub), ("dDelta_s", sb)):
+            result_vals[name] = np.std(arr[:, np.newaxis, :] - arr[:, :, np.newaxis], axis=0)
+    else:
+        covf = Theta[2 * K : 3 * K, 2 * K : 3 * K]
+        covu = Theta[0:K, 0:K] + Theta[K : 2 * K, K : 2 * K] - Theta[0:K, K : 2 * K] - Theta[K : 2 * K, 0:K]
+        covs = (covu + covf + Theta[0:K, 2 * K : 3 * K] + Theta[2 * K : 3 * K, 0:K]
+                - Theta[K : 2 * K, 2 * K : 3 * K] - Theta[2 * K : 3 * K, K : 2 * K])
+        result_vals["dDelta_f"] = mbar._ErrorOfDifferences(covf, warning_cutoff=warning_cutoff)
+        result_vals["dDelta_u"] = mbar._ErrorOfDifferences(covu, warning_cutoff=warning_cutoff)
+        result_vals["dDelta_s"] = mbar._ErrorOfDifferences(covs, warning_cutoff=warning_cutoff)
+    return result_vals

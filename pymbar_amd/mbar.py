@@ -7,14 +7,16 @@ Host-side mirror of the part of ``pymbar.mbar.MBAR`` that touches the hot path (
 The reduced-potential matrix is uploaded once and stays resident; ``W^T W`` is contracted on the
 fp64 matrix cores and only K x K linear algebra (eigh / pinv) runs on the host.
 
-Not mirrored here (out of the hot-path scope): ``compute_expectations*``,
-``compute_perturbed_free_energies``, ``compute_entropy_and_enthalpy``, BAR initialisation.
+The ``Log_W_nk`` consumers (``compute_expectations*``, ``compute_perturbed_free_energies``,
+``compute_entropy_and_enthalpy``) live in :mod:`pymbar_amd.expectations` and are bound as
+methods below.  Not mirrored (not on the K x N solver path): BAR initialisation, FES, timeseries.
 """
 import copy
 import logging
 
 import numpy as np
 
+from . import expectations as _expectations
 from . import mbar_solvers
 from .mbar_solvers import (BOOTSTRAP_SOLVER_PROTOCOL, DEFAULT_SOLVER_PROTOCOL, JAX_SOLVER_PROTOCOL,
                            ROBUST_SOLVER_PROTOCOL)
@@ -121,6 +123,7 @@ class MBAR:
                                                       "bootstrap_solver_protocol")
 
         # the matrix goes to HBM once and stays there for the lifetime of the object
+        self._device = device
         self._dm = DeviceMatrix.from_host(self.u_kn, device=device)
         self.f_k = mbar_solvers.solve_mbar_for_all_states(self._dm, self.N_k, self.f_k, self.states_with_samples,
                                                           solver_protocol)
@@ -245,30 +248,47 @@ class MBAR:
         needs the explicit (N, K) matrix."""
         if method is None or method == "bootstrap":
             method = "svd-ew"
-        N_k = np.asarray(N_k)
-        K = N_k.size
         if method not in ("approximate", "svd", "svd-ew"):
             raise ParameterError(f"Method {method} unrecognized.")
+        N_k = np.asarray(N_k)
         if W is None and method != "svd":
             G, wsum = self._gram_w()
-            check_w_sums(wsum, 0.0)
-        else:
-            if W is None:
-                W = self.W_nk
-            N, Kw = W.shape
-            if Kw != K:
-                raise ParameterError("W must be NxK, where N_k is a K-dimensional array.")
-            if np.sum(N_k) != N:
-                raise ParameterError("W must be NxK, where N = sum_k N_k.")
-            from .utils import check_w_normalized
+            return self._theta_from_gram(G, N_k, method, wsum=wsum)
+        if W is None:
+            W = self.W_nk
+        N, Kw = W.shape
+        if Kw != N_k.size:
+            raise ParameterError("W must be NxK, where N_k is a K-dimensional array.")
+        if np.sum(N_k) != N:
+            raise ParameterError("W must be NxK, where N = sum_k N_k.")
+        from .utils import check_w_normalized
 
-            check_w_normalized(W, N_k)
-            G = W.T @ W
+        check_w_normalized(W, N_k)
+        return self._theta_from_gram(W.T @ W, N_k, method, W=W)
+
+    def _theta_from_gram(self, G, N_k, method=None, wsum=None, W=None, dm=None, f_full=None):
+        """``Theta`` from the Gram matrix ``G = W^T W`` (device MFMA sweep).  "svd-ew" (default):
+        eigendecomposition of ``G``, negative eigenvalues clamped, ``Theta = V S pinv(I - S V^T diag(N_k) V S,
+        rcond=1e-10) S V^T`` (mbar.py:1838-1858); "approximate": ``G`` itself (:1816); "svd" needs ``W`` (taken
+        from ``dm`` if not given) (:1818-1836)."""
+        if method is None or method == "bootstrap":
+            method = "svd-ew"
+        if method not in ("approximate", "svd", "svd-ew"):
+            raise ParameterError(f"Method {method} unrecognized.")
+        N_k = np.asarray(N_k)
+        K = N_k.size
+        if wsum is not None:
+            check_w_sums(wsum, 0.0)
         if method == "approximate":
             return G
         Ndiag = np.diag(N_k)
         ident = np.identity(K, dtype=np.float64)
         if method == "svd":
+            if W is None:
+                if dm is None:
+                    W = self.W_nk
+                else:
+                    W = np.exp(dm.logw_kn(f_full)).T
             _, S, Vt = np.linalg.svd(W, full_matrices=False)
             Sigma, V = np.diag(S), Vt.T
         else:
@@ -276,6 +296,14 @@ class MBAR:
             S2[np.where(S2 < 0.0)] = 0.0
             Sigma = np.diag(np.sqrt(S2))
         return V @ Sigma @ self._pseudoinverse(ident - Sigma @ V.T @ Ndiag @ V @ Sigma) @ Sigma @ V.T
+
+    # ---- Log_W_nk consumers (pymbar_amd/expectations.py) -------------------------------------------
+    compute_expectations_inner = _expectations.compute_expectations_inner
+    compute_covariance_of_sums = _expectations.compute_covariance_of_sums
+    compute_expectations = _expectations.compute_expectations
+    compute_multiple_expectations = _expectations.compute_multiple_expectations
+    compute_perturbed_free_energies = _expectations.compute_perturbed_free_energies
+    compute_entropy_and_enthalpy = _expectations.compute_entropy_and_enthalpy
 
     def _initializeFreeEnergies(self, verbose=False, method="zeros"):
         """Initial guess (mbar.py:1868-1917): zeros or the per-state mean reduced potential."""

@@ -90,6 +90,18 @@ def check_w_sums(column_sums, row_sum_dev, tolerance=1.0e-4):
         raise ParameterError("Warning: Should have \\sum__k N_k W_nk = 1.")
 
 
+def kn_to_n(kn, N_k=None, cleanup=False):
+    """(K, N_max) -> (N_total,) concatenation of the first N_k[k] entries of each row (pymbar/utils.py:78-114)."""
+    kn = np.asarray(kn)
+    K, N_max = kn.shape
+    if N_k is None:
+        N_k = N_max * np.ones([K], dtype=np.int64)
+    out = np.concatenate([kn[k, : int(N_k[k])] for k in range(K)]).astype(np.float64)
+    if cleanup:
+        del kn
+    return out
+
+
 def kln_to_kn(kln, N_k=None, cleanup=False):
     """(K, L, N_max) -> (L, N_total) concatenation of the first N_k[k] samples of each k
     (pymbar/utils.py:41-76)."""

@@ -101,6 +101,35 @@ def mbar_block(u_kn, N_k, **kw):
     return out
 
 
+def expectations_block(x_n, u_kn, N_k, **kw):
+    """Log_W_nk consumers of the reference (mbar.py:732-1681) on one data set."""
+    m = pymbar.MBAR(u_kn, N_k, **kw)
+    out = dict()
+    r = m.compute_expectations(x_n)
+    out["exp_x_mu"], out["exp_x_sigma"] = r["mu"], r["sigma"]
+    r = m.compute_expectations(x_n ** 2, output="differences")
+    out["exp_x2_diff_mu"], out["exp_x2_diff_sigma"] = r["mu"], r["sigma"]
+    r = m.compute_expectations(u_kn, state_dependent=True, return_theta=True)
+    out["exp_u_sd_mu"], out["exp_u_sd_sigma"], out["exp_u_sd_Theta"] = r["mu"], r["sigma"], r["Theta"]
+    u_new = u_kn[:3] * 1.1 + 0.3
+    r = m.compute_expectations(x_n, u_kn=u_new)
+    out["exp_x_newstates_mu"], out["exp_x_newstates_sigma"] = r["mu"], r["sigma"]
+    A_in = np.array([x_n, x_n ** 2, np.cos(x_n)])
+    r = m.compute_multiple_expectations(A_in, u_kn[1], compute_covariance=True)
+    out["multi_mu"], out["multi_sigma"], out["multi_cov"] = r["mu"], r["sigma"], r["covariances"]
+    r = m.compute_perturbed_free_energies(u_new)
+    out["pert_Delta_f"], out["pert_dDelta_f"] = r["Delta_f"], r["dDelta_f"]
+    r = m.compute_entropy_and_enthalpy()
+    for key in ("Delta_f", "dDelta_f", "Delta_u", "dDelta_u", "Delta_s", "dDelta_s"):
+        out["se_" + key] = r[key]
+    inner = m.compute_expectations_inner(A_in, u_kn[:2], np.array([[0, 0, 1, 1], [0, 1, 2, 1]]), return_theta=True)
+    out["inner_observables"], out["inner_f"], out["inner_Theta"], out["inner_Amin"] = (
+        inner["observables"], inner["f"], inner["Theta"], inner["Amin"])
+    d_ij = np.abs(np.sin(np.arange(36.0).reshape(6, 6))) + 0.1
+    out["cov_of_sums"] = m.compute_covariance_of_sums(d_ij + d_ij.T, 3, [0.5, -1.5])
+    return out
+
+
 def main():
     manifest = {}
 
@@ -130,6 +159,14 @@ def main():
     out["f_k_robust"] = out_r["f_k"]
     np.savez_compressed(os.path.join(HERE, "ho_unsampled_K4_N2300.npz"), **out)
     manifest["ho_unsampled_K4_N2300.npz"] = "test_mbar.py fixture shape (tests/test_mbar.py:44-60), seed=3"
+
+    # ---- expectations / perturbed free energies / entropy-enthalpy on two data sets -------------------------
+    x_n, u_kn, N_k, s_n, O_k, K_k = ts.config1(seed=0)
+    np.savez_compressed(os.path.join(HERE, "expectations_config1.npz"), **expectations_block(x_n, u_kn, N_k))
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn([1, 2, 3, 4], [0.5, 1.0, 1.5, 2.0], [1000, 500, 0, 800], seed=3)
+    np.savez_compressed(os.path.join(HERE, "expectations_unsampled.npz"), **expectations_block(x_n, u_kn, N_k))
+    manifest["expectations_config1.npz"] = "Log_W_nk consumers (mbar.py:732-1681) on config1 (seed 0); inputs regenerated from seed"
+    manifest["expectations_unsampled.npz"] = "same on the K=4 fixture with an unsampled state (seed 3)"
 
     # ---- exponentials 20 x 50 (tests/test_mbar_solvers.py:28 shape, smaller) ---------------------
     rates = np.linspace(1, 3, 20)
