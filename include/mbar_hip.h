@@ -85,6 +85,11 @@ int mbar_ctx_generate_harmonic(mbar_ctx* ctx, uint64_t seed, const double* O_k, 
  * such states contribute nothing to denominators (mbar_solvers.py:238 with b=N_k). */
 int mbar_ctx_set_Nk(mbar_ctx* ctx, const double* N_k);
 
+/* Per-sample multiplicities c_n >= 0 for this rank's N_local samples (NULL restores c_n = 1).  Every sum over
+ * samples becomes sum_n c_n (...): a bootstrap replicate (mbar.py:417-449, resampling the columns of u_kn within each
+ * state) is the vector of draw counts, so replicates re-use the resident matrix instead of a gathered copy. */
+int mbar_ctx_set_sample_weights(mbar_ctx* ctx, const double* c_n);
+
 /* ---- multi-GPU (one process per GPU; N sharded; one small all-reduce per pass) ------------- */
 int mbar_comm_unique_id(void* id128);                 /* rank 0: ncclGetUniqueId (128 bytes)     */
 int mbar_ctx_comm_init(mbar_ctx* ctx, const void* id128, int rank, int nranks); /* RCCL over xGMI */

@@ -79,6 +79,9 @@ struct mbar_ctx {
     double* u = nullptr;
     double* logden[3] = {nullptr, nullptr, nullptr};
     double* dn = nullptr;           // objective offsets (or null)
+    double* cw = nullptr;           // per-sample multiplicities (ld doubles; 1 on data, 0 on padding by default)
+    double* lden_eff = nullptr;     // logden - alpha ln c for the kernels that consume logden (only when weighted)
+    bool weighted = false;
     double* small = nullptr;        // aden[2][Kp] | anum[Kp] | f[Kp] | Nk[Kp] | lnNk[Kp] | delta[...]
     double* part = nullptr;         // per-wave partial records
     size_t part_doubles = 0;
@@ -300,7 +303,7 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
         double* obj_part = c->part + (size_t)g.nwaves * rec;
         {
             ScopedTimer t(c, MBAR_TIMER_LSE);
-            HIPCHK(c, launch_lse(c->stream, nb, nf, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), ld0,
+            HIPCHK(c, launch_lse(c->stream, nb, nf, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), c->cw, ld0,
                                  ld1, dn, psum_part, obj_part));
         }
         {
@@ -321,7 +324,7 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
         if (!ldst) ldst = c->logden[i];  // the column-sum kernel needs logden even if the caller does not
         {
             ScopedTimer t(c, MBAR_TIMER_LSE);
-            HIPCHK(c, launch_lse_generic(c->stream, c->num_cu, c->u, c->ld, c->N, c->K, d_aden(c) + i * rows,
+            HIPCHK(c, launch_lse_generic(c->stream, c->num_cu, c->u, c->ld, c->N, c->K, d_aden(c) + i * rows, c->cw,
                                          ldst, dn, c->part, &blocks));
         }
         {
@@ -330,7 +333,7 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
         }
         {
             ScopedTimer t(c, MBAR_TIMER_LSE);
-            HIPCHK(c, launch_colsum_generic(c->stream, c->num_cu, c->u, c->ld, c->N, c->K, d_aden(c) + i * rows,
+            HIPCHK(c, launch_colsum_generic(c->stream, c->num_cu, c->u, c->ld, c->N, c->K, d_aden(c) + i * rows, c->cw,
                                             ldst, c->part, &cblocks));
         }
         {
@@ -381,6 +384,10 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
                                      "shard the sample axis over more ranks");
     const int64_t ntiles = (c->N + TS - 1) / TS;
     const bool dma = c->opt_staging == 0;
+    if (c->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent
+        HIPCHK(c, launch_shift_logden(c->stream, logden, c->cw, 0.5, c->N, c->lden_eff));
+        logden = c->lden_eff;
+    }
     for (const auto& it : plan.items) {
         const int tile_rows = it.diag ? it.nb * 16 : 128;
         LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid, (int)c->opt_gram_variant);
@@ -734,6 +741,13 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
         CRT(hipMalloc((void**)&c->logden[i], (size_t)c->ld * sizeof(double)));
         CRT(hipMemsetAsync(c->logden[i], 0, (size_t)c->ld * sizeof(double), c->stream));
     }
+    CRT(hipMalloc((void**)&c->cw, (size_t)c->ld * sizeof(double)));
+    CRT(hipMemsetAsync(c->cw, 0, (size_t)c->ld * sizeof(double), c->stream));
+    {
+        std::vector<double> ones((size_t)c->N, 1.0);
+        CRT(hipMemcpyAsync(c->cw, ones.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        CRT(hipStreamSynchronize(c->stream));
+    }
     CRT(hipMalloc((void**)&c->small, small_doubles(c->Kp) * sizeof(double)));
     CRT(hipMemsetAsync(c->small, 0, small_doubles(c->Kp) * sizeof(double), c->stream));
     CRT(hipStreamSynchronize(c->stream));
@@ -755,6 +769,8 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     for (int i = 0; i < 3; ++i)
         if (c->logden[i]) hipFree(c->logden[i]);
     if (c->dn) hipFree(c->dn);
+    if (c->cw) hipFree(c->cw);
+    if (c->lden_eff) hipFree(c->lden_eff);
     if (c->small) hipFree(c->small);
     if (c->part) hipFree(c->part);
     if (c->scratch) hipFree(c->scratch);
@@ -854,6 +870,28 @@ int mbar_ctx_set_Nk(mbar_ctx* c, const double* N_k) {
     return MBAR_OK;
 }
 
+int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
+    if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<double> w((size_t)c->N, 1.0);
+    bool weighted = false;
+    if (c_n) {
+        for (int64_t n = 0; n < c->N; ++n) {
+            if (!(c_n[n] >= 0.0) || !std::isfinite(c_n[n])) return fail(c, MBAR_ERR_ARG, "sample weights must be finite and >= 0");
+            w[n] = c_n[n];
+            if (c_n[n] != 1.0) weighted = true;
+        }
+    }
+    if (weighted && !c->lden_eff) {
+        HIPCHK(c, hipMalloc((void**)&c->lden_eff, (size_t)c->ld * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->lden_eff, 0, (size_t)c->ld * sizeof(double), c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->cw, w.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->weighted = weighted;
+    return MBAR_OK;
+}
+
 int mbar_comm_unique_id(void* id128) {
     if (!id128) return fail(nullptr, MBAR_ERR_ARG, "id128 is NULL");
     std::string err;
@@ -949,9 +987,14 @@ int mbar_lognum(mbar_ctx* c, const double* f, double* lognum) {
     double* omax = psum + (size_t)c->K * nch;
     double* osum = omax + c->K;
     HIPCHK(c, hipMemsetAsync(d_anum(c), 0, (size_t)c->Kp * sizeof(double), c->stream));  // anum = 0
+    const double* lden = c->logden[0];
+    if (c->weighted) {  // log sum_n c_n exp(...) = log sum_n exp(... + ln c_n)
+        HIPCHK(c, launch_shift_logden(c->stream, c->logden[0], c->cw, 1.0, c->N, c->lden_eff));
+        lden = c->lden_eff;
+    }
     {
         ScopedTimer t(c, MBAR_TIMER_OTHER);
-        HIPCHK(c, launch_lognum(c->stream, c->u, c->ld, c->N, c->K, d_anum(c), c->logden[0], pmax, psum, nch));
+        HIPCHK(c, launch_lognum(c->stream, c->u, c->ld, c->N, c->K, d_anum(c), lden, pmax, psum, nch));
         HIPCHK(c, launch_lognum_merge(c->stream, pmax, psum, c->K, nch, omax, osum));
     }
     std::vector<double> hm(c->K), hs(c->K);
@@ -1247,10 +1290,10 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
             double* obj_part = c->part + (size_t)g.nwaves * rows;
             if (timed) {
                 ScopedTimer t(c, MBAR_TIMER_LSE);
-                HIPCHK(c, launch_lse(c->stream, nbk, 1, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), nullptr,
+                HIPCHK(c, launch_lse(c->stream, nbk, 1, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr,
                                      nullptr, nullptr, psum_part, obj_part));
             } else {
-                HIPCHK(c, launch_lse(c->stream, nbk, 1, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), nullptr,
+                HIPCHK(c, launch_lse(c->stream, nbk, 1, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr,
                                      nullptr, nullptr, psum_part, obj_part));
             }
             const double* upd_src = psum_part;

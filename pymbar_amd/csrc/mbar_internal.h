@@ -35,11 +35,12 @@ struct LaunchGeom {
 
 // ---- evaluation pass -------------------------------------------------------------------------
 // psum_part: [nwaves][nf][16*nb], obj_part: [nwaves][nf]; logden0/1 may be null (not stored).
+// cw: per-sample multiplicities (ld doubles: 1 for plain data, bootstrap counts otherwise, 0 on the padding).
 // variant 0: paired waves for nb >= 6 (two waves share a tile stream), 1: always one tile stream per wave
 LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant);
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g,
                       const double* u, int64_t ld, int64_t N, const double* aden /*[nf][16nb]*/,
-                      double* logden0, double* logden1, const double* dn,
+                      const double* cw, double* logden0, double* logden1, const double* dn,
                       double* psum_part, double* obj_part);
 
 // ---- Gram pass (known logden) ------------------------------------------------------------------
@@ -58,11 +59,14 @@ hipError_t launch_gram_off(hipStream_t s, bool dma, const LaunchGeom& g, const d
 
 // ---- layout-agnostic fallbacks (any K) ---------------------------------------------------------
 hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
-                              const double* aden, double* logden, const double* dn,
+                              const double* aden, const double* cw, double* logden, const double* dn,
                               double* obj_part /*[blocks]*/, int* blocks_out);
 hipError_t launch_colsum_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
-                                 const double* anum, const double* logden,
+                                 const double* anum, const double* cw, const double* logden,
                                  double* psum_part /*[blocks_x][K]*/, int* blocks_out);
+// out[n] = logden[n] - alpha ln cw[n] (+inf where cw = 0)
+hipError_t launch_shift_logden(hipStream_t s, const double* logden, const double* cw, double alpha, int64_t N,
+                               double* out);
 
 // ---- reductions / small kernels ----------------------------------------------------------------
 // out[i] = sum_p part[p*count + i]; scratch must hold ceil(nparts/32)*count doubles.

@@ -156,7 +156,7 @@ __device__ __forceinline__ void row16_sum2(double& a, double& b) {
 template <int NB, int NF>
 __device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl, int rd0, int rd1,
                                                const double (&a)[NB], const double (&c)[NB], double (&acc)[NF][NB],
-                                               bool valid0, bool valid1, double& m2_0, double& m2_1,
+                                               double w0, double w1, double& m2_0, double& m2_1,
                                                double (&s0)[NF], double (&s1)[NF]) {
     double x0[NB], x1[NB];
 #pragma unroll
@@ -182,7 +182,7 @@ __device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl
         s0[f] = tree_sum<NB>(x0);
         s1[f] = tree_sum<NB>(x1);
         row16_sum2(s0[f], s1[f]);
-        const double r0 = valid0 ? recip_fast(s0[f]) : 0.0, r1 = valid1 ? recip_fast(s1[f]) : 0.0;
+        const double r0 = w0 * recip_fast(s0[f]), r1 = w1 * recip_fast(s1[f]);  // w: sample multiplicity (0 on padding)
 #pragma unroll
         for (int I = 0; I < NB; ++I) acc[f][I] = fma(x1[I], r1, fma(x0[I], r0, acc[f][I]));
     }
@@ -191,7 +191,7 @@ __device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl
 // Single-group version for wide panels (NB > 8), where two groups in flight would spill registers.
 template <int NB, int NF>
 __device__ __forceinline__ void lse_one_group(const char* cbuf, const char* tbl, int rd0, const double (&a)[NB],
-                                              const double (&c)[NB], double (&acc)[NF][NB], bool valid0, double& m2_0,
+                                              const double (&c)[NB], double (&acc)[NF][NB], double w0, double& m2_0,
                                               double (&s0)[NF]) {
     double x0[NB];
 #pragma unroll
@@ -206,19 +206,21 @@ __device__ __forceinline__ void lse_one_group(const char* cbuf, const char* tbl,
             for (int I = 0; I < NB; ++I) x0[I] *= c[I];
         }
         s0[f] = row16_sum(tree_sum<NB>(x0));
-        const double r0 = valid0 ? recip_fast(s0[f]) : 0.0;
+        const double r0 = w0 * recip_fast(s0[f]);
 #pragma unroll
         for (int I = 0; I < NB; ++I) acc[f][I] = fma(x0[I], r0, acc[f][I]);
     }
 }
 // Two consecutive groups g, g+1 of a tile; (mm, ss[]) capture the (shift, sums) of the sample this lane will write.
 template <int NB, int NF>
-__device__ __forceinline__ void lse_group_pair(const char* cbuf, const char* tbl, int rd_base, const int (&pos)[GROUPS],
-                                               int g, const double (&a)[NB], const double (&c)[NB],
-                                               double (&acc)[NF][NB], int64_t n_first, int64_t N, int ks, int ns,
+__device__ __forceinline__ void lse_group_pair(const char* cbuf, const char* wslot, const char* tbl, int rd_base,
+                                               const int (&pos)[GROUPS], int g, const double (&a)[NB],
+                                               const double (&c)[NB], double (&acc)[NF][NB], int ks, int ns,
                                                double& mm, double (&ss)[NF]) {
     double m2a, m2b, sa[NF], sb[NF];
-    const bool va = (n_first + 4 * g + ns) < N, vb = (n_first + 4 * (g + 1) + ns) < N;
+    // per-sample multiplicities (1 for plain data, bootstrap counts otherwise, 0 on the padding) from the tile's slot
+    const double va = *reinterpret_cast<const double*>(wslot + (4 * g + ns) * 8);
+    const double vb = *reinterpret_cast<const double*>(wslot + (4 * (g + 1) + ns) * 8);
     if constexpr (NB <= 8) {
         lse_two_groups<NB, NF>(cbuf, tbl, rd_base + pos[g], rd_base + pos[g + 1], a, c, acc, va, vb, m2a, m2b, sa, sb);
     } else {
@@ -318,12 +320,14 @@ struct RowTwoPanels {
 template <int NB, int NF, bool DMA>
 __global__ void __launch_bounds__(256)
 k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
-      const double* __restrict__ aden, double* __restrict__ logden0, double* __restrict__ logden1,
-      const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+      const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+      double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
+      double* __restrict__ obj_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = NB * 16;
-    constexpr int TILE_BYTES = ROWS * TS * 8;
-    constexpr int NDMA = ROWS / 8;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
+    constexpr int NDMA = ROWS / 8 + 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
@@ -362,20 +366,26 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     int64_t t = gw;
     int cur = 0;
     if constexpr (DMA) {
-        if (t < ntiles) stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
+        if (t < ntiles) {
+            stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
+            stage_vec16<true>(cw, t * TS, buf + U_BYTES, lane);
+        }
     }
     for (; t < ntiles; t += W) {
         char* cbuf = buf + cur * TILE_BYTES;
         if constexpr (DMA) {
             const int64_t tn = t + W;
             if (tn < ntiles) {
-                stage_tile<ROWS, true, 0, 1>(u, ld, tn * TS, buf + (cur ^ 1) * TILE_BYTES, lane, so, rows);
+                char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+                stage_tile<ROWS, true, 0, 1>(u, ld, tn * TS, nbuf, lane, so, rows);
+                stage_vec16<true>(cw, tn * TS, nbuf + U_BYTES, lane);
                 wait_vm<NDMA>();
             } else {
                 wait_vm<0>();
             }
         } else {
             stage_tile<ROWS, false, 0, 1>(u, ld, t * TS, cbuf, lane, so, rows);
+            stage_vec16<false>(cw, t * TS, cbuf + U_BYTES, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -384,18 +394,19 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         for (int f = 0; f < NF; ++f) ss[f] = 1.0;
 #pragma unroll
         for (int g = 0; g < GROUPS; g += 2)
-            lse_group_pair<NB, NF>(cbuf, tbl, rd_base, pos, g, a, c, acc, t * TS, N, ks, ns, mm, ss);
+            lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, tbl, rd_base, pos, g, a, c, acc, ks, ns, mm, ss);
         // lanes with (ks & 3) == g hold (shift, sums) of sample 4 g + ns: one log per candidate per tile
         {
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
             const bool writer = (ks < 4) && (n < N);
+            const double wn = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * (ks & 3) + ns) * 8);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const double ldv = fma(mm, LN2_OVER_32, log(ss[f]));
                 if (writer) {
                     double* out = f == 0 ? logden0 : logden1;
                     if (out) out[n] = ldv;
-                    obj[f] += dn ? (ldv - dn[n]) : ldv;
+                    obj[f] = fma(wn, dn ? (ldv - dn[n]) : ldv, obj[f]);
                 }
             }
         }
@@ -424,12 +435,13 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // ---------------------------------------------------------------------------------------------
 template <int NB, int NF, bool DMA, int HALF, int STREAMS>
 __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
-                                              const double* __restrict__ aden, double* __restrict__ logden0,
-                                              double* __restrict__ logden1, const double* __restrict__ dn,
-                                              double* __restrict__ psum_part, double* __restrict__ obj_part,
-                                              char* smem, int lane, int stream) {
+                                              const double* __restrict__ aden, const double* __restrict__ cw,
+                                              double* __restrict__ logden0, double* __restrict__ logden1,
+                                              const double* __restrict__ dn, double* __restrict__ psum_part,
+                                              double* __restrict__ obj_part, char* smem, int lane, int stream) {
     constexpr int ROWS = NB * 16;
-    constexpr int TILE_BYTES = ROWS * TS * 8;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;
     constexpr int G0 = 2 * HALF;
     const int ks = lane & 15, ns = lane >> 4;
     const char* tbl = smem;  // initialised by the kernel prologue
@@ -465,6 +477,7 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
 
     auto stage_mine = [&](int64_t tile, char* dst) {
         stage_tile<ROWS, DMA, HALF, 2>(u, ld, tile * TS, dst, lane, so, rows);
+        if constexpr (HALF == 0) stage_vec16<DMA>(cw, tile * TS, dst + U_BYTES, lane);
     };
 
     int64_t t = gs;
@@ -480,16 +493,17 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
             double mm = 0.0, ss[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) ss[f] = 1.0;
-            lse_group_pair<NB, NF>(cbuf, tbl, rd_base, pos, G0, a, c, acc, t * TS, N, ks, ns, mm, ss);
+            lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, tbl, rd_base, pos, G0, a, c, acc, ks, ns, mm, ss);
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
             const bool writer = (ks >= G0) && (ks < G0 + 2) && (n < N);
+            const double wn = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * (ks & 3) + ns) * 8);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const double ldv = fma(mm, LN2_OVER_32, log(ss[f]));
                 if (writer) {
                     double* out = f == 0 ? logden0 : logden1;
                     if (out) out[n] = ldv;
-                    obj[f] += dn ? (ldv - dn[n]) : ldv;
+                    obj[f] = fma(wn, dn ? (ldv - dn[n]) : ldv, obj[f]);
                 }
             }
         }
@@ -513,8 +527,9 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
 template <int NB, int NF, bool DMA>
 __global__ void __launch_bounds__(NB <= 8 ? 512 : 256, 2)
 k_lse_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
-           const double* __restrict__ aden, double* __restrict__ logden0, double* __restrict__ logden1,
-           const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+           const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+           double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
+           double* __restrict__ obj_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STREAMS = NB <= 8 ? 4 : 2;
     const int lane = threadIdx.x & 63;
@@ -523,11 +538,11 @@ k_lse_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     exp_table_init(smem);
     __syncthreads();
     if (wave / STREAMS == 0)
-        lse_pair_body<NB, NF, DMA, 0, STREAMS>(u, ld, N, ntiles, aden, logden0, logden1, dn, psum_part, obj_part, smem,
-                                               lane, stream);
+        lse_pair_body<NB, NF, DMA, 0, STREAMS>(u, ld, N, ntiles, aden, cw, logden0, logden1, dn, psum_part, obj_part,
+                                               smem, lane, stream);
     else
-        lse_pair_body<NB, NF, DMA, 1, STREAMS>(u, ld, N, ntiles, aden, logden0, logden1, dn, psum_part, obj_part, smem,
-                                               lane, stream);
+        lse_pair_body<NB, NF, DMA, 1, STREAMS>(u, ld, N, ntiles, aden, cw, logden0, logden1, dn, psum_part, obj_part,
+                                               smem, lane, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -888,7 +903,7 @@ k_gram_xchg(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_lse_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
-              const double* __restrict__ aden, double* __restrict__ logden,
+              const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden,
               const double* __restrict__ dn, double* __restrict__ obj_part) {
     __shared__ double red[4];
     double obj = 0.0;
@@ -910,7 +925,7 @@ k_lse_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
         }
         const double ldv = m + log(s);
         if (logden) logden[n] = ldv;
-        obj += dn ? (ldv - dn[n]) : ldv;
+        obj = fma(cw[n], dn ? (ldv - dn[n]) : ldv, obj);
     }
     obj = wave_sum(obj);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = obj;
@@ -922,7 +937,7 @@ k_lse_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
 // blockIdx.y selects a group of 8 states.
 __global__ void __launch_bounds__(256)
 k_colsum_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
-                 const double* __restrict__ anum, const double* __restrict__ logden,
+                 const double* __restrict__ anum, const double* __restrict__ cw, const double* __restrict__ logden,
                  double* __restrict__ psum_part) {
     __shared__ double red[4][8];
     const int64_t k0 = (int64_t)blockIdx.y * 8;
@@ -930,11 +945,11 @@ k_colsum_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        const double ldv = logden[n];
+        const double ldv = logden[n], wn = cw[n];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t k = k0 + j;
-            if (k < K) acc[j] += exp(anum[k] - u[k * ld + n] - ldv);
+            if (k < K) acc[j] = fma(wn, exp(anum[k] - u[k * ld + n] - ldv), acc[j]);
         }
     }
 #pragma unroll
@@ -1064,6 +1079,18 @@ k_check_u(const double* __restrict__ u, int64_t ld, int64_t N, int* __restrict__
     if (f) atomicOr(flags, f);
 }
 
+// out[n] = logden[n] - alpha * ln(cw[n]): folds per-sample multiplicities into the exponent of the kernels that take
+// logden as an input (alpha = 1/2: each MFMA operand of the Gram sweep carries sqrt(c_n); alpha = 1: the log-space
+// per-state reduction).  c_n = 0 gives +inf, i.e. weight zero.
+__global__ void __launch_bounds__(256)
+k_shift_logden(const double* __restrict__ logden, const double* __restrict__ cw, double alpha, int64_t N,
+               double* __restrict__ out) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const double c = cw[n];
+        out[n] = c > 0.0 ? logden[n] - alpha * log(c) : INFINITY;
+    }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -1191,7 +1218,7 @@ static int blocks_per_cu_for(size_t lds_bytes) {
 
 LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant) {
     LaunchGeom g;
-    const size_t tile = (size_t)nb * 16 * TS * 8;
+    const size_t tile = (size_t)nb * 16 * TS * 8 + TS * 8;  // u tile + its 16 sample weights
     g.variant = (nb >= 6 && variant == 0 && !(nb > 8 && nf == 2)) ? 0 : 1;  // (wide two-candidate pairs would spill)
     int64_t cap;
     if (g.variant == 0) {  // paired: STREAMS tile streams x 2 waves
@@ -1241,7 +1268,7 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
 
 template <int NB, int NF, bool DMA>
 static hipError_t launch_lse_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
-                               const double* aden, double* l0, double* l1, const double* dn,
+                               const double* aden, const double* cw, double* l0, double* l1, const double* dn,
                                double* psum_part, double* obj_part) {
     auto kern = k_lse<NB, NF, DMA>;
     if (g.lds_bytes > 64 * 1024) {
@@ -1250,14 +1277,14 @@ static hipError_t launch_lse_t(hipStream_t s, const LaunchGeom& g, const double*
         if (e != hipSuccess) return e;
     }
     const int64_t ntiles = (N + TS - 1) / TS;
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, l0,
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
                        l1, dn, psum_part, obj_part);
     return hipGetLastError();
 }
 
 template <int NB, int NF, bool DMA>
 static hipError_t launch_lse_pair_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
-                                    const double* aden, double* l0, double* l1, const double* dn,
+                                    const double* aden, const double* cw, double* l0, double* l1, const double* dn,
                                     double* psum_part, double* obj_part) {
     auto kern = k_lse_pair<NB, NF, DMA>;
     if (g.lds_bytes > 64 * 1024) {
@@ -1266,37 +1293,37 @@ static hipError_t launch_lse_pair_t(hipStream_t s, const LaunchGeom& g, const do
         if (e != hipSuccess) return e;
     }
     const int64_t ntiles = (N + TS - 1) / TS;
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, l0,
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
                        l1, dn, psum_part, obj_part);
     return hipGetLastError();
 }
 
 template <int NB>
 static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeom& g, const double* u,
-                                int64_t ld, int64_t N, const double* aden, double* l0, double* l1,
+                                int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
                                 const double* dn, double* pp, double* op) {
     if constexpr (NB >= 6) {
         if (g.variant == 0) {
             if (nf == 1)
-                return dma ? launch_lse_pair_t<NB, 1, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
-                           : launch_lse_pair_t<NB, 1, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
-            return dma ? launch_lse_pair_t<NB, 2, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
-                       : launch_lse_pair_t<NB, 2, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
+                return dma ? launch_lse_pair_t<NB, 1, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
+                           : launch_lse_pair_t<NB, 1, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
+            return dma ? launch_lse_pair_t<NB, 2, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
+                       : launch_lse_pair_t<NB, 2, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
         }
     }
     if (nf == 1)
-        return dma ? launch_lse_t<NB, 1, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
-                   : launch_lse_t<NB, 1, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
-    return dma ? launch_lse_t<NB, 2, true>(s, g, u, ld, N, aden, l0, l1, dn, pp, op)
-               : launch_lse_t<NB, 2, false>(s, g, u, ld, N, aden, l0, l1, dn, pp, op);
+        return dma ? launch_lse_t<NB, 1, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
+                   : launch_lse_t<NB, 1, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
+    return dma ? launch_lse_t<NB, 2, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
+               : launch_lse_t<NB, 2, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
 }
 
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,
-                      int64_t ld, int64_t N, const double* aden, double* l0, double* l1, const double* dn,
-                      double* pp, double* op) {
+                      int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
+                      const double* dn, double* pp, double* op) {
     switch (nb) {
 #define MBAR_CASE(NB_) \
-    case NB_: return launch_lse_nb<NB_>(s, nf, dma, g, u, ld, N, aden, l0, l1, dn, pp, op);
+    case NB_: return launch_lse_nb<NB_>(s, nf, dma, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
         MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7)
         MBAR_CASE(8) MBAR_CASE(12) MBAR_CASE(16)
 #undef MBAR_CASE
@@ -1386,21 +1413,22 @@ static int stream_blocks(int num_cu, int64_t N) {
 }
 
 hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
-                              const double* aden, double* logden, const double* dn, double* obj_part,
-                              int* blocks_out) {
+                              const double* aden, const double* cw, double* logden, const double* dn,
+                              double* obj_part, int* blocks_out) {
     const int blocks = stream_blocks(num_cu, N);
     *blocks_out = blocks;
-    hipLaunchKernelGGL(k_lse_generic, dim3(blocks), dim3(256), 0, s, u, ld, N, K, aden, logden, dn, obj_part);
+    hipLaunchKernelGGL(k_lse_generic, dim3(blocks), dim3(256), 0, s, u, ld, N, K, aden, cw, logden, dn, obj_part);
     return hipGetLastError();
 }
 
 hipError_t launch_colsum_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
-                                 const double* anum, const double* logden, double* psum_part, int* blocks_out) {
+                                 const double* anum, const double* cw, const double* logden, double* psum_part,
+                                 int* blocks_out) {
     int blocks = stream_blocks(num_cu, N);
     if (blocks > 512) blocks = 512;
     *blocks_out = blocks;
     hipLaunchKernelGGL(k_colsum_generic, dim3(blocks, (unsigned)((K + 7) / 8)), dim3(256), 0, s, u, ld, N, K,
-                       anum, logden, psum_part);
+                       anum, cw, logden, psum_part);
     return hipGetLastError();
 }
 
@@ -1447,6 +1475,15 @@ hipError_t launch_check_u(hipStream_t s, const double* u, int64_t ld, int64_t N,
     if (bx > 1024) bx = 1024;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(k_check_u, dim3((unsigned)bx, (unsigned)K), dim3(256), 0, s, u, ld, N, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_shift_logden(hipStream_t s, const double* logden, const double* cw, double alpha, int64_t N,
+                               double* out) {
+    int64_t bx = (N + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_shift_logden, dim3((unsigned)bx), dim3(256), 0, s, logden, cw, alpha, N, out);
     return hipGetLastError();
 }
 

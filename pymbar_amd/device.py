@@ -116,6 +116,17 @@ class DeviceMatrix:
             self._check(self._lib.mbar_ctx_set_Nk(self._ctx, _dptr(Nk)))
             self._Nk = Nk.copy()
 
+    def set_sample_weights(self, c_n):
+        """Per-sample multiplicities (``None`` restores 1): every sum over samples becomes ``sum_n c_n (...)``.
+        A bootstrap replicate is ``np.bincount(resampled_indices, minlength=N)``."""
+        if c_n is None:
+            self._check(self._lib.mbar_ctx_set_sample_weights(self._ctx, None))
+            return
+        c_n = np.ascontiguousarray(c_n, dtype=np.float64)
+        if c_n.shape != (self.N_local,):
+            raise ValueError(f"sample weights must have shape ({self.N_local},)")
+        self._check(self._lib.mbar_ctx_set_sample_weights(self._ctx, _dptr(c_n)))
+
     # ---- multi-GPU --------------------------------------------------------------------------------
     def comm_init_rccl(self, unique_id, rank, nranks):
         buf = C.create_string_buffer(bytes(unique_id), 128)

@@ -138,9 +138,13 @@ class MBAR:
                 for k in range(K):
                     k_indices = np.where(self.x_kindices == k)[0]
                     rints[k_indices] = k_indices[self.rng.integers(int(self.N_k[k]), size=int(self.N_k[k]))]
-                with DeviceMatrix.from_host(self.u_kn[:, rints], device=device) as dmb:
+                # a replicate is the vector of draw counts: the resident matrix is re-used, nothing is gathered
+                self._dm.set_sample_weights(np.bincount(rints, minlength=self.N))
+                try:
                     self.f_k_boots[b, :] = mbar_solvers.solve_mbar_for_all_states(
-                        dmb, self.N_k, self.f_k.copy(), self.states_with_samples, bootstrap_solver_protocol)
+                        self._dm, self.N_k, self.f_k.copy(), self.states_with_samples, bootstrap_solver_protocol)
+                finally:
+                    self._dm.set_sample_weights(None)
                 self.bootstrap_rints[b, :] = rints
         elif n_bootstraps < 0:
             logger.warning("n_bootstraps must be an integer >= 0")

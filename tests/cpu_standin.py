@@ -44,6 +44,17 @@ class OracleMatrix:
     def set_Nk(self, N_k):
         self.Nk = np.asarray(N_k, dtype=np.float64).copy()
 
+    def set_sample_weights(self, c_n):
+        """Multiplicities are emulated by materialising the resampled matrix (column n repeated c_n times)."""
+        if not hasattr(self, "u_full"):
+            self.u_full = self.u
+        if c_n is None:
+            self.u = self.u_full
+        else:
+            c = np.asarray(c_n)
+            assert np.all(c == np.round(c)) and c.shape == (self.u_full.shape[1],)
+            self.u = np.repeat(self.u_full, c.astype(int), axis=1)
+
     def _reduce(self, arr, op="sum"):
         if self.allreduce is not None:
             self.allreduce(arr, op)

@@ -160,6 +160,60 @@ def test_invariances_and_extreme_energies(DM):
         np.testing.assert_allclose(pbad[0], oracle.shard_partials(u_kn, N_k, f_bad)["psum"], rtol=1e-10, atol=1e-9)
 
 
+def test_sample_weights_equal_explicit_resampling(DM):
+    """Bootstrap replicates as per-sample multiplicities on the resident matrix == the reference's gathered copy
+    u_kn[:, rints] (mbar.py:417-449): every sweep, the all-state update, the covariance input and a whole solve."""
+    u_kn, N_k, f = random_problem(24, 3000, seed=41, unsampled=(5,))
+    rng = np.random.RandomState(2)
+    rints = np.concatenate([np.sort(rng.randint(a, b, size=b - a)) if b > a else np.zeros(0, int)
+                            for a, b in zip(np.cumsum(N_k) - N_k, np.cumsum(N_k))]).astype(int)
+    u_res = np.ascontiguousarray(u_kn[:, rints])
+    counts = np.bincount(rints, minlength=3000)
+    assert counts.sum() == 3000 and counts.max() > 1 and (counts == 0).any()
+    for force in (0, 1):
+        with DM.from_host(u_kn) as dm:
+            dm.set_option("force_generic", force)
+            dm.set_Nk(N_k)
+            dm.set_sample_weights(counts)
+            ps, sl, G = dm.eval(f, gram=True)
+            part = oracle.shard_partials(u_res, N_k, f, want_gram=True)
+            np.testing.assert_allclose(ps[0], part["psum"], rtol=1e-11, atol=1e-10)
+            np.testing.assert_allclose(sl[0], part["sumlogden"], rtol=1e-12)
+            np.testing.assert_allclose(G, part["gram"], rtol=1e-10, atol=1e-11)
+            np.testing.assert_allclose(ms.self_consistent_update(dm, N_k, f), oracle.self_consistent_update(u_res, N_k, f),
+                                       rtol=1e-12, atol=1e-11)
+            GW, ws = dm.gram_w(f)
+            W = oracle.mbar_W_nk(u_res, N_k, f)
+            np.testing.assert_allclose(GW, W.T @ W, rtol=1e-10, atol=1e-14)
+            np.testing.assert_allclose(ws, W.sum(0), rtol=1e-10)
+            sws = np.where(N_k > 0)[0]
+            fw = ms.solve_mbar_for_all_states(dm, N_k, np.zeros(24), sws, ms.BOOTSTRAP_SOLVER_PROTOCOL)
+            fr, _ = oracle.solve_mbar_for_all_states(u_res, N_k, np.zeros(24), sws, tol=1e-12, min_sc_iter=0)
+            np.testing.assert_allclose(fw, fr, rtol=1e-9, atol=1e-10)
+            dm.set_sample_weights(None)  # back to the plain data
+            ps1, _, _ = dm.eval(f)
+            np.testing.assert_allclose(ps1[0], oracle.shard_partials(u_kn, N_k, f)["psum"], rtol=1e-11, atol=1e-10)
+
+
+def test_mbar_bootstrap_on_gpu():
+    """n_bootstraps through the MBAR class: deterministic under rseed (reference tests/test_mbar.py:533-545) and
+    equal to solving each gathered replicate with the oracle."""
+    import pymbar_amd
+
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn([0.0, 1.0, 2.0, 3.0], [1.0, 2.0, 3.0, 4.0], [300, 0, 250, 200], seed=4)
+    a = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=4, rseed=11)
+    b = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=4, rseed=11)
+    assert np.array_equal(a.f_k_boots, b.f_k_boots)
+    sws = np.where(N_k > 0)[0]
+    for i in range(4):
+        fr, _ = oracle.solve_mbar_for_all_states(u_kn[:, a.bootstrap_rints[i]], N_k, a.f_k.copy(), sws, tol=1e-12, min_sc_iter=0)
+        np.testing.assert_allclose(a.f_k_boots[i], fr, rtol=1e-8, atol=1e-9)
+    r = a.compute_free_energy_differences(uncertainty_method="bootstrap")
+    assert r["dDelta_f"].shape == (4, 4) and np.all(np.isfinite(r["dDelta_f"]))
+    a.close()
+    b.close()
+
+
 def test_two_candidates_far_apart(DM):
     """The fused two-candidate sweep derives the second candidate from the first one's exponentials through
     exp(a'_k - a_k); candidates hundreds of kT apart take the two-sweep fallback.  Both must match the oracle."""
