@@ -99,7 +99,7 @@ struct mbar_ctx {
     double sci_graph_tol = 0.0;
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1;
-    int64_t opt_lse_variant = 1, opt_gram_variant = 0;  // measured best: independent-wave LSE sweep, operand-exchange Gram
+    int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
     // comm
     ncclComm_t comm = nullptr;
     mbar_allreduce_fn host_reduce = nullptr;

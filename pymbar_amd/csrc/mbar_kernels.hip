@@ -63,43 +63,94 @@ __device__ __forceinline__ double wave_max(double x) {
 
 // exp built for instruction count (gfx950 issues one fp64 VALU op per ~5.6 cycles per SIMD and fp64 MFMA does
 // not overlap with VALU -- profiles/r1_*microbench.txt -- so every fp64 instruction here is kernel time).
-// 2^(t/32) for t = 32 x log2(e):   s = rint(max(t, -35200));  z = t - s in [-1/2, 1/2];
-//   j = s & 31, q = s >> 5;   result = ldexp(T[j] * P(z), q),  T[j] = 2^(j/32) from a 256-byte LDS table
-//   (one 64-bank row: conflict-free for any lane pattern), P = degree-6 near-minimax polynomial of 2^(z/32)
-//   (tools/gen_exp2_table.py).  12 fp64 instructions (the library exp needs ~25), max error 1.9 ulp, mean
-//   0.4 ulp (tools/exp2tab_test.c).  exp(-inf) = 0 through the clamp, overflow gives inf through ldexp; NaN
-//   arguments are laundered to 0 by the clamp, which is why NaN / -inf entries of u_kn and non-finite f_k are
-//   detected at the boundary instead (mbar_capi.cpp).
+// 2^(t/S) for t = S x log2(e), S = 2^EXP2_BITS = 2048:   s = rint(max(t, EXP2_CLAMP));  z = t - s in [-1/2, 1/2];
+//   j = s & (S-1), q = s >> EXP2_BITS;   result = ldexp(T[j] * P(z), q),  T[j] = 2^(j/S) from a 16 KB LDS table at
+//   LDS offset 0, P = degree-3 polynomial of 2^(z/S) (error 9e-18; tools/gen_exp2_table.py).  Nine fp64 + three
+//   integer instructions (the library exp needs ~25).  exp(-inf) = 0 through the clamp, overflow gives inf through
+//   ldexp; NaN arguments are laundered to 0 by the clamp, which is why NaN / -inf entries of u_kn and non-finite f_k
+//   are detected at the boundary instead (mbar_capi.cpp).
+#include "exp2_table.inc"
 constexpr double LOG2E = 0x1.71547652b82fep+0, LN2 = 0x1.62e42fefa39efp-1;
-constexpr double LOG2E_32 = 32.0 * LOG2E, LN2_OVER_32 = LN2 / 32.0;
-constexpr int EXP_TABLE_BYTES = 256;
-__device__ const double EXP2_TABLE[32] = {
-    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
-    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
-    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
-    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
-    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
-    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
-    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
-// every thread block copies the table into its LDS once (tbl must be 256-byte aligned); callers barrier after
-__device__ __forceinline__ void exp_table_init(char* tbl) {
-    if (threadIdx.x < 32) reinterpret_cast<double*>(tbl)[threadIdx.x] = EXP2_TABLE[threadIdx.x];
+constexpr double EXP2_S = (double)(1 << EXP2_BITS);
+constexpr double LOG2E_S = EXP2_S * LOG2E, LN2_OVER_S = LN2 / EXP2_S;
+constexpr double EXP2_CLAMP = -1100.0 * EXP2_S;
+constexpr int EXP_TABLE_BYTES = (1 << EXP2_BITS) * 8;
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+// Every thread block copies the table to LDS offset 0 (its dynamic LDS starts there: the kernels have no static
+// __shared__), so a look-up address is just the masked integer -- no base add.  Callers barrier afterwards.
+__device__ __forceinline__ void exp_table_init(char* smem) {
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+    for (int i = threadIdx.x; i < (1 << EXP2_BITS); i += blockDim.x) reinterpret_cast<double*>(smem)[i] = EXP2_TABLE[i];
 }
-__device__ __forceinline__ double exp2s_fast(double t32, const char* tbl) {  // 2^(t32 / 32)
-    const double t = fmax(t32, -35200.0);
+__device__ __forceinline__ double exp2_table_at(int si) {
+    return *(lds_cdouble*)(uint32_t)((si << 3) & (EXP_TABLE_BYTES - 8));
+}
+__device__ __forceinline__ double exp2_poly(double z) {
+    double p = EXP2_POLY[EXP2_DEG];
+#pragma unroll
+    for (int k = EXP2_DEG - 1; k >= 0; --k) p = fma(p, z, EXP2_POLY[k]);
+    return p;
+}
+__device__ __forceinline__ double exp2s_fast(double ts) {  // 2^(ts / S)
+    const double t = fmax(ts, EXP2_CLAMP);
     const double s = __builtin_rint(t);
     const double z = t - s;
     const int si = (int)s;
-    const double T = *reinterpret_cast<const double*>(tbl + ((si & 31) << 3));
-    double p = 0x1.4412492492492p-43;
-    p = fma(p, z, 0x1.5d88592492492p-35);
-    p = fma(p, z, 0x1.3b2ab695b6db7p-27);
-    p = fma(p, z, 0x1.c6b08d7038492p-20);
-    p = fma(p, z, 0x1.ebfbdff82c7f7p-13);
-    p = fma(p, z, 0x1.62e42fefa39efp-6);
-    p = fma(p, z, 1.0);
-    return ldexp(T * p, si >> 5);
+    const double T = exp2_table_at(si);
+    return ldexp(T * exp2_poly(z), si >> EXP2_BITS);
+}
+// The same exp for N independent arguments, written as three stages separated by scheduling barriers: with one
+// or two waves per SIMD nothing else hides the LDS latency of the table look-up, and hipcc's own schedule leaves
+// only a handful of instructions between each ds_read and its use.  Stage 1 issues all N table reads, stage 2 (the
+// polynomials) runs while they are in flight, stage 3 combines.  x[] in: ts, out: 2^(ts/S).
+template <int N>
+__device__ __forceinline__ void exp2s_batch(double (&x)[N]) {
+    double T[N];
+    int q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double t = fmax(x[i], EXP2_CLAMP);
+        const double s = __builtin_rint(t);
+        x[i] = t - s;
+        const int si = (int)s;
+        q[i] = si >> EXP2_BITS;
+        T[i] = exp2_table_at(si);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = exp2_poly(x[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = ldexp(T[i] * x[i], q[i]);
+}
+template <int N>
+__device__ __forceinline__ void exp2s_batch2(double (&x0)[N], double (&x1)[N]) {  // two argument sets, one pipeline
+    double T0[N], T1[N];
+    int q0[N], q1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double t0 = fmax(x0[i], EXP2_CLAMP), t1 = fmax(x1[i], EXP2_CLAMP);
+        const double s0 = __builtin_rint(t0), s1 = __builtin_rint(t1);
+        x0[i] = t0 - s0;
+        x1[i] = t1 - s1;
+        const int i0 = (int)s0, i1 = (int)s1;
+        q0[i] = i0 >> EXP2_BITS;
+        q1[i] = i1 >> EXP2_BITS;
+        T0[i] = exp2_table_at(i0);
+        T1[i] = exp2_table_at(i1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        x0[i] = exp2_poly(x0[i]);
+        x1[i] = exp2_poly(x1[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        x0[i] = ldexp(T0[i] * x0[i], q0[i]);
+        x1[i] = ldexp(T1[i] * x1[i], q1[i]);
+    }
 }
 // 1 / s for s > 0: hardware estimate + two Newton steps (the divide expansion costs twice as many instructions)
 __device__ __forceinline__ double recip_fast(double s) {
@@ -166,13 +217,14 @@ __device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl
     }
     double m0 = tree_max<NB>(x0), m1 = tree_max<NB>(x1);
     row16_max2(m0, m1);
-    m2_0 = m0 * LOG2E_32;
-    m2_1 = m1 * LOG2E_32;
+    m2_0 = m0 * LOG2E_S;
+    m2_1 = m1 * LOG2E_S;
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
-        x0[I] = exp2s_fast(fma(x0[I], LOG2E_32, -m2_0), tbl);
-        x1[I] = exp2s_fast(fma(x1[I], LOG2E_32, -m2_1), tbl);
+        x0[I] = fma(x0[I], LOG2E_S, -m2_0);
+        x1[I] = fma(x1[I], LOG2E_S, -m2_1);
     }
+    exp2s_batch2<NB>(x0, x1);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         if (f == 1) {
@@ -196,9 +248,10 @@ __device__ __forceinline__ void lse_one_group(const char* cbuf, const char* tbl,
     double x0[NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I) x0[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
-    m2_0 = row16_max(tree_max<NB>(x0)) * LOG2E_32;
+    m2_0 = row16_max(tree_max<NB>(x0)) * LOG2E_S;
 #pragma unroll
-    for (int I = 0; I < NB; ++I) x0[I] = exp2s_fast(fma(x0[I], LOG2E_32, -m2_0), tbl);
+    for (int I = 0; I < NB; ++I) x0[I] = fma(x0[I], LOG2E_S, -m2_0);
+    exp2s_batch<NB>(x0);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         if (f == 1) {
@@ -333,7 +386,7 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int nwv = blockDim.x >> 6;
     const int ks = lane & 15, ns = lane >> 4;
     char* tbl = smem;  // exp table in the first 256 bytes, tiles behind it
-    exp_table_init(tbl);
+    exp_table_init(smem);
     __syncthreads();
     char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
@@ -402,7 +455,7 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             const double wn = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * (ks & 3) + ns) * 8);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const double ldv = fma(mm, LN2_OVER_32, log(ss[f]));
+                const double ldv = fma(mm, LN2_OVER_S, log(ss[f]));
                 if (writer) {
                     double* out = f == 0 ? logden0 : logden1;
                     if (out) out[n] = ldv;
@@ -499,7 +552,7 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
             const double wn = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * (ks & 3) + ns) * 8);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const double ldv = fma(mm, LN2_OVER_32, log(ss[f]));
+                const double ldv = fma(mm, LN2_OVER_S, log(ss[f]));
                 if (writer) {
                     double* out = f == 0 ? logden0 : logden1;
                     if (out) out[n] = ldv;
@@ -551,6 +604,7 @@ k_lse_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // triangular blocks only; otherwise an NBI x NBJ rectangle between two panels.
 // Output block b, register r, lane l  ->  element (row = (l >> 4) + 4 r, col = l & 15) of block b.
 // ---------------------------------------------------------------------------------------------
+constexpr int GRAM8_AGPR_BLOCKS = 31;
 template <int NBI, int NBJ, bool DIAG, bool DMA>
 __global__ void __launch_bounds__(256, 1)
 k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
@@ -569,7 +623,7 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int nwv = blockDim.x >> 6;
     const int ks = lane & 15, ns = lane >> 4;
     char* tbl = smem;
-    exp_table_init(tbl);
+    exp_table_init(smem);
     __syncthreads();
     char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
@@ -582,6 +636,9 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     for (int I = 0; I < NBT; ++I) a[I] = (DIAG || I < NBI) ? anum_i[16 * I + ks] : anum_j[16 * (I - NBI) + ks];
 #pragma unroll
     for (int I = 0; I < NBT; ++I) settle(a[I]);
+    double aS[NBT];  // exponent arguments are formed directly in table units: t = (a - logden - u) S log2(e)
+#pragma unroll
+    for (int I = 0; I < NBT; ++I) aS[I] = a[I] * LOG2E_S;
     v4d acc[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -617,21 +674,40 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        double ldc[GROUPS];
+        // every LDS operand of the tile is requested up front (one exposed LDS round trip per tile)
+        double ldc[GROUPS], uv[GROUPS][NBT];
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g)
+        for (int g = 0; g < GROUPS; ++g) {
             ldc[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+#pragma unroll
+            for (int I = 0; I < NBT; ++I)
+                uv[g][I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const bool valid = (t * TS + 4 * g + ns) < N;
             const double lde = valid ? ldc[g] : INFINITY;  // padded samples: exp(-inf) = 0
             double p[NBT];
 #pragma unroll
-            for (int I = 0; I < NBT; ++I) {
-                const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
-                p[I] = exp2s_fast(((a[I] - lde) - uv) * LOG2E_32, tbl);
-            }
-            if constexpr (DIAG) {
+            for (int I = 0; I < NBT; ++I) p[I] = fma(uv[g][I], -LOG2E_S, aS[I] - lde * LOG2E_S);
+            exp2s_batch<NBT>(p);
+            if constexpr (DIAG && NBI == 8) {
+                // 36 blocks = 288 accumulator registers: more than the 256 AGPRs, and hipcc then rotates every
+                // accumulator through v_accvgpr copies.  The register class is pinned per block instead: the first
+                // GRAM8_AGPR_BLOCKS live in AGPRs, the rest in VGPRs (the wave owns the SIMD's whole register file).
+                int b = 0;
+#pragma unroll
+                for (int I = 0; I < NBI; ++I)
+#pragma unroll
+                    for (int J = I; J < NBI; ++J) {
+                        if (b < GRAM8_AGPR_BLOCKS)
+                            asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(p[I]), "v"(p[J]));
+                        else
+                            asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(p[I]), "v"(p[J]));
+                        ++b;
+                    }
+            } else if constexpr (DIAG) {
                 int b = 0;
 #pragma unroll
                 for (int I = 0; I < NBI; ++I)
@@ -650,6 +726,10 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             }
         }
         cur ^= 1;
+    }
+    if constexpr (DIAG && NBI == 8) {
+        // the asm MFMAs are opaque to the hazard recogniser: cover the matrix-result -> VALU read distance by hand
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
@@ -746,7 +826,7 @@ __device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int
 #pragma unroll
                 for (int I = 0; I < NB; ++I) {
                     const double uv = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
-                    p[I] = exp2s_fast(((a[I] - lde) - uv) * LOG2E_32, tbl);
+                    p[I] = exp2s_fast(((a[I] - lde) - uv) * LOG2E_S);
                 }
                 gram_half_group<NB, HALF, NMINE>(p, acc);
             }
@@ -845,17 +925,26 @@ __device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int
         const bool active = t < ntiles;
         double p_own[2][NB];
         if (active) {
+            double ldc[2];
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {  // all LDS operands of this wave's two groups requested up front
+                ldc[gi] = *reinterpret_cast<const double*>(lbuf + (4 * (G0 + gi) + ns) * 8);
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+                    p_own[gi][I] = *reinterpret_cast<const double*>(ubuf + I * (16 * TS * 8) + rd_base + pos[gi]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi) {
                 const int g = G0 + gi;
                 const bool valid = (t * TS + 4 * g + ns) < N;
-                const double ldc = valid ? *reinterpret_cast<const double*>(lbuf + (4 * g + ns) * 8) : INFINITY;
+                const double lde = valid ? ldc[gi] : INFINITY;
 #pragma unroll
-                for (int I = 0; I < NB; ++I) {
-                    const double uv = *reinterpret_cast<const double*>(ubuf + I * (16 * TS * 8) + rd_base + pos[gi]);
-                    p_own[gi][I] = exp2s_fast(((a[I] - ldc) - uv) * LOG2E_32, tbl);
+                for (int I = 0; I < NB; ++I) p_own[gi][I] = ((a[I] - lde) - p_own[gi][I]) * LOG2E_S;
+                exp2s_batch<NB>(p_own[gi]);
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
                     *reinterpret_cast<double*>(pbuf + ((g * NB + I) * 64 + lane) * 8) = p_own[gi][I];
-                }
             }
         }
         __syncthreads();  // barrier 2: operands published, u tile dead
@@ -1224,7 +1313,7 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
     if (g.variant == 0) {  // paired: STREAMS tile streams x 2 waves
         const int streams = nb <= 8 ? 4 : 2;
         g.waves = 2 * streams;
-        g.lds_bytes = (size_t)streams * 2 * tile + 256;
+        g.lds_bytes = (size_t)streams * 2 * tile + EXP_TABLE_BYTES;
         int64_t want = (ntiles + streams - 1) / streams;
         cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
         if (grid_override > 0) cap = grid_override;
@@ -1233,7 +1322,7 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
         g.nwaves = g.blocks * streams * 2;  // one partial record per wave
     } else {
         g.waves = nb <= 8 ? 4 : 2;
-        g.lds_bytes = (size_t)g.waves * 2 * tile + 256;
+        g.lds_bytes = (size_t)g.waves * 2 * tile + EXP_TABLE_BYTES;
         int64_t want = (ntiles + g.waves - 1) / g.waves;
         cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
         if (grid_override > 0) cap = grid_override;
@@ -1250,11 +1339,13 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
     g.waves = 4;
     g.variant = -1;
     const size_t tile = (size_t)tile_rows * TS * 8 + TS * 8;  // u tile + its 16 logden values
-    g.lds_bytes = (size_t)4 * 2 * tile + 256;
-    if (diag && tile_rows == 128) {
+    g.lds_bytes = (size_t)4 * 2 * tile + EXP_TABLE_BYTES;
+    if (diag && tile_rows == 128 && nb8_variant == 2) {
+        g.variant = 2;
+    } else if (diag && tile_rows == 128) {
         g.variant = nb8_variant == 1 ? 1 : 0;
         g.waves = 8;
-        if (g.variant == 0) g.lds_bytes = (size_t)4 * (tile + (size_t)GROUPS * 8 * 64 * 8) + 256;  // single u buffer + operand buffer
+        if (g.variant == 0) g.lds_bytes = (size_t)4 * (tile + (size_t)GROUPS * 8 * 64 * 8) + EXP_TABLE_BYTES;  // single u buffer + operand buffer
     }
     int64_t want = (ntiles + 3) / 4;
     int64_t cap = num_cu;  // the accumulators own the register file: one workgroup per CU
@@ -1380,6 +1471,9 @@ static hipError_t launch_gram_xchg_t(hipStream_t s, const LaunchGeom& g, const d
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
                             int64_t N, const double* anum, const double* logden, int64_t row0, double* gp,
                             double* pp) {
+    if (nb == 8 && g.variant == 2)  // one wave per SIMD owns all 36 blocks (accumulator classes pinned by hand)
+        return dma ? launch_gram_t<8, 8, true, true>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp)
+                   : launch_gram_t<8, 8, true, false>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp);
     if (nb == 8) {  // paired-wave variants: g.nwaves counts tile streams (4 per workgroup)
         if (g.variant == 0)
             return dma ? launch_gram_xchg_t<8, true>(s, g, u, ld, N, anum, logden, row0, gp, pp)
