@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="columns for the CPU baseline (0 = skip)")
     ap.add_argument("--staging", type=int, default=0)
-    ap.add_argument("--lse-variant", type=int, default=1)
+    ap.add_argument("--lse-variant", type=int, default=2)
     ap.add_argument("--gram-variant", type=int, default=2)
     args = ap.parse_args()
 

@@ -99,7 +99,7 @@ struct mbar_ctx {
     double sci_graph_tol = 0.0;
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1;
-    int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
+    int64_t opt_lse_variant = 2, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
     // comm
     ncclComm_t comm = nullptr;
     mbar_allreduce_fn host_reduce = nullptr;
@@ -276,6 +276,10 @@ int agree_with_rank0(mbar_ctx* c, double* v, int64_t count) {
 
 // ---- evaluation building blocks -----------------------------------------------------------------
 // The fused kernels address a tile row as (wave-uniform base) + (32-bit per-lane byte offset <= 7 ld 8 + 120).
+// variant 2 (single tile buffer, two waves per SIMD) exists for LDS-DMA staging only
+int lse_variant_for(const mbar_ctx* c) {
+    return (c->opt_lse_variant == 2 && c->opt_staging != 0) ? 1 : (int)c->opt_lse_variant;
+}
 bool use_fast(const mbar_ctx* c) {
     return c->K <= MAX_FAST_K && !c->opt_force_generic && (uint64_t)c->ld * 56u + 128u < (1ull << 32);
 }
@@ -293,7 +297,7 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
     if (use_fast(c)) {
         const int nb = (int)(rows / 16);
         const int64_t ntiles = (c->N + TS - 1) / TS;
-        LaunchGeom g = lse_geometry(nb, nf, c->num_cu, ntiles, c->opt_grid, (int)c->opt_lse_variant);
+        LaunchGeom g = lse_geometry(nb, nf, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
         const size_t rec = (size_t)nf * rows;
         int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rec + nf));
         if (rc) return rc;
@@ -1274,7 +1278,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     const bool fast = use_fast(c);
     const int nbk = (int)(rows / 16);
     const int64_t ntiles = (c->N + TS - 1) / TS;
-    LaunchGeom g = fast ? lse_geometry(nbk, 1, c->num_cu, ntiles, c->opt_grid, (int)c->opt_lse_variant) : LaunchGeom();
+    LaunchGeom g = fast ? lse_geometry(nbk, 1, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c)) : LaunchGeom();
     if (fast) {
         rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rows + 1));
         if (rc) return rc;

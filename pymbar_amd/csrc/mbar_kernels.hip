@@ -70,20 +70,25 @@ __device__ __forceinline__ double wave_max(double x) {
 //   ldexp; NaN arguments are laundered to 0 by the clamp, which is why NaN / -inf entries of u_kn and non-finite f_k
 //   are detected at the boundary instead (mbar_capi.cpp).
 #include "exp2_table.inc"
+#include "log_table.inc"
 constexpr double LOG2E = 0x1.71547652b82fep+0, LN2 = 0x1.62e42fefa39efp-1;
 constexpr double EXP2_S = (double)(1 << EXP2_BITS);
 constexpr double LOG2E_S = EXP2_S * LOG2E, LN2_OVER_S = LN2 / EXP2_S;
 constexpr double EXP2_CLAMP = -1100.0 * EXP2_S;
-constexpr int EXP_TABLE_BYTES = (1 << EXP2_BITS) * 8;
+constexpr int EXP2_TABLE_BYTES = (1 << EXP2_BITS) * 8;
+constexpr int LOG_TABLE_BYTES = 256 * 8;
+constexpr int EXP_TABLE_BYTES = EXP2_TABLE_BYTES + LOG_TABLE_BYTES;  // LDS reserved for both look-up tables
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 // Every thread block copies the table to LDS offset 0 (its dynamic LDS starts there: the kernels have no static
 // __shared__), so a look-up address is just the masked integer -- no base add.  Callers barrier afterwards.
 __device__ __forceinline__ void exp_table_init(char* smem) {
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
     for (int i = threadIdx.x; i < (1 << EXP2_BITS); i += blockDim.x) reinterpret_cast<double*>(smem)[i] = EXP2_TABLE[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x)
+        reinterpret_cast<double*>(smem + EXP2_TABLE_BYTES)[i] = LOG_TABLE[i];
 }
 __device__ __forceinline__ double exp2_table_at(int si) {
-    return *(lds_cdouble*)(uint32_t)((si << 3) & (EXP_TABLE_BYTES - 8));
+    return *(lds_cdouble*)(uint32_t)((si << 3) & (EXP2_TABLE_BYTES - 8));
 }
 __device__ __forceinline__ double exp2_poly(double z) {
     double p = EXP2_POLY[EXP2_DEG];
@@ -98,6 +103,26 @@ __device__ __forceinline__ double exp2s_fast(double ts) {  // 2^(ts / S)
     const int si = (int)s;
     const double T = exp2_table_at(si);
     return ldexp(T * exp2_poly(z), si >> EXP2_BITS);
+}
+// log s for positive finite s (the per-sample sums of the evaluation sweep), 12 fp64 + 2 integer instructions
+// (the library log is ~50 and keeps a dozen constants in registers):  s = 2^e m, m in [1/2, 1); the top 7 mantissa
+// bits pick c_j with |m / c_j - 1| <= 2^-8 from the 2 KB LDS table behind the exp table (tools/gen_log_table.py);
+// log s = e ln2 + log c_j + log1p(r), r = m / c_j - 1, log1p by its degree-6 Taylor polynomial (error 2e-18).
+// Absolute error ~2e-16 (it is added to a shift of order one or more).  s = 0 / negative are not supported.
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double log_pos(double s) {
+    const double m = __builtin_amdgcn_frexp_mant(s);
+    const double ed = (double)__builtin_amdgcn_frexp_exp(s);
+    const uint32_t off = (uint32_t)(__double2hiint(m) >> 9) & 0x7f0u;
+    const v2d tc = *(__attribute__((address_space(3))) const v2d*)(uint32_t)(EXP2_TABLE_BYTES + off);
+    const double r = fma(m, tc.x, -1.0);
+    double q = -1.0 / 6.0;
+    q = fma(q, r, 0.2);
+    q = fma(q, r, -0.25);
+    q = fma(q, r, 1.0 / 3.0);
+    q = fma(q, r, -0.5);
+    q = fma(q, r, 1.0);
+    return fma(ed, LN2, tc.y) + q * r;
 }
 // The same exp for N independent arguments, written as three stages separated by scheduling barriers: with one
 // or two waves per SIMD nothing else hides the LDS latency of the table look-up, and hipcc's own schedule leaves
@@ -204,17 +229,43 @@ __device__ __forceinline__ void row16_sum2(double& a, double& b) {
 // A second candidate f' costs no second exp: exp(a'_k - u_kn - m) = e_kn * c_k with the per-state constant
 // c_k = exp(a'_k - a_k), so  e' = e c,  s' = sum_k e',  acc[1] += e' / s'  (3 fp64 ops per element instead of ~20).
 // logden_f = m2 ln2/32 + log s_f for both candidates (same shift m2).
-template <int NB, int NF>
-__device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl, int rd0, int rd1,
-                                               const double (&a)[NB], const double (&c)[NB], double (&acc)[NF][NB],
-                                               double w0, double w1, double& m2_0, double& m2_1,
-                                               double (&s0)[NF], double (&s1)[NF]) {
-    double x0[NB], x1[NB];
+// logden_n = shift + log(sum) for every candidate with ONE log per tile: all 16 lanes of a DPP row hold the sums of
+// all candidates of their sample, so lanes ks in [4f, 4f+4) evaluate candidate f ((ks & 3) = the group whose
+// sample this lane kept).  objl accumulates this lane's objective terms; its candidate is (ks >> 2).
+template <int NF>
+__device__ __forceinline__ void logden_out(double mm, const double (&ss)[NF], int ks, bool sample_ok, int64_t n,
+                                           double wn, double* __restrict__ logden0, double* __restrict__ logden1,
+                                           const double* __restrict__ dn, double& objl) {
+    const bool second = NF == 2 && (ks & 4);
+    const double s_first = ss[0], s_second = ss[NF - 1];  // (scalars: a select on ss[] itself becomes a scratch array)
+    const double ldv = fma(mm, LN2_OVER_S, log_pos(second ? s_second : s_first));
+    if (sample_ok && ks < 4 * NF) {
+        double* out = second ? logden1 : logden0;
+        if (out) out[n] = ldv;
+        objl = fma(wn, dn ? (ldv - dn[n]) : ldv, objl);
+    }
+}
+template <int NF>
+__device__ __forceinline__ void objective_out(double objl, int ks, int lane, double* __restrict__ obj_part, int64_t rec) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const double o = wave_sum((ks >> 2) == f ? objl : 0.0);
+        if (lane == 0) obj_part[rec * NF + f] = o;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void lse_load2(const char* cbuf, int rd0, int rd1, const double (&a)[NB],
+                                          double (&x0)[NB], double (&x1)[NB]) {
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
         x0[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
         x1[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd1);
     }
+}
+template <int NB, int NF>
+__device__ __forceinline__ void lse_math2(double (&x0)[NB], double (&x1)[NB], const double (&c)[NB],
+                                          double (&acc)[NF][NB], double w0, double w1, double& m2_0, double& m2_1,
+                                          double (&s0)[NF], double (&s1)[NF]) {
     double m0 = tree_max<NB>(x0), m1 = tree_max<NB>(x1);
     row16_max2(m0, m1);
     m2_0 = m0 * LOG2E_S;
@@ -238,6 +289,15 @@ __device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl
 #pragma unroll
         for (int I = 0; I < NB; ++I) acc[f][I] = fma(x1[I], r1, fma(x0[I], r0, acc[f][I]));
     }
+}
+template <int NB, int NF>
+__device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl, int rd0, int rd1,
+                                               const double (&a)[NB], const double (&c)[NB], double (&acc)[NF][NB],
+                                               double w0, double w1, double& m2_0, double& m2_1,
+                                               double (&s0)[NF], double (&s1)[NF]) {
+    double x0[NB], x1[NB];
+    lse_load2<NB>(cbuf, rd0, rd1, a, x0, x1);
+    lse_math2<NB, NF>(x0, x1, c, acc, w0, w1, m2_0, m2_1, s0, s1);
 }
 
 // Single-group version for wide panels (NB > 8), where two groups in flight would spill registers.
@@ -315,7 +375,15 @@ __device__ __forceinline__ StageOffsets make_stage_offsets(int64_t ld, int lane)
 template <bool DMA>
 __device__ __forceinline__ void stage_piece(const double* __restrict__ ubase /*wave-uniform*/, uint32_t voff,
                                             char* dst /*wave-uniform*/, int lane) {
-    const char* src = reinterpret_cast<const char*>(ubase) + voff;
+    // Launder the base through an SGPR constraint: loop strength reduction otherwise turns every DMA address of
+    // the tile loop into its own 64-bit per-lane induction variable (2 VGPRs + a 64-bit VALU add per instruction
+    // per tile) and the instruction loses its scalar-base form.
+    // The 32-bit lane offset is laundered too, so that its zero-extension stays in the block of the DMA (instruction
+    // selection is per basic block and only matches base + zext(offset) when it sees both).
+    uint64_t ub = reinterpret_cast<uint64_t>(ubase);
+    asm("" : "+s"(ub));
+    asm("" : "+v"(voff));
+    const char* src = reinterpret_cast<const char*>(ub) + voff;
     if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -394,7 +462,7 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const RowIdentity rows{0};
     const StageOffsets so = make_stage_offsets(ld, lane);
 
-    double a[NB], c[NB], acc[NF][NB], obj[NF];
+    double a[NB], c[NB], acc[NF][NB], objl = 0.0;
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
         a[I] = aden[16 * I + ks];
@@ -407,7 +475,6 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        obj[f] = 0.0;
 #pragma unroll
         for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
     }
@@ -451,17 +518,8 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         // lanes with (ks & 3) == g hold (shift, sums) of sample 4 g + ns: one log per candidate per tile
         {
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
-            const bool writer = (ks < 4) && (n < N);
             const double wn = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * (ks & 3) + ns) * 8);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const double ldv = fma(mm, LN2_OVER_S, log(ss[f]));
-                if (writer) {
-                    double* out = f == 0 ? logden0 : logden1;
-                    if (out) out[n] = ldv;
-                    obj[f] = fma(wn, dn ? (ldv - dn[n]) : ldv, obj[f]);
-                }
-            }
+            logden_out<NF>(mm, ss, ks, n < N, n, wn, logden0, logden1, dn, objl);
         }
         cur ^= 1;
     }
@@ -475,9 +533,111 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             v += __shfl_xor(v, 32);
             if (lane < 16) psum_part[(gw * NF + f) * ROWS + 16 * I + lane] = v;
         }
-        const double o = wave_sum(obj[f]);
-        if (lane == 0) obj_part[gw * NF + f] = o;
     }
+    objective_out<NF>(objl, ks, lane, obj_part, gw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass, two waves per SIMD (default for 5 <= NB <= 8).  With a double-buffered tile per wave LDS
+// limits k_lse to ONE wave per SIMD, and a lone wave issues an fp64 VALU op only every ~7 cycles and a 32-bit
+// one every ~5.8 (5.6 / 3.0 with a second wave to alternate with; profiles/r1_fp64_valu_issue_cost_microbench.txt),
+// and nothing covers its s_waitcnt stalls.  Here every wave owns a SINGLE tile buffer: all LDS operands of the tile
+// are in registers by the middle of the tile, the DMA of the wave's next tile is issued right there into the same
+// buffer, and it lands while this wave finishes the tile and its SIMD partner works.
+// ---------------------------------------------------------------------------------------------
+template <int NB, int NF>
+__global__ void __launch_bounds__(512, 2)
+k_lse_sb(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+         const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+         double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
+         double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    exp_table_init(smem);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * TILE_BYTES;
+    const char* wslot = buf + U_BYTES;
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const RowIdentity rows{0};
+    const StageOffsets so = make_stage_offsets(ld, lane);
+
+    double a[NB], c[NB], acc[NF][NB], objl = 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        a[I] = aden[16 * I + ks];
+        c[I] = NF == 2 ? aden[ROWS + 16 * I + ks] : 1.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        settle(a[I]);
+        if (NF == 2) settle(c[I]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
+    }
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    int64_t t = gw;
+    if (t < ntiles) {
+        stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
+        stage_vec16<true>(cw, t * TS, buf + U_BYTES, lane);
+    }
+    for (; t < ntiles; t += W) {
+        wait_vm<0>();
+        // the weight slot is refilled together with the tile: take what this lane needs from it first
+        double w[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) w[g] = *reinterpret_cast<const double*>(wslot + (4 * g + ns) * 8);
+        const double wn = *reinterpret_cast<const double*>(wslot + (4 * (ks & 3) + ns) * 8);
+        double x0[NB], x1[NB], m2a, m2b, sa[NF], sb[NF], mm = 0.0, ss[NF];
+        const int gq = ks & 3;  // this lane keeps (shift, sums) of sample 4 gq + ns for the log below
+        lse_load2<NB>(buf, pos[0], pos[1], a, x0, x1);
+        lse_math2<NB, NF>(x0, x1, c, acc, w[0], w[1], m2a, m2b, sa, sb);
+        mm = gq == 0 ? m2a : m2b;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ss[f] = gq == 0 ? sa[f] : sb[f];
+        lse_load2<NB>(buf, pos[2], pos[3], a, x0, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS operand of this tile is in registers
+        if (t + W < ntiles) {
+            stage_tile<ROWS, true, 0, 1>(u, ld, (t + W) * TS, buf, lane, so, rows);
+            stage_vec16<true>(cw, (t + W) * TS, buf + U_BYTES, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lse_math2<NB, NF>(x0, x1, c, acc, w[2], w[3], m2a, m2b, sa, sb);
+        if (gq >= 2) {
+            mm = gq == 2 ? m2a : m2b;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) ss[f] = gq == 2 ? sa[f] : sb[f];
+        }
+        {
+            const int64_t n = t * TS + 4 * gq + ns;
+            logden_out<NF>(mm, ss, ks, n < N, n, wn, logden0, logden1, dn, objl);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(gw * NF + f) * ROWS + 16 * I + lane] = v;
+        }
+    }
+    objective_out<NF>(objl, ks, lane, obj_part, gw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -506,7 +666,7 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
     const RowIdentity rows{0};
     const StageOffsets so = make_stage_offsets(ld, lane);
 
-    double a[NB], c[NB], acc[NF][NB], obj[NF];
+    double a[NB], c[NB], acc[NF][NB], objl = 0.0;
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
         a[I] = aden[16 * I + ks];
@@ -519,7 +679,6 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        obj[f] = 0.0;
 #pragma unroll
         for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
     }
@@ -548,17 +707,9 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
             for (int f = 0; f < NF; ++f) ss[f] = 1.0;
             lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, tbl, rd_base, pos, G0, a, c, acc, ks, ns, mm, ss);
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
-            const bool writer = (ks >= G0) && (ks < G0 + 2) && (n < N);
+            const bool mine = ((ks & 3) >= G0) && ((ks & 3) < G0 + 2) && (n < N);
             const double wn = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * (ks & 3) + ns) * 8);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const double ldv = fma(mm, LN2_OVER_S, log(ss[f]));
-                if (writer) {
-                    double* out = f == 0 ? logden0 : logden1;
-                    if (out) out[n] = ldv;
-                    obj[f] = fma(wn, dn ? (ldv - dn[n]) : ldv, obj[f]);
-                }
-            }
+            logden_out<NF>(mm, ss, ks, mine, n, wn, logden0, logden1, dn, objl);
         }
         cur ^= 1;
     }
@@ -572,9 +723,8 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
             v += __shfl_xor(v, 32);
             if (lane < 16) psum_part[(rec * NF + f) * ROWS + 16 * I + lane] = v;
         }
-        const double o = wave_sum(obj[f]);
-        if (lane == 0) obj_part[rec * NF + f] = o;
     }
+    objective_out<NF>(objl, ks, lane, obj_part, rec);
 }
 
 template <int NB, int NF, bool DMA>
@@ -1309,8 +1459,18 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
     LaunchGeom g;
     const size_t tile = (size_t)nb * 16 * TS * 8 + TS * 8;  // u tile + its 16 sample weights
     g.variant = (nb >= 6 && variant == 0 && !(nb > 8 && nf == 2)) ? 0 : 1;  // (wide two-candidate pairs would spill)
+    if (variant == 2 && nb >= 5 && nb <= 8) g.variant = 2;
     int64_t cap;
-    if (g.variant == 0) {  // paired: STREAMS tile streams x 2 waves
+    if (g.variant == 2) {  // single tile buffer per wave, 8 waves per workgroup = 2 per SIMD
+        g.waves = 8;
+        g.lds_bytes = (size_t)g.waves * tile + EXP_TABLE_BYTES;
+        int64_t want = (ntiles + g.waves - 1) / g.waves;
+        cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+        if (grid_override > 0) cap = grid_override;
+        if (want < 1) want = 1;
+        g.blocks = (int)(want < cap ? want : cap);
+        g.nwaves = g.blocks * g.waves;
+    } else if (g.variant == 0) {  // paired: STREAMS tile streams x 2 waves
         const int streams = nb <= 8 ? 4 : 2;
         g.waves = 2 * streams;
         g.lds_bytes = (size_t)streams * 2 * tile + EXP_TABLE_BYTES;
@@ -1389,10 +1549,33 @@ static hipError_t launch_lse_pair_t(hipStream_t s, const LaunchGeom& g, const do
     return hipGetLastError();
 }
 
+template <int NB, int NF>
+static hipError_t launch_lse_sb_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                  const double* aden, const double* cw, double* l0, double* l1, const double* dn,
+                                  double* psum_part, double* obj_part) {
+    auto kern = k_lse_sb<NB, NF>;
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TS - 1) / TS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
+                       l1, dn, psum_part, obj_part);
+    return hipGetLastError();
+}
+
 template <int NB>
 static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeom& g, const double* u,
                                 int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
                                 const double* dn, double* pp, double* op) {
+    if constexpr (NB >= 5 && NB <= 8) {
+        if (g.variant == 2) {
+            if (!dma) return hipErrorInvalidValue;  // (the caller selects variant 2 only with LDS-DMA staging)
+            return nf == 1 ? launch_lse_sb_t<NB, 1>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
+                           : launch_lse_sb_t<NB, 2>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
+        }
+    }
     if constexpr (NB >= 6) {
         if (g.variant == 0) {
             if (nf == 1)
