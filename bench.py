@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="columns for the CPU baseline (0 = skip)")
     ap.add_argument("--staging", type=int, default=0)
-    ap.add_argument("--lse-variant", type=int, default=2)
+    ap.add_argument("--lse-variant", type=int, default=1)
     ap.add_argument("--gram-variant", type=int, default=2)
     args = ap.parse_args()
 
@@ -217,7 +217,7 @@ def main():
             "roofline": {
                 "kernel": ({0: "k_gram_xchg<8>", 1: "k_gram_pair<8>"}.get(args.gram_variant, "k_gram<8,8> one wave per SIMD") + " (fp64 MFMA W^T W)") if K == 128 else "k_gram",
                 "bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("k_gram", K, n_loc),
+                "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("k_gram<", K, n_loc),
                 "avg_launch_ms": gram_avg, "launches": gram_n, "algorithmic_flop_per_launch": flops,
                 "measured_mfma_f64_peak_tflops": mfma_peak,
             },

@@ -99,7 +99,7 @@ struct mbar_ctx {
     double sci_graph_tol = 0.0;
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1;
-    int64_t opt_lse_variant = 2, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
+    int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
     // comm
     ncclComm_t comm = nullptr;
     mbar_allreduce_fn host_reduce = nullptr;
@@ -276,9 +276,9 @@ int agree_with_rank0(mbar_ctx* c, double* v, int64_t count) {
 
 // ---- evaluation building blocks -----------------------------------------------------------------
 // The fused kernels address a tile row as (wave-uniform base) + (32-bit per-lane byte offset <= 7 ld 8 + 120).
-// variant 2 (single tile buffer, two waves per SIMD) exists for LDS-DMA staging only
+// variants 2 / 3 (early refill of the tile buffer) exist for LDS-DMA staging only
 int lse_variant_for(const mbar_ctx* c) {
-    return (c->opt_lse_variant == 2 && c->opt_staging != 0) ? 1 : (int)c->opt_lse_variant;
+    return (c->opt_lse_variant >= 2 && c->opt_staging != 0) ? 1 : (int)c->opt_lse_variant;
 }
 bool use_fast(const mbar_ctx* c) {
     return c->K <= MAX_FAST_K && !c->opt_force_generic && (uint64_t)c->ld * 56u + 128u < (1ull << 32);

@@ -262,7 +262,7 @@ __device__ __forceinline__ void lse_load2(const char* cbuf, int rd0, int rd1, co
         x1[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd1);
     }
 }
-template <int NB, int NF>
+template <int NB, int NF, bool SPLIT = false>
 __device__ __forceinline__ void lse_math2(double (&x0)[NB], double (&x1)[NB], const double (&c)[NB],
                                           double (&acc)[NF][NB], double w0, double w1, double& m2_0, double& m2_1,
                                           double (&s0)[NF], double (&s1)[NF]) {
@@ -275,7 +275,12 @@ __device__ __forceinline__ void lse_math2(double (&x0)[NB], double (&x1)[NB], co
         x0[I] = fma(x0[I], LOG2E_S, -m2_0);
         x1[I] = fma(x1[I], LOG2E_S, -m2_1);
     }
-    exp2s_batch2<NB>(x0, x1);
+    if constexpr (SPLIT) {  // (register budget of two waves per SIMD: half the look-ups in flight at a time)
+        exp2s_batch<NB>(x0);
+        exp2s_batch<NB>(x1);
+    } else {
+        exp2s_batch2<NB>(x0, x1);
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         if (f == 1) {
@@ -538,16 +543,17 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Evaluation pass, two waves per SIMD (default for 5 <= NB <= 8).  With a double-buffered tile per wave LDS
-// limits k_lse to ONE wave per SIMD, and a lone wave issues an fp64 VALU op only every ~7 cycles and a 32-bit
-// one every ~5.8 (5.6 / 3.0 with a second wave to alternate with; profiles/r1_fp64_valu_issue_cost_microbench.txt),
-// and nothing covers its s_waitcnt stalls.  Here every wave owns a SINGLE tile buffer: all LDS operands of the tile
-// are in registers by the middle of the tile, the DMA of the wave's next tile is issued right there into the same
-// buffer, and it lands while this wave finishes the tile and its SIMD partner works.
+// Evaluation pass with early refill (5 <= NB <= 8, LDS-DMA staging).  All LDS operands of a tile are in registers
+// by the middle of the tile; the buffer is handed back to the DMA engine right there instead of at the next loop
+// top:
+//   NBUF = 2 (default): one wave per SIMD, two tile buffers; the refill is the tile after next, so every DMA has
+//             ~1.5 tile periods to land instead of 1 (the k_lse loop spends ~20% of its time in s_waitcnt vmcnt).
+//   NBUF = 1: two waves per SIMD (8 per workgroup), one buffer each; the refill is the wave's next tile and lands
+//             while this wave finishes the tile and its SIMD partner works.
 // ---------------------------------------------------------------------------------------------
-template <int NB, int NF>
-__global__ void __launch_bounds__(512, 2)
-k_lse_sb(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+template <int NB, int NF, int NBUF>
+__global__ void __launch_bounds__(NBUF == 1 ? 512 : 256, NBUF == 1 ? 2 : 1)
+k_lse_early(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
          const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
          double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
          double* __restrict__ obj_part) {
@@ -555,14 +561,14 @@ k_lse_sb(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     constexpr int ROWS = NB * 16;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
+    constexpr int NDMA = ROWS / 8 + 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
     const int ks = lane & 15, ns = lane >> 4;
     exp_table_init(smem);
     __syncthreads();
-    char* buf = smem + EXP_TABLE_BYTES + wave * TILE_BYTES;
-    const char* wslot = buf + U_BYTES;
+    char* buf0 = smem + EXP_TABLE_BYTES + wave * (NBUF * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
     const RowIdentity rows{0};
@@ -590,12 +596,20 @@ k_lse_sb(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
 
     int64_t t = gw;
-    if (t < ntiles) {
-        stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
-        stage_vec16<true>(cw, t * TS, buf + U_BYTES, lane);
-    }
+    int cur = 0;
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b)
+        if (t + b * W < ntiles) {
+            stage_tile<ROWS, true, 0, 1>(u, ld, (t + b * W) * TS, buf0 + b * TILE_BYTES, lane, so, rows);
+            stage_vec16<true>(cw, (t + b * W) * TS, buf0 + b * TILE_BYTES + U_BYTES, lane);
+        }
     for (; t < ntiles; t += W) {
-        wait_vm<0>();
+        char* buf = buf0 + cur * TILE_BYTES;
+        const char* wslot = buf + U_BYTES;
+        if (NBUF == 2 && t + W < ntiles)
+            wait_vm<NDMA>();  // the tile after this one may still be in flight
+        else
+            wait_vm<0>();
         // the weight slot is refilled together with the tile: take what this lane needs from it first
         double w[GROUPS];
 #pragma unroll
@@ -603,20 +617,36 @@ k_lse_sb(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         const double wn = *reinterpret_cast<const double*>(wslot + (4 * (ks & 3) + ns) * 8);
         double x0[NB], x1[NB], m2a, m2b, sa[NF], sb[NF], mm = 0.0, ss[NF];
         const int gq = ks & 3;  // this lane keeps (shift, sums) of sample 4 gq + ns for the log below
-        lse_load2<NB>(buf, pos[0], pos[1], a, x0, x1);
-        lse_math2<NB, NF>(x0, x1, c, acc, w[0], w[1], m2a, m2b, sa, sb);
-        mm = gq == 0 ? m2a : m2b;
+        auto refill = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS operand of this tile is in registers
+            if (t + NBUF * W < ntiles) {
+                stage_tile<ROWS, true, 0, 1>(u, ld, (t + NBUF * W) * TS, buf, lane, so, rows);
+                stage_vec16<true>(cw, (t + NBUF * W) * TS, buf + U_BYTES, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (NBUF == 1) {
+            // the whole tile goes to registers first: the refill then has a full tile period to land
+            double x2[NB], x3[NB];
+            lse_load2<NB>(buf, pos[0], pos[1], a, x0, x1);
+            lse_load2<NB>(buf, pos[2], pos[3], a, x2, x3);
+            refill();
+            lse_math2<NB, NF, true>(x0, x1, c, acc, w[0], w[1], m2a, m2b, sa, sb);
+            mm = gq == 0 ? m2a : m2b;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) ss[f] = gq == 0 ? sa[f] : sb[f];
-        lse_load2<NB>(buf, pos[2], pos[3], a, x0, x1);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS operand of this tile is in registers
-        if (t + W < ntiles) {
-            stage_tile<ROWS, true, 0, 1>(u, ld, (t + W) * TS, buf, lane, so, rows);
-            stage_vec16<true>(cw, (t + W) * TS, buf + U_BYTES, lane);
+            for (int f = 0; f < NF; ++f) ss[f] = gq == 0 ? sa[f] : sb[f];
+            lse_math2<NB, NF, true>(x2, x3, c, acc, w[2], w[3], m2a, m2b, sa, sb);
+        } else {
+            lse_load2<NB>(buf, pos[0], pos[1], a, x0, x1);
+            lse_math2<NB, NF>(x0, x1, c, acc, w[0], w[1], m2a, m2b, sa, sb);
+            mm = gq == 0 ? m2a : m2b;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) ss[f] = gq == 0 ? sa[f] : sb[f];
+            lse_load2<NB>(buf, pos[2], pos[3], a, x0, x1);
+            refill();
+            lse_math2<NB, NF>(x0, x1, c, acc, w[2], w[3], m2a, m2b, sa, sb);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        lse_math2<NB, NF>(x0, x1, c, acc, w[2], w[3], m2a, m2b, sa, sb);
         if (gq >= 2) {
             mm = gq == 2 ? m2a : m2b;
 #pragma unroll
@@ -626,6 +656,7 @@ k_lse_sb(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             const int64_t n = t * TS + 4 * gq + ns;
             logden_out<NF>(mm, ss, ks, n < N, n, wn, logden0, logden1, dn, objl);
         }
+        cur ^= NBUF - 1;
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -1459,11 +1490,11 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
     LaunchGeom g;
     const size_t tile = (size_t)nb * 16 * TS * 8 + TS * 8;  // u tile + its 16 sample weights
     g.variant = (nb >= 6 && variant == 0 && !(nb > 8 && nf == 2)) ? 0 : 1;  // (wide two-candidate pairs would spill)
-    if (variant == 2 && nb >= 5 && nb <= 8) g.variant = 2;
+    if (variant >= 2 && nb >= 5 && nb <= 8) g.variant = variant == 2 ? 2 : 3;
     int64_t cap;
-    if (g.variant == 2) {  // single tile buffer per wave, 8 waves per workgroup = 2 per SIMD
-        g.waves = 8;
-        g.lds_bytes = (size_t)g.waves * tile + EXP_TABLE_BYTES;
+    if (g.variant >= 2) {  // early refill: 8 waves x 1 tile buffer (2) or 4 waves x 2 buffers (3)
+        g.waves = g.variant == 2 ? 8 : 4;
+        g.lds_bytes = (size_t)8 * tile + EXP_TABLE_BYTES;
         int64_t want = (ntiles + g.waves - 1) / g.waves;
         cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
         if (grid_override > 0) cap = grid_override;
@@ -1549,11 +1580,11 @@ static hipError_t launch_lse_pair_t(hipStream_t s, const LaunchGeom& g, const do
     return hipGetLastError();
 }
 
-template <int NB, int NF>
-static hipError_t launch_lse_sb_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+template <int NB, int NF, int NBUF>
+static hipError_t launch_lse_early_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                                   const double* aden, const double* cw, double* l0, double* l1, const double* dn,
                                   double* psum_part, double* obj_part) {
-    auto kern = k_lse_sb<NB, NF>;
+    auto kern = k_lse_early<NB, NF, NBUF>;
     if (g.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
@@ -1570,10 +1601,13 @@ static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeo
                                 int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
                                 const double* dn, double* pp, double* op) {
     if constexpr (NB >= 5 && NB <= 8) {
-        if (g.variant == 2) {
-            if (!dma) return hipErrorInvalidValue;  // (the caller selects variant 2 only with LDS-DMA staging)
-            return nf == 1 ? launch_lse_sb_t<NB, 1>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
-                           : launch_lse_sb_t<NB, 2>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
+        if (g.variant >= 2) {
+            if (!dma) return hipErrorInvalidValue;  // (the caller selects these variants only with LDS-DMA staging)
+            if (g.variant == 2)
+                return nf == 1 ? launch_lse_early_t<NB, 1, 1>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
+                               : launch_lse_early_t<NB, 2, 1>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
+            return nf == 1 ? launch_lse_early_t<NB, 1, 2>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
+                           : launch_lse_early_t<NB, 2, 2>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
         }
     }
     if constexpr (NB >= 6) {

@@ -74,11 +74,13 @@ def test_l1_parity_fast_path(DM, K, N, staging):
 
 
 @pytest.mark.parametrize("K,N", [(96, 1500), (100, 777), (112, 800), (128, 2048), (128, 100000), (192, 1200), (256, 600)])
-@pytest.mark.parametrize("lse_variant,gram_variant,staging", [(1, 0, 0), (1, 0, 1), (0, 1, 0), (0, 0, 0), (1, 1, 1)])
+@pytest.mark.parametrize("lse_variant,gram_variant,staging",
+                         [(1, 2, 0), (1, 2, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (2, 2, 0), (3, 1, 0), (3, 2, 1)])
 def test_l1_parity_kernel_variants(DM, K, N, lse_variant, gram_variant, staging):
-    """Wide panels (NB >= 6) have two implementations of each sweep: one tile stream per wave (default) and
-    paired waves sharing a stream; the full 128-state Gram panel has the operand-exchange (default) and the
-    duplicate-operand pairing.  All must agree with the oracle."""
+    """Wide panels have several implementations of each sweep.  Evaluation: one tile stream per wave (1, default),
+    paired waves sharing a stream (0), early refill with one (2) or two (3) tile buffers.  Full 128-state Gram panel:
+    one wave per SIMD with pinned accumulator classes (2, default), operand exchange (0), duplicate-operand pairing
+    (1).  All must agree with the oracle."""
     u_kn, N_k, f = random_problem(K, N, seed=3 * K + N)
     N_k = np.maximum(N_k, 1)  # every state sampled (N_k only acts as a weight vector here)
     with DM.from_host(u_kn) as dm:
