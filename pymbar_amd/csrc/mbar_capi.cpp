@@ -275,14 +275,16 @@ int agree_with_rank0(mbar_ctx* c, double* v, int64_t count) {
 }
 
 // ---- evaluation building blocks -----------------------------------------------------------------
-// The fused kernels address a tile row as (wave-uniform base) + (32-bit per-lane byte offset <= 7 ld 8 + 120).
 // variants 2 / 3 (early refill of the tile buffer) exist for LDS-DMA staging only
+// Row pitches from 7.6e7 samples up need 64-bit lane offsets in the tile DMA; only the default kernels are
+// instantiated for that, so the optional variants fall back to them.
+bool wide_pitch(const mbar_ctx* c) { return (uint64_t)c->ld * 56u + 128u >= (1ull << 32); }
 int lse_variant_for(const mbar_ctx* c) {
+    if (wide_pitch(c)) return 1;
     return (c->opt_lse_variant >= 2 && c->opt_staging != 0) ? 1 : (int)c->opt_lse_variant;
 }
-bool use_fast(const mbar_ctx* c) {
-    return c->K <= MAX_FAST_K && !c->opt_force_generic && (uint64_t)c->ld * 56u + 128u < (1ull << 32);
-}
+int gram_variant_for(const mbar_ctx* c) { return wide_pitch(c) ? 2 : (int)c->opt_gram_variant; }
+bool use_fast(const mbar_ctx* c) { return c->K <= MAX_FAST_K && !c->opt_force_generic; }
 
 // Host vector a[k] = f[k] + ln N_k (-inf where N_k = 0 or k >= K), written into out[rows].
 void build_aden(const mbar_ctx* c, const double* f, double* out, int64_t rows) {
@@ -383,9 +385,6 @@ GramPlan gram_plan(int64_t Kp) {
 // device: rows of p sum to one (sum_k p_nk = 1, resp. sum_k N_k W_nk = 1), so they are column sums of the
 // reduced Gram matrix (gram_operand_sums below).
 int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan) {
-    if ((uint64_t)c->ld * 56u + 128u >= (1ull << 32))
-        return fail(c, MBAR_ERR_ARG, "Gram sweep: N_local must be below 7.6e7 samples per rank (32-bit tile offsets); "
-                                     "shard the sample axis over more ranks");
     const int64_t ntiles = (c->N + TS - 1) / TS;
     const bool dma = c->opt_staging == 0;
     if (c->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent
@@ -394,7 +393,7 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
     }
     for (const auto& it : plan.items) {
         const int tile_rows = it.diag ? it.nb * 16 : 128;
-        LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid, (int)c->opt_gram_variant);
+        LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
         const size_t rec = (size_t)it.nblk * 256;
         int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
         if (rc) return rc;

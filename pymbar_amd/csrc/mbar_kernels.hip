@@ -19,6 +19,7 @@
 #include "mbar_internal.h"
 
 #include <math.h>
+#include <type_traits>
 
 namespace mbar {
 
@@ -364,18 +365,35 @@ __device__ __forceinline__ void lse_group_pair(const char* cbuf, const char* wsl
 // 8 (j & 1)), so it is two loop-invariant 32-bit byte offsets (StageOffsets) added to a wave-uniform base:
 // the DMA is issued as `global_load_lds_dwordx4 voff, s[base]` with no per-instruction VALU address math.
 // rowmap(tile_row) gives the global row (8-row groups never straddle a panel).
-struct StageOffsets {
-    uint32_t off[2];
+// WIDE: the row pitch is so large (N_local >= 7.6e7) that 7 ld 8 + 120 does not fit 32 bits; the lane offsets are then
+// 64-bit and every DMA pays one 64-bit VALU add (own kernel instantiations, selected by the launchers).
+template <bool WIDE>
+struct StageOffsetsT {
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type off_t;
+    off_t off[2];
 };
-__device__ __forceinline__ StageOffsets make_stage_offsets(int64_t ld, int lane) {
-    StageOffsets so;
+typedef StageOffsetsT<false> StageOffsets;
+template <bool WIDE = false>
+__device__ __forceinline__ StageOffsetsT<WIDE> make_stage_offsets(int64_t ld, int lane) {
+    StageOffsetsT<WIDE> so;
     const int r = lane >> 3, pos = 2 * (lane & 7);
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
         const int smp = (pos - ((r & 6) | (par << 3))) & 15;
-        so.off[par] = (uint32_t)(((int64_t)r * ld + smp) * 8);
+        so.off[par] = (typename StageOffsetsT<WIDE>::off_t)(((int64_t)r * ld + smp) * 8);
     }
     return so;
+}
+template <bool DMA>
+__device__ __forceinline__ void stage_piece(const double* __restrict__ ubase /*wave-uniform*/, uint64_t voff,
+                                            char* dst /*wave-uniform*/, int lane) {
+    const char* src = reinterpret_cast<const char*>(ubase) + voff;
+    if constexpr (DMA) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    } else {
+        *reinterpret_cast<double2*>(dst + lane * 16) = *reinterpret_cast<const double2*>(src);
+    }
 }
 template <bool DMA>
 __device__ __forceinline__ void stage_piece(const double* __restrict__ ubase /*wave-uniform*/, uint32_t voff,
@@ -396,9 +414,9 @@ __device__ __forceinline__ void stage_piece(const double* __restrict__ ubase /*w
         *reinterpret_cast<double2*>(dst + lane * 16) = *reinterpret_cast<const double2*>(src);
     }
 }
-template <int ROWS, bool DMA, int J0, int JSTEP, typename RowMap>
+template <int ROWS, bool DMA, int J0, int JSTEP, typename RowMap, typename SO>
 __device__ __forceinline__ void stage_tile(const double* __restrict__ u, int64_t ld, int64_t n0, char* dst, int lane,
-                                           const StageOffsets& so, RowMap rowmap) {
+                                           const SO& so, RowMap rowmap) {
     constexpr int NDMA = ROWS / 8;
 #pragma unroll
     for (int j = J0; j < NDMA; j += JSTEP)
@@ -443,7 +461,7 @@ struct RowTwoPanels {
 // One exp per matrix element in total: e = exp(x - max) is kept in registers, normalised by the reciprocal of
 // its sum, and re-used for the second candidate through the per-state ratio c_k.
 // ---------------------------------------------------------------------------------------------
-template <int NB, int NF, bool DMA>
+template <int NB, int NF, bool DMA, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
       const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
@@ -465,7 +483,7 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
     const RowIdentity rows{0};
-    const StageOffsets so = make_stage_offsets(ld, lane);
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
     double a[NB], c[NB], acc[NF][NB], objl = 0.0;
 #pragma unroll
@@ -786,7 +804,7 @@ k_lse_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // Output block b, register r, lane l  ->  element (row = (l >> 4) + 4 r, col = l & 15) of block b.
 // ---------------------------------------------------------------------------------------------
 constexpr int GRAM8_AGPR_BLOCKS = 31;
-template <int NBI, int NBJ, bool DIAG, bool DMA>
+template <int NBI, int NBJ, bool DIAG, bool DMA, bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
        const double* __restrict__ anum_i, const double* __restrict__ anum_j,
@@ -810,7 +828,7 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
     const RowTwoPanels rows{row_i0, row_j0, DIAG ? ROWS : NBI * 16};
-    const StageOffsets so = make_stage_offsets(ld, lane);
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
     double a[NBT];
 #pragma unroll
@@ -1548,11 +1566,29 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
     return g;
 }
 
+static bool stage_offsets_wide(int64_t ld) { return (uint64_t)ld * 56u + 128u >= (1ull << 32); }
+
+template <typename Kern>
+static hipError_t launch_kernel_lse(Kern kern, hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                    const double* aden, const double* cw, double* l0, double* l1, const double* dn,
+                                    double* psum_part, double* obj_part) {
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TS - 1) / TS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
+                       l1, dn, psum_part, obj_part);
+    return hipGetLastError();
+}
+
 template <int NB, int NF, bool DMA>
 static hipError_t launch_lse_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                                const double* aden, const double* cw, double* l0, double* l1, const double* dn,
                                double* psum_part, double* obj_part) {
-    auto kern = k_lse<NB, NF, DMA>;
+    if (stage_offsets_wide(ld)) return launch_kernel_lse(k_lse<NB, NF, DMA, true>, s, g, u, ld, N, aden, cw, l0, l1, dn, psum_part, obj_part);
+    auto kern = k_lse<NB, NF, DMA, false>;
     if (g.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
@@ -1643,16 +1679,18 @@ template <int NBI, int NBJ, bool DIAG, bool DMA>
 static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                                 const double* ai, const double* aj, const double* logden, int64_t ri,
                                 int64_t rj, double* gp, double* pp) {
-    auto kern = k_gram<NBI, NBJ, DIAG, DMA>;
-    if (g.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    const int64_t ntiles = (N + TS - 1) / TS;
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, ai, aj,
-                       logden, ri, rj, gp, pp);
-    return hipGetLastError();
+    auto launch = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, ai, aj,
+                           logden, ri, rj, gp, pp);
+        return hipGetLastError();
+    };
+    return stage_offsets_wide(ld) ? launch(k_gram<NBI, NBJ, DIAG, DMA, true>) : launch(k_gram<NBI, NBJ, DIAG, DMA, false>);
 }
 
 template <int NB, bool DMA>

@@ -448,6 +448,39 @@ def test_config3_full_size_properties(DM):
         np.testing.assert_allclose(sl[0], part["sumlogden"], rtol=1e-13)
 
 
+@pytest.mark.parametrize("K", [32, 128])
+def test_wide_row_pitch_matches_sum_of_shards(DM, K):
+    """From 7.6e7 samples per rank the tile DMA needs 64-bit lane offsets (separate kernel instantiations).  The
+    whole matrix must give the sums of its two column shards (each below the threshold, i.e. on the 32-bit kernels),
+    and the solver must run on it.  K = 128 at 7.8e7 samples is a 80 GB matrix: the largest case in the suite."""
+    from pymbar_amd.device import device_info
+
+    N = 78_000_000
+    if device_info()["total_mem_bytes"] < (8 * K * N * 3) // 2 + (8 << 30):
+        pytest.skip("not enough device memory for the wide-pitch case")
+    O_k, K_k, N_k = ts.config3_params(K=K, N=N)
+    f = ts.harmonic_free_energies(K_k) + 0.01 * np.cos(np.arange(K))
+    f[0] = 0
+    f2 = np.stack([f, f + 0.003 * np.sin(np.arange(K))])
+    with DM.harmonic(O_k, K_k, N_k, seed=5) as whole:
+        whole.set_Nk(N_k)
+        pw, sw, gw = whole.eval(f2, gram=True)
+        lnw = whole.lognum(f)
+        fs, res = ms.solve_mbar_once(whole, N_k, f.copy(), method="adaptive", tol=1e-10, options=dict(min_sc_iter=0, maxiter=3))
+        assert np.all(np.isfinite(fs))
+    parts = []
+    n_half = N // 2 + 16
+    for n0, nloc in ((0, n_half), (n_half, N - n_half)):
+        with DM.harmonic(O_k, K_k, N_k, seed=5, n_global0=n0, N_local=nloc) as sh:
+            sh.set_Nk(N_k)
+            parts.append(sh.eval(f2, gram=True) + (sh.lognum(f),))
+    np.testing.assert_allclose(parts[0][0] + parts[1][0], pw, rtol=1e-12)
+    np.testing.assert_allclose(parts[0][1] + parts[1][1], sw, rtol=1e-13)
+    np.testing.assert_allclose(parts[0][2] + parts[1][2], gw, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(np.logaddexp(parts[0][3], parts[1][3]), lnw, rtol=1e-12, atol=1e-12)
+    assert abs(pw[0].sum() - N) < 1e-6 * N ** 0.5
+
+
 def test_rccl_communicator_single_rank(DM):
     """RCCL path end to end on one GPU: dlopen librccl, ncclGetUniqueId, ncclCommInitRank(nranks=1), and every
     reduced output going through ncclAllReduce on the compute stream.  (More ranks need more GPUs; the decomposition
