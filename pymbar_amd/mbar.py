@@ -9,7 +9,7 @@ fp64 matrix cores and only K x K linear algebra (eigh / pinv) runs on the host.
 
 The ``Log_W_nk`` consumers (``compute_expectations*``, ``compute_perturbed_free_energies``,
 ``compute_entropy_and_enthalpy``) live in :mod:`pymbar_amd.expectations` and are bound as
-methods below.  Not mirrored (not on the K x N solver path): BAR initialisation, FES, timeseries.
+methods below.  Not mirrored (not on the K x N solver path): FES, timeseries, the other estimators.
 """
 import copy
 import logging
@@ -320,9 +320,10 @@ class MBAR:
             if np.max(np.abs(means)) < 0.000001:
                 logger.warning("Warning: All mean reduced potentials are close to zero.")
             self.f_k = means
-        elif method == "BAR":
-            raise ParameterError("initialize='BAR' is outside the MI355X hot-path scope (SURVEY.md 8f rank 4); "
-                                 "use 'zeros' or 'mean-reduced-potential'")
+        elif method == "BAR":  # chained pairwise BAR estimates on the host copy (mbar.py:1936-1988)
+            from .bar_init import initialize_with_bar
+
+            self.f_k = initialize_with_bar(self.u_kn, self.N_k, self.x_kindices)
         else:
             raise ParameterError("Method " + method + " unrecognized.")
         self.f_k[:] = self.f_k[:] - self.f_k[0]
