@@ -309,6 +309,18 @@ class MBAR:
     compute_perturbed_free_energies = _expectations.compute_perturbed_free_energies
     compute_entropy_and_enthalpy = _expectations.compute_entropy_and_enthalpy
 
+    def _computeUnnormalizedLogWeights(self, u_n):
+        """``-ln sum_k N_k exp(f_k - (u_k(x_n) - u(x_n)))`` for one target potential ``u_n`` (mbar.py:1919-1934):
+        ``-(u_n + logden_n)`` with the per-sample log-denominator from one device sweep."""
+        self._dm.set_Nk(self.N_k)
+        return -(np.asarray(u_n, dtype=np.float64) + self._dm.logden(self.f_k))
+
+    def _initialize_with_bar(self, u_kn, f_k_init=None):
+        """Chained pairwise BAR guess (mbar.py:1936-1988); see :mod:`pymbar_amd.bar_init`."""
+        from .bar_init import initialize_with_bar
+
+        return initialize_with_bar(np.asarray(u_kn), self.N_k, self.x_kindices, f_k_init)
+
     def _initializeFreeEnergies(self, verbose=False, method="zeros"):
         """Initial guess (mbar.py:1868-1917): zeros or the per-state mean reduced potential."""
         if method == "zeros":

@@ -92,3 +92,18 @@ def test_bootstrap_is_deterministic_under_rseed():
     assert r["dDelta_f"].shape == (3, 3) and np.all(np.diag(r["dDelta_f"]) == 0)
     ra = a.compute_free_energy_differences()
     assert np.all(np.abs(r["dDelta_f"] - ra["dDelta_f"]) < 0.2)
+
+
+def test_initialize_bar_and_unnormalized_log_weights(golden):
+    """initialize="BAR" feeds the solver the chained pairwise guess (tests/golden/bar_init.npz holds the reference's
+    values); _computeUnnormalizedLogWeights is the reference's one-line logsumexp (mbar.py:1919-1934)."""
+    from scipy.special import logsumexp
+
+    gb = golden("bar_init.npz")
+    g = golden("config1_ho_K5_N5000.npz")
+    mbar = pymbar_amd.MBAR(g["u_kn"], g["N_k"], initialize="BAR")
+    np.testing.assert_allclose(mbar.f_k, gb["config1_f_k"], atol=1e-10)
+    np.testing.assert_allclose(mbar._initialize_with_bar(mbar.u_kn), gb["config1_f_init"], rtol=1e-12, atol=1e-13)
+    u_n = 0.5 * (g["u_kn"][1] + g["u_kn"][3])
+    ref = -1.0 * logsumexp(mbar.f_k + u_n[:, np.newaxis] - mbar.u_kn.T, b=mbar.N_k, axis=1)
+    np.testing.assert_allclose(mbar._computeUnnormalizedLogWeights(u_n), ref, rtol=1e-12, atol=1e-12)
