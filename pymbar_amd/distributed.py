@@ -44,19 +44,30 @@ def attach_allreduce(dm, prefer="rccl"):
     rank, nranks = dist.get_rank(), dist.get_world_size()
     if prefer == "rccl":
         ok = True
-        try:
-            from . import _lib
-            import ctypes as C
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+            # single-node rendezvous: RCCL's bootstrap sockets may use the loopback interface (it is skipped by
+            # default, and a network-less container has no other one); the data path is xGMI either way
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        payload = [None]
+        if rank == 0:  # a failure here must still reach the broadcast below, or the other ranks wait forever
+            try:
+                from . import _lib
+                import ctypes as C
 
-            buf = C.create_string_buffer(128)
-            if rank == 0:
+                buf = C.create_string_buffer(128)
                 _lib.check(_lib.load_library().mbar_comm_unique_id(buf))
-            payload = [bytes(buf.raw) if rank == 0 else None]
-            dist.broadcast_object_list(payload, src=0)
-            dm.comm_init_rccl(payload[0], rank, nranks)
-        except Exception as exc:  # pragma: no cover - needs several GPUs
-            logger.warning("RCCL initialisation failed on rank %d (%s); using the host all-reduce", rank, exc)
+                payload = [bytes(buf.raw)]
+            except Exception as exc:  # pragma: no cover - needs RCCL
+                logger.warning("RCCL unique id could not be created (%s); using the host all-reduce", exc)
+        dist.broadcast_object_list(payload, src=0)
+        if payload[0] is None:
             ok = False
+        else:
+            try:
+                dm.comm_init_rccl(payload[0], rank, nranks)
+            except Exception as exc:  # pragma: no cover - needs several GPUs
+                logger.warning("RCCL initialisation failed on rank %d (%s); using the host all-reduce", rank, exc)
+                ok = False
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:

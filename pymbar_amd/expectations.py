@@ -32,24 +32,29 @@ logger = logging.getLogger(__name__)
 _LOGFACTOR = 4.0 * np.finfo(np.float64).eps  # pymbar/mbar.py:827-832
 
 
-def _augmented_solve(mbar, u_kn, f_k, rows, device):
-    """Upload ``[u_kn; rows]`` with the extra rows unsampled; return (f_full, lognum, Gram W^T W or None fn)."""
+def _augmented_matrix(mbar, rows, device):
+    """Upload ``[u_kn; rows]`` once, the extra rows as unsampled states (N_k = 0: they do not enter the denominator)."""
     from .device import DeviceMatrix
 
     K = mbar.K
     R = rows.shape[0]
-    aug = np.empty((K + R, u_kn.shape[1]), dtype=np.float64)
-    aug[:K] = u_kn
+    aug = np.empty((K + R, mbar.u_kn.shape[1]), dtype=np.float64)
+    aug[:K] = mbar.u_kn
     aug[K:] = rows
     N_aug = np.zeros(K + R, dtype=np.float64)
     N_aug[:K] = mbar.N_k
     dm = DeviceMatrix.from_host(aug, device=device)
     dm.set_Nk(N_aug)
+    return dm, N_aug
+
+
+def _augmented_solve(dm, K, R, f_k):
+    """Normalisers of the augmented matrix at ``f_k``: (f_full, lognum) with f_full[K:] = -lognum[K:]."""
     f_full = np.zeros(K + R, dtype=np.float64)
     f_full[:K] = f_k
-    lognum = dm.lognum(f_full)  # extra rows do not enter the denominator (N_k = 0)
+    lognum = dm.lognum(f_full)
     f_full[K:] = -lognum[K:]
-    return dm, f_full, lognum, N_aug
+    return f_full, lognum
 
 
 def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=None, warning_cutoff=1.0e-10,
@@ -93,20 +98,23 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
         A_i_bootstrap = np.zeros([mbar.n_bootstraps, S])
         f_bootstrap = np.zeros([mbar.n_bootstraps, len(state_list)])
     Theta_ij = None
-    for n in range(n_total):
-        if n == 0:
-            f_k, ri, u_kn = mbar.f_k, slice(None), mbar.u_kn
-        else:
-            f_k, ri = mbar.f_k_boots[n - 1, :], mbar.bootstrap_rints[n - 1]
-            u_kn = mbar.u_kn[:, ri]
-        rows = np.empty((NL + S, N), dtype=np.float64)
-        for j, l in enumerate(L_list):
-            rows[j] = u_ln[l, ri]
-        with np.errstate(divide="ignore"):
-            for s in range(S):
-                rows[NL + s] = u_ln[state_list[s], ri] - np.log(A_n[obs_list[s], ri])
-        dm, f_full, lognum, N_aug = _augmented_solve(mbar, u_kn, f_k, rows, getattr(mbar, "_device", None))
-        try:
+    # The augmented matrix goes to the device once.  A bootstrap replicate (mbar.py:905-912 gathers
+    # u_kn[:, bootstrap_rints[n]]) is the same matrix with per-sample multiplicities = draw counts.
+    rows = np.empty((NL + S, N), dtype=np.float64)
+    for j, l in enumerate(L_list):
+        rows[j] = u_ln[l]
+    with np.errstate(divide="ignore"):
+        for s in range(S):
+            rows[NL + s] = u_ln[state_list[s]] - np.log(A_n[obs_list[s]])
+    dm, N_aug = _augmented_matrix(mbar, rows, getattr(mbar, "_device", None))
+    try:
+        for n in range(n_total):
+            if n == 0:
+                f_k = mbar.f_k
+            else:
+                f_k = mbar.f_k_boots[n - 1, :]
+                dm.set_sample_weights(np.bincount(mbar.bootstrap_rints[n - 1], minlength=N))
+            f_full, lognum = _augmented_solve(dm, K, NL + S, f_k)
             f_states = np.array([f_full[K + col_of_state[int(l)]] for l in state_list])
             A_i = np.array([np.exp(lognum[K + NL + s] - lognum[K + col_of_state[int(state_list[s])]]) for s in range(S)])
             if n == 0:
@@ -119,8 +127,8 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
             else:
                 A_i_bootstrap[n - 1, :] = A_i + (A_min[obs_list] - logfactors[obs_list]) if S > 0 else 0.0
                 f_bootstrap[n - 1, :] = f_states
-        finally:
-            dm.close()
+    finally:
+        dm.close()
     if bootstrap:
         result_vals["bootstrapped_observables"] = A_i_bootstrap
         result_vals["bootstrapped_f"] = f_bootstrap
