@@ -1170,10 +1170,10 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
         }
         f_old = f;
         int choice;
-        double take_sci = (gn_sci < gn_nr || res.sci_iter < min_sc_iter) ? 1.0 : 0.0;
-        rc = agree_with_rank0(c, &take_sci, 1);
-        if (rc) return rc;
-        if (take_sci > 0.5) {  // :607
+        // (every rank holds bit-identical reduced sums, so this choice needs no collective; only the loop exit below
+        // is agreed on explicitly, because a desynchronised exit would strand the other ranks in an all-reduce)
+        const bool take_sci = gn_sci < gn_nr || res.sci_iter < min_sc_iter;
+        if (take_sci) {  // :607
             std::copy(f_sci, f_sci + K, f.begin());
             std::copy(psum2.begin(), psum2.begin() + K, psum.begin());
             cur = sA;
