@@ -16,12 +16,8 @@ from scipy.special import logsumexp
 logger = logging.getLogger(__name__)
 
 
-class BarConvergenceError(Exception):
-    """The bisection did not meet its tolerance within the iteration limit."""
-
-
-class BarBoundsError(Exception):
-    """The root is not bracketed any more (other_estimators.py: BoundsError)."""
+from .utils import BoundsError as BarBoundsError  # noqa: E402  (pymbar's own classes when pymbar is installed)
+from .utils import ConvergenceError as BarConvergenceError  # noqa: E402
 
 
 def exp_delta_f(w):

@@ -9,20 +9,27 @@ import warnings
 import numpy as np
 
 
-class ParameterError(Exception):
-    """An error in the input parameters has been detected."""
+try:
+    # With pymbar itself installed the SAME exception classes are raised, so callers that switch the backend keep
+    # their ``except pymbar.utils.ParameterError`` clauses (and the reference's own tests pass unchanged).
+    from pymbar.utils import (BoundsError, ConvergenceError, DataError, ParameterError,  # noqa: F401
+                              TypeCastPerformanceWarning)
+except Exception:  # pymbar absent (or not importable in this interpreter): same names, same meaning (utils.py:401-422)
 
+    class ParameterError(Exception):
+        """An error in the input parameters has been detected."""
 
-class ConvergenceError(Exception):
-    """Convergence could not be achieved."""
+    class ConvergenceError(Exception):
+        """Convergence could not be achieved."""
 
+    class BoundsError(Exception):
+        """Could not determine bounds on free energy."""
 
-class DataError(Exception):
-    """Data is inconsistent."""
+    class DataError(Exception):
+        """Data is inconsistent."""
 
-
-class TypeCastPerformanceWarning(RuntimeWarning):
-    pass
+    class TypeCastPerformanceWarning(RuntimeWarning):
+        pass
 
 
 def ensure_type(val, dtype, ndim, name, length=None, can_be_none=False, shape=None, warn_on_cast=True,

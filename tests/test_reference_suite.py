@@ -1,0 +1,34 @@
+"""Run the REFERENCE'S OWN test files against this repository's drop-in.
+
+``/root/reference/pymbar/tests/test_mbar.py`` and ``test_mbar_solvers.py`` are executed in place (nothing is copied) in
+a subprocess whose ``pymbar.MBAR`` and ``pymbar.mbar_solvers`` are replaced by ``pymbar_amd.MBAR`` /
+``pymbar_amd.mbar_solvers`` (tests/refshim/refshim_plugin.py); the device is the CPU stand-in, so this checks the
+boundary -- names, argument meaning, return types, exception classes, and the numbers the reference's tests assert
+(analytical free energies within z-scores, expectations, overlap, bootstrap determinism, every solver method and
+protocol).  numpy's global RNG is seeded per test because the reference's fixtures draw unseeded samples.
+
+Only meaningful where the reference is mounted (the build container); skipped elsewhere (GPU box)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pymbar", "tests")), reason="reference tree not mounted")
+@pytest.mark.parametrize("test_file,min_passed", [("test_mbar.py", 60), ("test_mbar_solvers.py", 34)])
+def test_reference_tests_pass_on_the_drop_in(test_file, min_passed):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests", "refshim"), REF, ROOT])
+    cmd = [sys.executable, "-m", "pytest", os.path.join(REF, "pymbar", "tests", test_file), "-p", "refshim_plugin",
+           "-p", "no:cacheprovider", "-q", "--rootdir=/tmp", "-c", "/dev/null", "-W", "ignore"]
+    out = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=900)
+    tail = out.stdout[-3000:]
+    assert out.returncode == 0, tail + out.stderr[-2000:]
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= min_passed, tail
+    assert not re.search(r"\d+ (failed|error)", tail.splitlines()[-1])
