@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmbar_hip.so")
+LIB_PATH = os.environ.get("MBAR_HIP_LIBRARY") or os.path.join(HERE, "csrc", "libmbar_hip.so")  # (override: A/B builds)
 
 MBAR_OK = 0
 EVAL_GRAM = 1
