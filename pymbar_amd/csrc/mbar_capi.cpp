@@ -504,6 +504,7 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
     std::vector<double> h((size_t)nf * rows);
     for (int i = 0; i < nf; ++i) build_aden(c, f + (size_t)i * c->K, h.data() + (size_t)i * rows, rows);
     bool split = false;
+    std::vector<double> ratio;  // c_k of the fused two-candidate sweep; applied to its second psum row below
     if (nf == 2 && use_fast(c)) {
         double dmax = 0.0;
         for (int64_t k = 0; k < rows; ++k) {
@@ -513,6 +514,7 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
             h[rows + k] = std::exp(d);
         }
         split = !(dmax < 300.0);
+        if (!split) ratio.assign(h.begin() + rows, h.begin() + 2 * rows);
     }
     if (split) {
         std::vector<double> ps((size_t)2 * c->K), sl(2);
@@ -542,6 +544,8 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
     HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     rc = sync_stream(c);
     if (rc) return rc;
+    if (!ratio.empty())  // the fused sweep accumulates sum_n e_nk / s'_n for the second candidate: times c_k = its psum
+        for (int64_t k = 0; k < rows; ++k) c->hred[(size_t)rows + k] *= ratio[(size_t)k];
     if (psum)
         for (int i = 0; i < nf; ++i)
             for (int64_t k = 0; k < c->K; ++k) psum[(size_t)i * c->K + k] = c->hred[(size_t)i * rows + k];

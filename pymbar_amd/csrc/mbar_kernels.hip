@@ -131,6 +131,11 @@ __device__ __forceinline__ double log_pos(double s) {
 // polynomials) runs while they are in flight, stage 3 combines.  x[] in: ts, out: 2^(ts/S).
 template <int N>
 __device__ __forceinline__ void exp2s_batch(double (&x)[N]) {
+#ifdef MBAR_EXPERIMENT_NOEXP
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = fma(x[i], 1e-9, 1.0);
+    return;
+#endif
     double T[N];
     int q[N];
 #pragma unroll
@@ -151,6 +156,11 @@ __device__ __forceinline__ void exp2s_batch(double (&x)[N]) {
 }
 template <int N>
 __device__ __forceinline__ void exp2s_batch2(double (&x0)[N], double (&x1)[N]) {  // two argument sets, one pipeline
+#ifdef MBAR_EXPERIMENT_NOEXP
+#pragma unroll
+    for (int i = 0; i < N; ++i) { x0[i] = fma(x0[i], 1e-9, 1.0); x1[i] = fma(x1[i], 1e-9, 1.0); }
+    return;
+#endif
     double T0[N], T1[N];
     int q0[N], q1[N];
 #pragma unroll
@@ -211,6 +221,22 @@ __device__ __forceinline__ double tree_sum(const double (&x)[NB]) {
         for (int i = 0; i < n / 2; ++i) t[i] += t[n - 1 - i];
     }
     return t[0];
+}
+// sum_i x_i c_i as two interleaved FMA chains (NB + 1 instructions; a product array + tree_sum takes 2 NB - 1)
+template <int NB>
+__device__ __forceinline__ double dot_sum(const double (&x)[NB], const double (&c)[NB]) {
+    if constexpr (NB == 1) {
+        return x[0] * c[0];
+    } else {
+        double e = x[0] * c[0], o = x[1] * c[1];
+#pragma unroll
+        for (int i = 2; i + 1 < NB; i += 2) {
+            e = fma(x[i], c[i], e);
+            o = fma(x[i + 1], c[i + 1], o);
+        }
+        if constexpr (NB & 1) e = fma(x[NB - 1], c[NB - 1], e);
+        return e + o;
+    }
 }
 // 16-lane all-reduce of two independent values at once (the two dependency chains interleave)
 __device__ __forceinline__ void row16_max2(double& a, double& b) {
@@ -282,14 +308,13 @@ __device__ __forceinline__ void lse_math2(double (&x0)[NB], double (&x1)[NB], co
     } else {
         exp2s_batch2<NB>(x0, x1);
     }
+    // Second candidate: e'_k = e_k c_k.  Only its sum needs the products (an FMA dot instead of NB multiplies + a
+    // tree of adds); the per-state accumulator takes the UNSCALED e_k r' and the constant c_k is applied once to
+    // the reduced sums on the host (mbar_capi.cpp: eval_core).
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        if (f == 1) {
-#pragma unroll
-            for (int I = 0; I < NB; ++I) { x0[I] *= c[I]; x1[I] *= c[I]; }
-        }
-        s0[f] = tree_sum<NB>(x0);
-        s1[f] = tree_sum<NB>(x1);
+        s0[f] = f == 0 ? tree_sum<NB>(x0) : dot_sum<NB>(x0, c);
+        s1[f] = f == 0 ? tree_sum<NB>(x1) : dot_sum<NB>(x1, c);
         row16_sum2(s0[f], s1[f]);
         const double r0 = w0 * recip_fast(s0[f]), r1 = w1 * recip_fast(s1[f]);  // w: sample multiplicity (0 on padding)
 #pragma unroll
@@ -320,11 +345,7 @@ __device__ __forceinline__ void lse_one_group(const char* cbuf, const char* tbl,
     exp2s_batch<NB>(x0);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        if (f == 1) {
-#pragma unroll
-            for (int I = 0; I < NB; ++I) x0[I] *= c[I];
-        }
-        s0[f] = row16_sum(tree_sum<NB>(x0));
+        s0[f] = row16_sum(f == 0 ? tree_sum<NB>(x0) : dot_sum<NB>(x0, c));
         const double r0 = w0 * recip_fast(s0[f]);
 #pragma unroll
         for (int I = 0; I < NB; ++I) acc[f][I] = fma(x0[I], r0, acc[f][I]);
