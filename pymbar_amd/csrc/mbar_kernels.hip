@@ -131,7 +131,7 @@ __device__ __forceinline__ double log_pos(double s) {
 // polynomials) runs while they are in flight, stage 3 combines.  x[] in: ts, out: 2^(ts/S).
 template <int N>
 __device__ __forceinline__ void exp2s_batch(double (&x)[N]) {
-#ifdef MBAR_EXPERIMENT_NOEXP
+#ifdef MBAR_EXPERIMENT_NOEXP  // timing experiment only (profiles/r1_noexp_experiment.txt): results are garbage
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = fma(x[i], 1e-9, 1.0);
     return;
@@ -505,6 +505,8 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int64_t W = (int64_t)gridDim.x * nwv;
     const RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+    // one global store per tile (lanes ks < 4 write logden0, 4 <= ks < 8 logden1) unless neither vector is wanted
+    const bool has_store = logden0 != nullptr || logden1 != nullptr;
 
     double a[NB], c[NB], acc[NF][NB], objl = 0.0;
 #pragma unroll
@@ -543,7 +545,13 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                 char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
                 stage_tile<ROWS, true, 0, 1>(u, ld, tn * TS, nbuf, lane, so, rows);
                 stage_vec16<true>(cw, tn * TS, nbuf + U_BYTES, lane);
-                wait_vm<NDMA>();
+                // vmcnt counts stores too (in issue order with the loads on gfx9): the queue here is
+                // [tile t][logden store of tile t - W][tile tn].  Waiting for "at most NDMA outstanding" would
+                // also wait for that store -- a full memory round trip exposed on every tile.
+                if (has_store && t != gw)  // (no store has been issued before the wave's first tile)
+                    wait_vm<NDMA + 1>();
+                else
+                    wait_vm<NDMA>();
             } else {
                 wait_vm<0>();
             }
@@ -612,6 +620,7 @@ k_lse_early(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int64_t W = (int64_t)gridDim.x * nwv;
     const RowIdentity rows{0};
     const StageOffsets so = make_stage_offsets(ld, lane);
+    const bool has_store = logden0 != nullptr || logden1 != nullptr;  // one store instruction per tile
 
     double a[NB], c[NB], acc[NF][NB], objl = 0.0;
 #pragma unroll
@@ -645,10 +654,20 @@ k_lse_early(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     for (; t < ntiles; t += W) {
         char* buf = buf0 + cur * TILE_BYTES;
         const char* wslot = buf + U_BYTES;
-        if (NBUF == 2 && t + W < ntiles)
-            wait_vm<NDMA>();  // the tile after this one may still be in flight
-        else
+        // vmcnt counts the logden stores too, in issue order: [tile t][store][tile t + W][store] for two buffers,
+        // [tile t][store] for one
+        if (NBUF == 2 && t + W < ntiles) {
+            if (!has_store || t == gw)
+                wait_vm<NDMA>();      // first tile: [tile t][tile t + W]
+            else if (t == gw + W)
+                wait_vm<NDMA + 1>();  // second: [tile t][tile t + W][store]
+            else
+                wait_vm<NDMA + 2>();
+        } else if (NBUF == 1 && has_store && t != gw) {
+            wait_vm<1>();
+        } else {
             wait_vm<0>();
+        }
         // the weight slot is refilled together with the tile: take what this lane needs from it first
         double w[GROUPS];
 #pragma unroll

@@ -23,7 +23,8 @@ __device__ __forceinline__ void dma16(const char* base /*uniform*/, uint32_t vof
 
 // MODE 0: row-major, 1: tile-major.  WPB waves per block, each wave double-buffers its own tiles.
 template <int MODE, int WPB>
-__global__ void __launch_bounds__(WPB * 64) k_dma(const double* __restrict__ u, int64_t ld, int64_t ntiles, double* sink) {
+__global__ void __launch_bounds__(WPB * 64) k_dma(const double* __restrict__ u, int64_t ld, int64_t ntiles, double* sink,
+                                                  int delay /* x64 clocks of s_sleep per tile: stands in for the compute */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -52,6 +53,7 @@ __global__ void __launch_bounds__(WPB * 64) k_dma(const double* __restrict__ u, 
         const char* cb = buf + cur * (ROWS * TS * 8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc += *reinterpret_cast<const double*>(cb + (i * 64 + lane) * 8 * 8);
+        for (int d = 0; d < delay; ++d) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
         cur ^= 1;
     }
     if (acc == 12345.6789) sink[threadIdx.x] = acc;
@@ -67,7 +69,7 @@ __global__ void __launch_bounds__(256) k_stream(const double2* __restrict__ u, i
 }
 
 template <int MODE, int WPB>
-void run(const double* u, int64_t ld, int64_t ntiles, double* sink, int blocks, const char* name) {
+void run(const double* u, int64_t ld, int64_t ntiles, double* sink, int blocks, const char* name, int delay = 0) {
     const size_t lds = (size_t)WPB * 2 * ROWS * TS * 8;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_dma<MODE, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
@@ -75,15 +77,15 @@ void run(const double* u, int64_t ld, int64_t ntiles, double* sink, int blocks, 
     hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_dma<MODE, WPB>), dim3(blocks), dim3(WPB * 64), lds, 0, u, ld, ntiles, sink);
+        hipLaunchKernelGGL((k_dma<MODE, WPB>), dim3(blocks), dim3(WPB * 64), lds, 0, u, ld, ntiles, sink, delay);
         hipEventRecord(e1);
         hipDeviceSynchronize();
     }
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double bytes = (double)ntiles * ROWS * TS * 8;
-    printf("%-34s blocks=%4d waves/block=%d : %.3f ms  %.0f GB/s  (%s)\n", name, blocks, WPB, ms, bytes / ms * 1e-6,
-           hipGetErrorString(hipGetLastError()));
+    printf("%-34s blocks=%4d waves/block=%d delay=%3d x64clk : %.3f ms  %.0f GB/s  (%s)\n", name, blocks, WPB, delay, ms,
+           bytes / ms * 1e-6, hipGetErrorString(hipGetLastError()));
 }
 
 int main() {
@@ -98,6 +100,8 @@ int main() {
     printf("device %s CUs=%d, %.2f GB per sweep\n", p.gcnArchName, cus, ROWS * N * 8e-9);
     run<0, 4>(u, ld, ntiles, sink, cus, "row-major tiles (128 x 128 B)");
     run<1, 4>(u, ld, ntiles, sink, cus, "tile-major tiles (16 KB blocks)");
+    for (int delay : {20, 40, 60, 80, 100, 120})  // 64-clock units: 100 = 6400 clocks = 3 us of "compute" per tile
+        run<0, 4>(u, ld, ntiles, sink, cus, "row-major + per-tile delay", delay);
     run<0, 2>(u, ld, ntiles, sink, 2 * cus, "row-major tiles (128 x 128 B)");
     run<1, 2>(u, ld, ntiles, sink, 2 * cus, "tile-major tiles (16 KB blocks)");
     hipEvent_t e0, e1;
