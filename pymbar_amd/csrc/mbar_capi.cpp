@@ -351,9 +351,12 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
     return MBAR_OK;
 }
 
-// Gram-pass geometry: list of (kind, row_i0, row_j0, nb) launches and where their blocks land.
+// Gram-pass geometry: list of launches and where their 16 x 16 blocks land.  Up to 128 states: one diagonal panel.
+// Beyond: 128-state panels (+ one trailing 64-state panel); a diagonal panel is one launch (upper-triangular blocks),
+// a pair of panels is covered by 64 x 128 rectangles (nbi = 4 block rows of the I panel x nbj = 8 block columns of the
+// J panel = 32 blocks, the most one wave's register file holds next to the operands).
 struct GramPlan {
-    struct Item { bool diag; int64_t ri, rj; int nb; int nblk; size_t off; };
+    struct Item { bool diag; int64_t ri, rj; int nbi, nbj; int nblk; size_t off; };
     std::vector<Item> items;
     size_t total_blocks = 0;
 };
@@ -361,20 +364,41 @@ GramPlan gram_plan(int64_t Kp) {
     GramPlan p;
     if (Kp <= 128) {
         int nb = (int)(Kp / 16);
-        p.items.push_back({true, 0, 0, nb, nb * (nb + 1) / 2, 0});
+        p.items.push_back({true, 0, 0, nb, nb, nb * (nb + 1) / 2, 0});
         p.total_blocks = (size_t)nb * (nb + 1) / 2;
         return p;
     }
-    const int P = (int)(Kp / PANEL);
-    size_t off = 0;
-    for (int a = 0; a < P; ++a) {
-        p.items.push_back({true, (int64_t)a * PANEL, (int64_t)a * PANEL, 4, 10, off});
-        off += 10;
+    struct Panel { int64_t r0; int nb; };
+    std::vector<Panel> panels;
+    for (int64_t r = 0; r < Kp;) {
+        const int nb = Kp - r >= 128 ? 8 : (int)((Kp - r) / 16);  // Kp is a multiple of PANEL = 64 here
+        panels.push_back({r, nb});
+        r += 16 * nb;
     }
-    for (int a = 0; a < P; ++a)
-        for (int b = a + 1; b < P; ++b) {
-            p.items.push_back({false, (int64_t)a * PANEL, (int64_t)b * PANEL, 4, 16, off});
-            off += 16;
+    size_t off = 0;
+    for (const auto& a : panels) {
+        const int nblk = a.nb * (a.nb + 1) / 2;
+        p.items.push_back({true, a.r0, a.r0, a.nb, a.nb, nblk, off});
+        off += nblk;
+    }
+    for (size_t ia = 0; ia < panels.size(); ++ia)
+        for (size_t ib = ia + 1; ib < panels.size(); ++ib) {
+            const Panel &a = panels[ia], &b = panels[ib];
+            if (b.nb == 8) {  // 128 x 128: two 64 x 128 rectangles
+                for (int h = 0; h < 2; ++h) {
+                    p.items.push_back({false, a.r0 + 64 * h, b.r0, 4, 8, 32, off});
+                    off += 32;
+                }
+            } else if (b.nb == 4) {  // the trailing 64-state panel against a 128-state one: I = the short panel
+                p.items.push_back({false, b.r0, a.r0, 4, 8, 32, off});
+                off += 32;
+            } else {  // (cannot happen for Kp a multiple of 64; kept correct anyway: 64 x 64 squares)
+                for (int64_t ri = a.r0; ri < a.r0 + 16 * a.nb; ri += 64)
+                    for (int64_t rj = b.r0; rj < b.r0 + 16 * b.nb; rj += 64) {
+                        p.items.push_back({false, ri, rj, 4, 4, 16, off});
+                        off += 16;
+                    }
+            }
         }
     p.total_blocks = off;
     return p;
@@ -392,7 +416,7 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
         logden = c->lden_eff;
     }
     for (const auto& it : plan.items) {
-        const int tile_rows = it.diag ? it.nb * 16 : 128;
+        const int tile_rows = it.diag ? it.nbi * 16 : (it.nbi + it.nbj) * 16;
         LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
         const size_t rec = (size_t)it.nblk * 256;
         int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
@@ -403,10 +427,10 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
         {
             ScopedTimer t(c, MBAR_TIMER_GRAM);
             if (it.diag)
-                HIPCHK(c, launch_gram_diag(c->stream, it.nb, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, logden,
+                HIPCHK(c, launch_gram_diag(c->stream, it.nbi, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, logden,
                                            it.ri, gp, nullptr));
             else
-                HIPCHK(c, launch_gram_off(c->stream, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
+                HIPCHK(c, launch_gram_off(c->stream, it.nbj, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
                                           logden, it.ri, it.rj, gp));
         }
         {
@@ -431,8 +455,8 @@ void gram_operand_sums(const double* G, int64_t K, const double* w, double* out)
 void unpack_gram(const GramPlan& plan, const double* blocks, int64_t K, double* G) {
     for (const auto& it : plan.items) {
         int b = 0;
-        for (int I = 0; I < it.nb; ++I) {
-            for (int J = it.diag ? I : 0; J < it.nb; ++J) {
+        for (int I = 0; I < it.nbi; ++I) {
+            for (int J = it.diag ? I : 0; J < it.nbj; ++J) {
                 const double* blk = blocks + (it.off + b) * 256;
                 for (int r = 0; r < 16; ++r)
                     for (int q = 0; q < 16; ++q) {

@@ -53,7 +53,7 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u,
                             int64_t ld, int64_t N, const double* anum /*indexed from row0*/,
                             const double* logden, int64_t row0, double* gram_part, double* psum_part);
-hipError_t launch_gram_off(hipStream_t s, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
+hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
                            int64_t N, const double* anum_i, const double* anum_j, const double* logden,
                            int64_t row_i0, int64_t row_j0, double* gram_part);
 

@@ -843,7 +843,7 @@ k_lse_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // triangular blocks only; otherwise an NBI x NBJ rectangle between two panels.
 // Output block b, register r, lane l  ->  element (row = (l >> 4) + 4 r, col = l & 15) of block b.
 // ---------------------------------------------------------------------------------------------
-constexpr int GRAM8_AGPR_BLOCKS = 31;
+constexpr int GRAM_AGPR_BLOCKS = 31;
 template <int NBI, int NBJ, bool DIAG, bool DMA, bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
@@ -857,6 +857,15 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the tile's 16 logden values
     constexpr int NDMA = ROWS / 8 + 1;
     constexpr int NBLK = DIAG ? NBI * (NBI + 1) / 2 : NBI * NBJ;
+    // More than 31 blocks (36 for the full diagonal panel, 32 for the 64 x 128 rectangle) do not fit the 256 AGPRs next
+    // to anything else, and hipcc then rotates every accumulator through v_accvgpr copies.  The register class is
+    // pinned per block instead: the first GRAM_AGPR_BLOCKS live in AGPRs, the rest in VGPRs (one wave per SIMD owns
+    // the whole register file).
+    constexpr bool PINNED = NBLK > GRAM_AGPR_BLOCKS;
+    // Tiles of more than 128 rows (the rectangle stages 192) get ONE buffer per wave: every LDS operand of a tile is
+    // in registers right after the loop top, so the buffer is refilled there and the DMA still has the whole tile
+    // period to land.
+    constexpr int NBUF = ROWS > 128 ? 1 : 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
@@ -864,7 +873,7 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     char* tbl = smem;
     exp_table_init(smem);
     __syncthreads();
-    char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
+    char* buf = smem + EXP_TABLE_BYTES + wave * (NBUF * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
     const RowTwoPanels rows{row_i0, row_j0, DIAG ? ROWS : NBI * 16};
@@ -897,7 +906,9 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     }
     for (; t < ntiles; t += W) {
         char* cbuf = buf + cur * TILE_BYTES;
-        if constexpr (DMA) {
+        if constexpr (DMA && NBUF == 1) {
+            wait_vm<0>();
+        } else if constexpr (DMA) {
             const int64_t tn = t + W;
             if (tn < ntiles) {
                 char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
@@ -923,6 +934,14 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                 uv[g][I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DMA && NBUF == 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the whole tile is in registers: refill its buffer
+            if (t + W < ntiles) {
+                stage_tile<ROWS, true, 0, 1>(u, ld, (t + W) * TS, cbuf, lane, so, rows);
+                stage_vec16<true>(logden, (t + W) * TS, cbuf + U_BYTES, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const bool valid = (t * TS + 4 * g + ns) < N;
@@ -931,42 +950,40 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 #pragma unroll
             for (int I = 0; I < NBT; ++I) p[I] = fma(uv[g][I], -LOG2E_S, aS[I] - lde * LOG2E_S);
             exp2s_batch<NBT>(p);
-            if constexpr (DIAG && NBI == 8) {
-                // 36 blocks = 288 accumulator registers: more than the 256 AGPRs, and hipcc then rotates every
-                // accumulator through v_accvgpr copies.  The register class is pinned per block instead: the first
-                // GRAM8_AGPR_BLOCKS live in AGPRs, the rest in VGPRs (the wave owns the SIMD's whole register file).
+            auto mfma = [&](int b, double x, double y) {
+                if constexpr (PINNED) {
+                    if (b < GRAM_AGPR_BLOCKS)
+                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(x), "v"(y));
+                    else
+                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(x), "v"(y));
+                } else {
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[b], 0, 0, 0);
+                }
+            };
+            // The asm MFMAs are opaque to the scheduler and to the hazard recogniser.  Left free, hipcc interleaves the next
+            // group's VALU work between them and the 64 x 128 rectangle then produced wrong blocks (a matrix-core
+            // hazard the compiler could not see); fenced, the block is issued as written, behind one conservative s_nop.
+            if constexpr (PINNED) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7");
+            }
+            if constexpr (DIAG) {
                 int b = 0;
 #pragma unroll
                 for (int I = 0; I < NBI; ++I)
 #pragma unroll
-                    for (int J = I; J < NBI; ++J) {
-                        if (b < GRAM8_AGPR_BLOCKS)
-                            asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(p[I]), "v"(p[J]));
-                        else
-                            asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(p[I]), "v"(p[J]));
-                        ++b;
-                    }
-            } else if constexpr (DIAG) {
-                int b = 0;
-#pragma unroll
-                for (int I = 0; I < NBI; ++I)
-#pragma unroll
-                    for (int J = I; J < NBI; ++J) {
-                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[I], p[J], acc[b], 0, 0, 0);
-                        ++b;
-                    }
+                    for (int J = I; J < NBI; ++J) mfma(b++, p[I], p[J]);
             } else {
 #pragma unroll
                 for (int I = 0; I < NBI; ++I)
 #pragma unroll
-                    for (int J = 0; J < NBJ; ++J)
-                        acc[I * NBJ + J] =
-                            __builtin_amdgcn_mfma_f64_16x16x4f64(p[I], p[NBI + J], acc[I * NBJ + J], 0, 0, 0);
+                    for (int J = 0; J < NBJ; ++J) mfma(I * NBJ + J, p[I], p[NBI + J]);
             }
+            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
         }
-        cur ^= 1;
+        cur ^= NBUF - 1;
     }
-    if constexpr (DIAG && NBI == 8) {
+    if constexpr (PINNED) {
         // the asm MFMAs are opaque to the hazard recogniser: cover the matrix-result -> VALU read distance by hand
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
@@ -1588,7 +1605,7 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
     g.waves = 4;
     g.variant = -1;
     const size_t tile = (size_t)tile_rows * TS * 8 + TS * 8;  // u tile + its 16 logden values
-    g.lds_bytes = (size_t)4 * 2 * tile + EXP_TABLE_BYTES;
+    g.lds_bytes = (size_t)4 * (tile_rows > 128 ? 1 : 2) * tile + EXP_TABLE_BYTES;  // (192-row tiles: one buffer per wave)
     if (diag && tile_rows == 128 && nb8_variant == 2) {
         g.variant = 2;
     } else if (diag && tile_rows == 128) {
@@ -1787,9 +1804,12 @@ hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g
     }
 }
 
-hipError_t launch_gram_off(hipStream_t s, bool dma, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+hipError_t launch_gram_off(hipStream_t s, int nbj, bool dma, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                            const double* ai, const double* aj, const double* logden, int64_t ri, int64_t rj,
                            double* gp) {
+    if (nbj == 8)  // 64 x 128 rectangle: 32 blocks, pinned accumulator classes, one 192-row tile buffer per wave
+        return dma ? launch_gram_t<4, 8, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr)
+                   : launch_gram_t<4, 8, false, false>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
     return dma ? launch_gram_t<4, 4, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr)
                : launch_gram_t<4, 4, false, false>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
 }
