@@ -154,7 +154,7 @@ struct ScopedTimer {
     }
     ~ScopedTimer() {
         if (on) {
-            hipEventRecord(tp.b, c->stream);
+            (void)hipEventRecord(tp.b, c->stream);
             c->pending.push_back(tp);
         }
     }
@@ -791,26 +791,26 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
 
 void mbar_ctx_destroy(mbar_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     flush_timers(c);
-    for (auto e : c->pool) hipEventDestroy(e);
+    for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->u) hipFree(c->u);
+    if (c->u) (void)hipFree(c->u);
     for (int i = 0; i < 3; ++i)
-        if (c->logden[i]) hipFree(c->logden[i]);
-    if (c->dn) hipFree(c->dn);
-    if (c->cw) hipFree(c->cw);
-    if (c->lden_eff) hipFree(c->lden_eff);
-    if (c->small) hipFree(c->small);
-    if (c->part) hipFree(c->part);
-    if (c->scratch) hipFree(c->scratch);
-    if (c->red) hipFree(c->red);
-    if (c->hred) hipHostFree(c->hred);
-    if (c->lognum_part) hipFree(c->lognum_part);
-    if (c->f_hist) hipFree(c->f_hist);
-    if (c->sci_graph) hipGraphExecDestroy(c->sci_graph);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (c->logden[i]) (void)hipFree(c->logden[i]);
+    if (c->dn) (void)hipFree(c->dn);
+    if (c->cw) (void)hipFree(c->cw);
+    if (c->lden_eff) (void)hipFree(c->lden_eff);
+    if (c->small) (void)hipFree(c->small);
+    if (c->part) (void)hipFree(c->part);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->red) (void)hipFree(c->red);
+    if (c->hred) (void)hipHostFree(c->hred);
+    if (c->lognum_part) (void)hipFree(c->lognum_part);
+    if (c->f_hist) (void)hipFree(c->f_hist);
+    if (c->sci_graph) (void)hipGraphExecDestroy(c->sci_graph);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -1071,13 +1071,13 @@ int mbar_logw(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out) {
         {
             ScopedTimer t(c, MBAR_TIMER_OTHER);
             hipError_t e = launch_logw(c->stream, c->u + k0 * c->ld, c->ld, c->N, nr, d_f(c) + k0, c->logden[0], stage, c->ld);
-            if (e != hipSuccess) { hipFree(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
+            if (e != hipSuccess) { (void)hipFree(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
         }
         hipError_t e = hipMemcpy2DAsync(out_kn + k0 * ld_out, (size_t)ld_out * sizeof(double), stage,
                                         (size_t)c->ld * sizeof(double), (size_t)c->N * sizeof(double), (size_t)nr,
                                         hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { hipFree(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
     }
     flush_timers(c);
     HIPCHK(c, hipFree(stage));
@@ -1373,7 +1373,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
             if (crc) return crc;
             if (ee != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
             ee = hipGraphInstantiate(&c->sci_graph, graph, nullptr, nullptr, 0);
-            hipGraphDestroy(graph);
+            (void)hipGraphDestroy(graph);
             if (ee != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ee));
             c->sci_graph_batch = batch;
             c->sci_graph_sig = sig;
@@ -1454,8 +1454,8 @@ int mbar_mfma_f64_peak(mbar_ctx* c, double* tflops) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, a, b));
-    hipEventDestroy(a);
-    hipEventDestroy(b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
     const double flop = (double)blocks * 4 /*waves*/ * iters * 4 /*mfma*/ * 2048.0;
     *tflops = flop / (ms * 1e-3) * 1e-12;
     return MBAR_OK;

@@ -89,7 +89,7 @@ __device__ __forceinline__ void exp_table_init(char* smem) {
         reinterpret_cast<double*>(smem + EXP2_TABLE_BYTES)[i] = LOG_TABLE[i];
 }
 __device__ __forceinline__ double exp2_table_at(int si) {
-    return *(lds_cdouble*)(uint32_t)((si << 3) & (EXP2_TABLE_BYTES - 8));
+    return *(lds_cdouble*)(uintptr_t)(uint32_t)((si << 3) & (EXP2_TABLE_BYTES - 8));
 }
 __device__ __forceinline__ double exp2_poly(double z) {
     double p = EXP2_POLY[EXP2_DEG];
@@ -115,7 +115,7 @@ __device__ __forceinline__ double log_pos(double s) {
     const double m = __builtin_amdgcn_frexp_mant(s);
     const double ed = (double)__builtin_amdgcn_frexp_exp(s);
     const uint32_t off = (uint32_t)(__double2hiint(m) >> 9) & 0x7f0u;
-    const v2d tc = *(__attribute__((address_space(3))) const v2d*)(uint32_t)(EXP2_TABLE_BYTES + off);
+    const v2d tc = *(__attribute__((address_space(3))) const v2d*)(uintptr_t)(uint32_t)(EXP2_TABLE_BYTES + off);
     const double r = fma(m, tc.x, -1.0);
     double q = -1.0 / 6.0;
     q = fma(q, r, 0.2);
@@ -322,7 +322,7 @@ __device__ __forceinline__ void lse_math2(double (&x0)[NB], double (&x1)[NB], co
     }
 }
 template <int NB, int NF>
-__device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl, int rd0, int rd1,
+__device__ __forceinline__ void lse_two_groups(const char* cbuf, int rd0, int rd1,
                                                const double (&a)[NB], const double (&c)[NB], double (&acc)[NF][NB],
                                                double w0, double w1, double& m2_0, double& m2_1,
                                                double (&s0)[NF], double (&s1)[NF]) {
@@ -333,7 +333,7 @@ __device__ __forceinline__ void lse_two_groups(const char* cbuf, const char* tbl
 
 // Single-group version for wide panels (NB > 8), where two groups in flight would spill registers.
 template <int NB, int NF>
-__device__ __forceinline__ void lse_one_group(const char* cbuf, const char* tbl, int rd0, const double (&a)[NB],
+__device__ __forceinline__ void lse_one_group(const char* cbuf, int rd0, const double (&a)[NB],
                                               const double (&c)[NB], double (&acc)[NF][NB], double w0, double& m2_0,
                                               double (&s0)[NF]) {
     double x0[NB];
@@ -353,7 +353,7 @@ __device__ __forceinline__ void lse_one_group(const char* cbuf, const char* tbl,
 }
 // Two consecutive groups g, g+1 of a tile; (mm, ss[]) capture the (shift, sums) of the sample this lane will write.
 template <int NB, int NF>
-__device__ __forceinline__ void lse_group_pair(const char* cbuf, const char* wslot, const char* tbl, int rd_base,
+__device__ __forceinline__ void lse_group_pair(const char* cbuf, const char* wslot, int rd_base,
                                                const int (&pos)[GROUPS], int g, const double (&a)[NB],
                                                const double (&c)[NB], double (&acc)[NF][NB], int ks, int ns,
                                                double& mm, double (&ss)[NF]) {
@@ -362,10 +362,10 @@ __device__ __forceinline__ void lse_group_pair(const char* cbuf, const char* wsl
     const double va = *reinterpret_cast<const double*>(wslot + (4 * g + ns) * 8);
     const double vb = *reinterpret_cast<const double*>(wslot + (4 * (g + 1) + ns) * 8);
     if constexpr (NB <= 8) {
-        lse_two_groups<NB, NF>(cbuf, tbl, rd_base + pos[g], rd_base + pos[g + 1], a, c, acc, va, vb, m2a, m2b, sa, sb);
+        lse_two_groups<NB, NF>(cbuf, rd_base + pos[g], rd_base + pos[g + 1], a, c, acc, va, vb, m2a, m2b, sa, sb);
     } else {
-        lse_one_group<NB, NF>(cbuf, tbl, rd_base + pos[g], a, c, acc, va, m2a, sa);
-        lse_one_group<NB, NF>(cbuf, tbl, rd_base + pos[g + 1], a, c, acc, vb, m2b, sb);
+        lse_one_group<NB, NF>(cbuf, rd_base + pos[g], a, c, acc, va, m2a, sa);
+        lse_one_group<NB, NF>(cbuf, rd_base + pos[g + 1], a, c, acc, vb, m2b, sb);
     }
     if ((ks & 3) == g) {
         mm = m2a;
@@ -497,7 +497,6 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
     const int ks = lane & 15, ns = lane >> 4;
-    char* tbl = smem;  // exp table in the first 256 bytes, tiles behind it
     exp_table_init(smem);
     __syncthreads();
     char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
@@ -566,7 +565,7 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         for (int f = 0; f < NF; ++f) ss[f] = 1.0;
 #pragma unroll
         for (int g = 0; g < GROUPS; g += 2)
-            lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, tbl, rd_base, pos, g, a, c, acc, ks, ns, mm, ss);
+            lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, rd_base, pos, g, a, c, acc, ks, ns, mm, ss);
         // lanes with (ks & 3) == g hold (shift, sums) of sample 4 g + ns: one log per candidate per tile
         {
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
@@ -746,7 +745,6 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
     constexpr int TILE_BYTES = U_BYTES + TS * 8;
     constexpr int G0 = 2 * HALF;
     const int ks = lane & 15, ns = lane >> 4;
-    const char* tbl = smem;  // initialised by the kernel prologue
     char* buf = smem + EXP_TABLE_BYTES + stream * (2 * TILE_BYTES);
     const int64_t gs = (int64_t)blockIdx.x * STREAMS + stream;
     const int64_t S = (int64_t)gridDim.x * STREAMS;
@@ -794,7 +792,7 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
             double mm = 0.0, ss[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) ss[f] = 1.0;
-            lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, tbl, rd_base, pos, G0, a, c, acc, ks, ns, mm, ss);
+            lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, rd_base, pos, G0, a, c, acc, ks, ns, mm, ss);
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
             const bool mine = ((ks & 3) >= G0) && ((ks & 3) < G0 + 2) && (n < N);
             const double wn = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * (ks & 3) + ns) * 8);
@@ -870,7 +868,6 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
     const int ks = lane & 15, ns = lane >> 4;
-    char* tbl = smem;
     exp_table_init(smem);
     __syncthreads();
     char* buf = smem + EXP_TABLE_BYTES + wave * (NBUF * TILE_BYTES);
@@ -1026,12 +1023,10 @@ __device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int
     constexpr int ROWS = NB * 16;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + TS * 8;
-    constexpr int NDMA = ROWS / 8;
     constexpr int NBLK = NB * (NB + 1) / 2;
     constexpr int NMINE = HALF == 0 ? (NBLK + 1) / 2 : NBLK / 2;  // blocks b with (b & 1) == HALF
     constexpr int STREAMS = 4;
     const int ks = lane & 15, ns = lane >> 4;
-    const char* tbl = smem;
     char* buf = smem + EXP_TABLE_BYTES + stream * (2 * TILE_BYTES);
     const int64_t gs = (int64_t)blockIdx.x * STREAMS + stream;   // global stream id = partial record
     const int64_t S = (int64_t)gridDim.x * STREAMS;
@@ -1137,13 +1132,11 @@ __device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int
     constexpr int L_BYTES = TS * 8;
     constexpr int P_BYTES = GROUPS * NB * 64 * 8;
     constexpr int STREAM_BYTES = U_BYTES + L_BYTES + P_BYTES;
-    constexpr int NDMA = ROWS / 8;
     constexpr int NBLK = NB * (NB + 1) / 2;
     constexpr int NMINE = HALF == 0 ? (NBLK + 1) / 2 : NBLK / 2;
     constexpr int STREAMS = 4;
     constexpr int G0 = 2 * HALF, P0 = 2 * (1 - HALF);  // own groups G0, G0+1; partner's P0, P0+1
     const int ks = lane & 15, ns = lane >> 4;
-    const char* tbl = smem;
     char* ubuf = smem + EXP_TABLE_BYTES + stream * STREAM_BYTES;
     char* lbuf = ubuf + U_BYTES;
     char* pbuf = lbuf + L_BYTES;
