@@ -98,7 +98,7 @@ struct mbar_ctx {
     int64_t sci_graph_batch = 0, sci_graph_sig = 0;
     double sci_graph_tol = 0.0;
     // options
-    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1;
+    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1, opt_small = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
     // comm
     ncclComm_t comm = nullptr;
@@ -281,7 +281,11 @@ int agree_with_rank0(mbar_ctx* c, double* v, int64_t count) {
 bool wide_pitch(const mbar_ctx* c) { return (uint64_t)c->ld * 56u + 128u >= (1ull << 32); }
 int lse_variant_for(const mbar_ctx* c) {
     if (wide_pitch(c)) return 1;
-    return (c->opt_lse_variant >= 2 && c->opt_staging != 0) ? 1 : (int)c->opt_lse_variant;
+    int v = (c->opt_lse_variant >= 2 && c->opt_staging != 0) ? 1 : (int)c->opt_lse_variant;
+    // bit 4: the context qualifies for the few-state kernel (one sample per lane, 64-sample tiles); lse_geometry
+    // takes it for single-candidate sweeps of up to 32 states
+    if (c->opt_small && c->opt_staging == 0 && c->Kp <= 32 && c->ld % 64 == 0) v |= 0x10;
+    return v;
 }
 int gram_variant_for(const mbar_ctx* c) { return wide_pitch(c) ? 2 : (int)c->opt_gram_variant; }
 bool use_fast(const mbar_ctx* c) { return c->K <= MAX_FAST_K && !c->opt_force_generic; }
@@ -745,7 +749,8 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
     c->K = K;
     c->Kp = padded_K(K);
     c->N = N_local;
-    c->ld = (N_local + TS - 1) / TS * TS;
+    // row pitch: whole 16-sample tiles; whole 64-sample tiles where the few-state evaluation kernel may run (K <= 32)
+    c->ld = c->Kp <= 32 ? (N_local + 63) / 64 * 64 : (N_local + TS - 1) / TS * TS;
 #define CRT(expr)                                                                                   \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \
@@ -826,6 +831,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     if (k == "staging") c->opt_staging = value;
     else if (k == "grid_blocks") c->opt_grid = value;
     else if (k == "force_generic") c->opt_force_generic = value;
+    else if (k == "small_k_kernel") c->opt_small = value;
     else if (k == "check_finite") c->opt_check_finite = value;
     else if (k == "timing") c->opt_timing = value;
     else if (k == "graph") c->opt_graph = value;

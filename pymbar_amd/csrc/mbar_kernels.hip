@@ -283,10 +283,18 @@ __device__ __forceinline__ void objective_out(double objl, int ks, int lane, dou
 template <int NB>
 __device__ __forceinline__ void lse_load2(const char* cbuf, int rd0, int rd1, const double (&a)[NB],
                                           double (&x0)[NB], double (&x1)[NB]) {
+    // all 2 NB reads are issued before the first use: left to itself hipcc interleaves the subtractions with the reads in
+    // three batches, and every batch ends in an s_waitcnt that exposes a full LDS round trip to the lone wave
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
-        x0[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
-        x1[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd1);
+        x0[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
+        x1[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        x0[I] = a[I] - x0[I];
+        x1[I] = a[I] - x1[I];
     }
 }
 template <int NB, int NF, bool SPLIT = false>
@@ -726,6 +734,105 @@ k_lse_early(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         }
     }
     objective_out<NF>(objl, ks, lane, obj_part, gw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass for few states (K <= 32, one candidate): one SAMPLE per lane, all states of that sample in the
+// lane's registers.  In the MFMA operand layout of the other kernels a sample's states are spread over 16 lanes, so
+// every max / sum over states costs a 4-step DPP butterfly per 4-sample group; with 16-32 states that is more than
+// half of the instruction stream (and the matrix cores are not used by this pass anyway).  Here the reductions
+// over states are in-register trees and the only cross-lane work is one reduction of the per-state accumulators at
+// the end of the kernel.  A tile is 64 consecutive samples x all state rows (512 contiguous bytes per row, LDS row
+// k = bytes [512 k, 512 k + 512): the column read of lane n is conflict-free); each LDS-DMA instruction moves two
+// rows.  The tile is read into registers in one go, so its single buffer is refilled immediately (two waves per
+// SIMD, 8 per workgroup).  Requires a row pitch that is a multiple of 64 (mbar_ctx_create pads it for K <= 32).
+// ---------------------------------------------------------------------------------------------
+constexpr int TSS = 64;  // samples per tile of the small-K kernel
+template <int NB>
+__global__ void __launch_bounds__(512, 2)
+k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+            const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+            const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TSS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TSS * 8;  // + the 64 sample weights of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    exp_table_init(smem);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * TILE_BYTES;
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const bool has_store = logden0 != nullptr;
+    // DMA instruction j moves rows 2j, 2j+1: lane l -> row 2j + (l >> 5), bytes [16 (l & 31), +16) of its 512
+    const uint32_t voff = (uint32_t)(((int64_t)(lane >> 5) * ld + 2 * (lane & 31)) * 8);
+
+    double a[ROWS], acc[ROWS], objl = 0.0;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        a[k] = aden[k];
+        acc[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) settle(a[k]);
+
+    auto stage = [&](int64_t tile) {
+#pragma unroll
+        for (int j = 0; j < ROWS / 2; ++j) stage_piece<true>(u + (int64_t)(2 * j) * ld + tile * TSS, voff, buf + j * 1024, lane);
+        if (lane < 32) stage_piece<true>(cw + tile * TSS, (uint32_t)(lane * 16), buf + U_BYTES, lane);
+    };
+
+    int64_t t = gw;
+    if (t < ntiles) stage(t);
+    for (; t < ntiles; t += W) {
+        if (has_store && t != gw)
+            wait_vm<1>();  // [this tile][logden store of the previous one]: vmcnt counts stores too
+        else
+            wait_vm<0>();
+        double x[ROWS];
+        const double w = *reinterpret_cast<const double*>(buf + U_BYTES + lane * 8);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) x[k] = *reinterpret_cast<const double*>(buf + k * (TSS * 8) + lane * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is in registers: refill its buffer
+        if (t + W < ntiles) stage(t + W);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) x[k] = a[k] - x[k];
+        const double m = tree_max<ROWS>(x);
+        const double m2 = m * LOG2E_S;
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) x[k] = fma(x[k], LOG2E_S, -m2);
+#pragma unroll
+        for (int k0 = 0; k0 < ROWS; k0 += 8) {
+            double e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = x[k0 + i];
+            exp2s_batch<8>(e);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[k0 + i] = e[i];
+        }
+        const double ssum = tree_sum<ROWS>(x);
+        const double r = w * recip_fast(ssum);  // w: sample multiplicity (0 on the padding)
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) acc[k] = fma(x[k], r, acc[k]);
+        const double ldv = m + log_pos(ssum);
+        const int64_t n = t * TSS + lane;
+        if (n < N) {
+            if (logden0) logden0[n] = ldv;
+            objl = fma(w, dn ? (ldv - dn[n]) : ldv, objl);
+        }
+    }
+    // per-wave partial sums (one record of ROWS doubles per wave, like the other evaluation kernels)
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) psum_part[gw * ROWS + k] = v;
+    }
+    const double o = wave_sum(objl);
+    if (lane == 0) obj_part[gw] = o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1557,7 +1664,24 @@ static int blocks_per_cu_for(size_t lds_bytes) {
 LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant) {
     LaunchGeom g;
     const size_t tile = (size_t)nb * 16 * TS * 8 + TS * 8;  // u tile + its 16 sample weights
+    const bool small_ok = (variant & 0x10) != 0;  // set by the caller when the context qualifies (pitch, staging)
+    variant &= 0xf;
     g.variant = (nb >= 6 && variant == 0 && !(nb > 8 && nf == 2)) ? 0 : 1;  // (wide two-candidate pairs would spill)
+    if (small_ok && nf == 1 && nb <= 2) {  // few states (a third block of 16 would spill the per-lane state arrays): one sample per lane, 64-sample tiles, 8 waves x 1 buffer
+        g.variant = 4;
+        g.waves = 8;
+        const size_t tile64 = (size_t)nb * 16 * TSS * 8 + TSS * 8;
+        g.lds_bytes = (size_t)g.waves * tile64 + EXP_TABLE_BYTES;
+        const int64_t nt64 = (ntiles * TS + TSS - 1) / TSS;
+        int64_t want = (nt64 + g.waves - 1) / g.waves;
+        int64_t cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+        if (grid_override > 0) cap = grid_override;
+        if (want < 1) want = 1;
+        g.blocks = (int)(want < cap ? want : cap);
+        g.nwaves = g.blocks * g.waves;
+        g.psum_records = g.nwaves;
+        return g;
+    }
     if (variant >= 2 && nb >= 5 && nb <= 8) g.variant = variant == 2 ? 2 : 3;
     int64_t cap;
     if (g.variant >= 2) {  // early refill: 8 waves x 1 tile buffer (2) or 4 waves x 2 buffers (3)
@@ -1712,9 +1836,33 @@ static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeo
                : launch_lse_t<NB, 2, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
 }
 
+template <int NB>
+static hipError_t launch_lse_small_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                     const double* aden, const double* cw, double* l0, const double* dn,
+                                     double* psum_part, double* obj_part) {
+    auto kern = k_lse_small<NB>;
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TSS - 1) / TSS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0, dn,
+                       psum_part, obj_part);
+    return hipGetLastError();
+}
+
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,
                       int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
                       const double* dn, double* pp, double* op) {
+    if (g.variant == 4) {  // (geometry chose the few-state kernel: nf == 1, nb <= 3, LDS-DMA staging, pitch % 64 == 0)
+        if (nf != 1 || !dma || (ld % TSS) != 0) return hipErrorInvalidValue;
+        switch (nb) {
+            case 1: return launch_lse_small_t<1>(s, g, u, ld, N, aden, cw, l0, dn, pp, op);
+            case 2: return launch_lse_small_t<2>(s, g, u, ld, N, aden, cw, l0, dn, pp, op);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (nb) {
 #define MBAR_CASE(NB_) \
     case NB_: return launch_lse_nb<NB_>(s, nf, dma, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
