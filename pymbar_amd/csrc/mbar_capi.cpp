@@ -1335,7 +1335,11 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
             }
             const double* upd_src = psum_part;
             int64_t upd_n = g.nwaves;
-            if (g.nwaves > 64) {
+            // the update kernel sums the partial records itself, 256 / KW of them in parallel per state (KW = states
+            // rounded up to a power of two): worth it up to ~32 sequential adds per thread, a level-1 reduction otherwise
+            int64_t kw2 = 1;
+            while (kw2 < std::min<int64_t>(rows, 256)) kw2 <<= 1;
+            if ((int64_t)g.nwaves * kw2 > 8192) {
                 HIPCHK(c, launch_reduce_level1(c->stream, psum_part, g.nwaves, rows, c->scratch, &upd_n));
                 upd_src = c->scratch;
             }

@@ -736,6 +736,85 @@ k_lse_early(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     objective_out<NF>(objl, ks, lane, obj_part, gw);
 }
 
+// SCI step on the reduced per-state sums, executed by (at least) 256 threads of ONE workgroup; threads >= 256 only
+// take part in the barriers.  part: nparts records of `rows` doubles.  psum: Kp + 256 doubles of LDS, red: 5.
+//   f_k <- f_k - log(psum_k / N_k), gauge f_first = 0, aden_k = f_k + ln N_k, delta = max relative change (:627-633)
+struct SciArgs {
+    const double* Nk;
+    const double* lnNk;
+    int64_t K, Kp;
+    int first;
+    double tol;
+    double* f;
+    double* aden;
+    double* f_hist;
+    double* delta_out;
+};
+__device__ __forceinline__ void sci_update_block(const double* part, int64_t nparts, int64_t rows, const SciArgs& q,
+                                                 double* psum, double* red) {
+    const int tid = threadIdx.x;
+    const bool act = tid < 256;
+    double* scr = psum + q.Kp;
+    const int64_t Kp = q.Kp, K = q.K;
+    // all 256 threads share the partial-record sum: thread (g, kk) adds records g, g + G, ... of state kk
+    for (int64_t k0 = 0; k0 < Kp; k0 += 256) {
+        const int64_t kw = Kp - k0 < 256 ? Kp - k0 : 256;   // states in this pass
+        int KW = 1;
+        while (KW < kw) KW <<= 1;                            // power of two >= kw, <= 256
+        const int G = 256 / KW, g = tid / KW, kk = tid % KW;
+        if (act) {
+            double sm = 0.0;
+            if (kk < kw)
+                for (int64_t p = g; p < nparts; p += G) sm += part[p * rows + k0 + kk];
+            scr[tid] = sm;
+        }
+        __syncthreads();
+        if (tid < kw) {
+            double tot = 0.0;
+            for (int gg = 0; gg < G; ++gg) tot += scr[gg * KW + tid];
+            psum[k0 + tid] = tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) red[4] = q.f[q.first] - log(psum[q.first] / q.Nk[q.first]);
+    __syncthreads();
+    const double f0new = red[4];
+    double dmax = 0.0;
+    const double small = q.tol < 1e-8 ? q.tol : 1e-8;
+    if (act)
+        for (int64_t k = tid; k < Kp; k += 256) {
+            if (k < K && q.Nk[k] > 0.0) {
+                const double fo = q.f[k];
+                const double fn = fo - log(psum[k] / q.Nk[k]) - f0new;
+                q.f[k] = fn;
+                q.f_hist[k] = fn;
+                q.aden[k] = fn + q.lnNk[k];
+                if (k != q.first) {
+                    const double div = fabs(fn) < small ? 1.0 : fabs(fn);
+                    const double d = fabs(fn - fo) / div;
+                    dmax = (d > dmax || d != d) ? d : dmax;  // propagate NaN
+                }
+            } else {
+                q.aden[k] = -INFINITY;
+                q.f_hist[k] = k < K ? q.f[k] : 0.0;
+            }
+        }
+    // NaN-propagating max
+    double m = dmax;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        const double o = __shfl_xor(m, sft);
+        m = (o > m || o != o) ? o : m;
+    }
+    if (act && (tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        double r = red[0];
+        for (int w = 1; w < 4; ++w) r = (red[w] > r || red[w] != red[w]) ? red[w] : r;
+        *q.delta_out = r;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Evaluation pass for few states (K <= 32, one candidate): one SAMPLE per lane, all states of that sample in the
 // lane's registers.  In the MFMA operand layout of the other kernels a sample's states are spread over 16 lanes, so
@@ -825,14 +904,26 @@ k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             objl = fma(w, dn ? (ldv - dn[n]) : ldv, objl);
         }
     }
-    // per-wave partial sums (one record of ROWS doubles per wave, like the other evaluation kernels)
+    // one partial record per WORKGROUP (the 8 waves are folded through LDS in a fixed order): few enough records for
+    // the SCI update kernel to sum directly, which saves the level-1 reduction launch of the device-resident loop
+    __syncthreads();  // every wave is done with its tile buffer: re-use the LDS behind the tables
+    double* fold = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const double v = wave_sum(acc[k]);
-        if (lane == 0) psum_part[gw * ROWS + k] = v;
+        if (lane == 0) fold[wave * (ROWS + 1) + k] = v;
     }
     const double o = wave_sum(objl);
-    if (lane == 0) obj_part[gw] = o;
+    if (lane == 0) fold[wave * (ROWS + 1) + ROWS] = o;
+    __syncthreads();
+    if (threadIdx.x <= ROWS) {
+        double tot = 0.0;
+        for (int w = 0; w < nwv; ++w) tot += fold[w * (ROWS + 1) + threadIdx.x];
+        if (threadIdx.x < ROWS)
+            psum_part[(int64_t)blockIdx.x * ROWS + threadIdx.x] = tot;
+        else
+            obj_part[blockIdx.x] = tot;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1572,66 +1663,10 @@ k_generate_harmonic(double* __restrict__ u, int64_t ld, int64_t N, int64_t K, ui
 // (mbar_solvers.py:231-242 via s_k), gauge f'[first] = 0 (:588), relative change (:627-631).  The new f is also
 // written to `f_hist` (the host picks the accepted iterate after a batch).
 __global__ void __launch_bounds__(256)
-k_sci_update(const double* __restrict__ part, int64_t nparts, int64_t rows, const double* __restrict__ Nk,
-             const double* __restrict__ lnNk, int64_t K, int64_t Kp, int first, double tol, double* __restrict__ f,
-             double* __restrict__ aden, double* __restrict__ f_hist, double* __restrict__ delta_out) {
-    __shared__ double red[4];
-    __shared__ double f0new;
+k_sci_update(const double* __restrict__ part, int64_t nparts, int64_t rows, SciArgs q) {
+    __shared__ double red[5];
     extern __shared__ double psum[];  // Kp doubles, then 256 doubles of scratch
-    double* scr = psum + Kp;
-    // all 256 threads share the partial-record sum: thread (g, kk) adds records g, g + G, ... of state kk
-    for (int64_t k0 = 0; k0 < Kp; k0 += 256) {
-        const int64_t kw = Kp - k0 < 256 ? Kp - k0 : 256;   // states in this pass
-        int KW = 1;
-        while (KW < kw) KW <<= 1;                            // power of two >= kw, <= 256
-        const int G = 256 / KW, g = threadIdx.x / KW, kk = threadIdx.x % KW;
-        double sm = 0.0;
-        if (kk < kw)
-            for (int64_t p = g; p < nparts; p += G) sm += part[p * rows + k0 + kk];
-        scr[threadIdx.x] = sm;
-        __syncthreads();
-        if (threadIdx.x < kw) {
-            double tot = 0.0;
-            for (int gg = 0; gg < G; ++gg) tot += scr[gg * KW + threadIdx.x];
-            psum[k0 + threadIdx.x] = tot;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) f0new = f[first] - log(psum[first] / Nk[first]);
-    __syncthreads();
-    double dmax = 0.0;
-    const double small = tol < 1e-8 ? tol : 1e-8;
-    for (int64_t k = threadIdx.x; k < Kp; k += blockDim.x) {
-        if (k < K && Nk[k] > 0.0) {
-            const double fo = f[k];
-            const double fn = fo - log(psum[k] / Nk[k]) - f0new;
-            f[k] = fn;
-            f_hist[k] = fn;
-            aden[k] = fn + lnNk[k];
-            if (k != first) {
-                const double div = fabs(fn) < small ? 1.0 : fabs(fn);
-                const double d = fabs(fn - fo) / div;
-                dmax = (d > dmax || d != d) ? d : dmax;  // propagate NaN
-            }
-        } else {
-            aden[k] = -INFINITY;
-            f_hist[k] = k < K ? f[k] : 0.0;
-        }
-    }
-    // NaN-propagating max
-    double m = dmax;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const double o = __shfl_xor(m, s);
-        m = (o > m || o != o) ? o : m;
-    }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double r = red[0];
-        for (int w = 1; w < 4; ++w) r = (red[w] > r || red[w] != red[w]) ? red[w] : r;
-        *delta_out = r;
-    }
+    sci_update_block(part, nparts, rows, q, psum, red);
 }
 
 // fp64 MFMA peak probe: 4 independent accumulators per wave, nothing else in the loop
@@ -1678,7 +1713,7 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
         if (grid_override > 0) cap = grid_override;
         if (want < 1) want = 1;
         g.blocks = (int)(want < cap ? want : cap);
-        g.nwaves = g.blocks * g.waves;
+        g.nwaves = g.blocks;  // partial records: this kernel folds its 8 waves and writes one per workgroup
         g.psum_records = g.nwaves;
         return g;
     }
@@ -2051,8 +2086,8 @@ hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_
 hipError_t launch_sci_update(hipStream_t s, const double* part, int64_t nparts, int64_t rows, const double* Nk,
                              const double* lnNk, int64_t K, int64_t Kp, int first_state, double tol, double* f,
                              double* aden, double* f_hist, double* delta_out) {
-    hipLaunchKernelGGL(k_sci_update, dim3(1), dim3(256), (size_t)(Kp + 256) * sizeof(double), s, part, nparts, rows, Nk, lnNk, K,
-                       Kp, first_state, tol, f, aden, f_hist, delta_out);
+    const SciArgs q{Nk, lnNk, K, Kp, first_state, tol, f, aden, f_hist, delta_out};
+    hipLaunchKernelGGL(k_sci_update, dim3(1), dim3(256), (size_t)(Kp + 256) * sizeof(double), s, part, nparts, rows, q);
     return hipGetLastError();
 }
 
