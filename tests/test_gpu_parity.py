@@ -481,6 +481,29 @@ def test_wide_row_pitch_matches_sum_of_shards(DM, K):
     assert abs(pw[0].sum() - N) < 1e-6 * N ** 0.5
 
 
+@pytest.mark.parametrize("K,N", [(128, 300_000), (256, 100_000), (32, 500_000)])
+def test_reduced_outputs_are_bit_reproducible(DM, K, N):
+    """Fixed-order reductions, no atomics: every launch returns the same bits (tools/soak_determinism.py runs the long
+    version).  Also the canary for matrix-core hazards around the hand-pinned MFMA blocks: they show up as noise."""
+    O_k, K_k, N_k = ts.config3_params(K=K, N=N)
+    N_k[-1] += N - N_k.sum()
+    with DM.harmonic(O_k, K_k, N_k, seed=1) as dm:
+        dm.set_Nk(N_k)
+        rng = np.random.default_rng(K)
+        f = ts.harmonic_free_energies(K_k) + 0.05 * rng.normal(size=K)
+        f[0] = 0.0
+        f2 = np.stack([f, f + 0.01 * rng.normal(size=K)])
+        first = None
+        for _ in range(25):
+            psum, sld, G = dm.eval(f2, gram=True)
+            cur = (psum.tobytes(), sld.tobytes(), G.tobytes(), dm.lognum(f).tobytes())
+            first = first or cur
+            assert cur == first
+        a, ra = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+        b, rb = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+        assert np.array_equal(a, b) and ra["iterations"] == rb["iterations"]
+
+
 def test_rccl_communicator_single_rank(DM):
     """RCCL path end to end on one GPU: dlopen librccl, ncclGetUniqueId, ncclCommInitRank(nranks=1), and every
     reduced output going through ncclAllReduce on the compute stream.  (More ranks need more GPUs; the decomposition
