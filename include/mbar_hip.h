@@ -64,8 +64,17 @@ int mbar_device_info(int device, char* name, int name_len, int* compute_units, i
 int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local);
 void mbar_ctx_destroy(mbar_ctx* ctx);
 int mbar_ctx_synchronize(mbar_ctx* ctx);
-/* Tuning / test knobs: "staging" (0 = LDS-DMA, 1 = through registers), "grid_blocks" (0 = auto),
- * "force_generic" (1 = use the layout-agnostic fallback kernels), "check_finite" (default 1). */
+/* Tuning / test knobs (defaults are the measured best; every variant is parity-tested):
+ *   "staging"        0 = LDS-DMA tiles (default), 1 = through registers
+ *   "grid_blocks"    0 = auto
+ *   "force_generic"  1 = layout-agnostic fallback kernels for any K
+ *   "check_finite"   default 1
+ *   "lse_variant"    evaluation sweep for 5-8 blocks of 16 states: 1 = one tile stream per wave (default),
+ *                    0 = paired waves, 2 / 3 = early refill with one / two tile buffers
+ *   "gram_variant"   full 128-state Gram panel: 2 = one wave per SIMD, pinned accumulator classes (default),
+ *                    0 = operand exchange between paired waves, 1 = paired waves, duplicate operands
+ *   "small_k_kernel" 1 = one-sample-per-lane sweep for K <= 32, single candidate (default), 0 = off
+ *   "graph", "sci_batch", "timing"   hipGraph batching of the SCI loop; HIP-event timers (mbar_ctx_timing) */
 int mbar_ctx_set_option(mbar_ctx* ctx, const char* key, int64_t value);
 
 /* ---- data ---------------------------------------------------------------------------------- */

@@ -102,6 +102,10 @@ int main() {
     run<1, 4>(u, ld, ntiles, sink, cus, "tile-major tiles (16 KB blocks)");
     for (int delay : {20, 40, 60, 80, 100, 120})  // 64-clock units: 100 = 6400 clocks = 3 us of "compute" per tile
         run<0, 4>(u, ld, ntiles, sink, cus, "row-major + per-tile delay", delay);
+    for (int delay : {80, 90, 100, 110})
+        run<1, 4>(u, ld, ntiles, sink, cus, "tile-major + per-tile delay", delay);
+    for (int delay : {90, 100, 110})
+        run<0, 4>(u, ld, ntiles, sink, cus, "row-major + per-tile delay", delay);
     run<0, 2>(u, ld, ntiles, sink, 2 * cus, "row-major tiles (128 x 128 B)");
     run<1, 2>(u, ld, ntiles, sink, 2 * cus, "tile-major tiles (16 KB blocks)");
     hipEvent_t e0, e1;
