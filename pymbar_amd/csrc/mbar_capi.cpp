@@ -1148,7 +1148,7 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     bool done = false;
     const GramPlan plan = gram_plan(c->Kp);
     const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
-    double tA = 0, tH = 0, tB = 0, tC = 0;
+    double tA = 0, tH = 0, tB = 0;
     for (int64_t it = 0; it < maxiter && !done; ++it) {
         // ---- pass A: Gram at f with the known logden -> Hessian (mbar_solvers.py:581) ----
         const double t_a0 = now_ms();
@@ -1263,7 +1263,6 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
         std::fprintf(stderr, "[mbar] adaptive: %lld it, per it: passA %.3f ms, host solve %.3f ms, passB %.3f ms, total %.3f ms\n",
                      (long long)res.iterations, tA / res.iterations, tH / res.iterations, tB / res.iterations,
                      res.wall_ms / res.iterations);
-    (void)tC;
     std::copy(f.begin(), f.end(), f_inout);
     if (result) *result = res;
     return MBAR_OK;
