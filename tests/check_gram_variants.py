@@ -1,4 +1,4 @@
-"""GPU check: the three NB = 8 Gram kernels (operand exchange, paired, single wave with pinned accumulator classes)
+"""GPU check (stand-alone script; lives under tests/ because it uses the oracle): the three NB = 8 Gram kernels (operand exchange, paired, single wave with pinned accumulator classes)
 must agree with each other to round-off and with the oracle on a small K = 128 problem."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
