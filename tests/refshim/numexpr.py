@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-__version__ = "0.0-stub"
+__version__ = "2.8.4"  # (pandas parses the version of an optional numexpr)
 
 
 def evaluate(expr, local_dict=None, global_dict=None, **kwargs):

@@ -1,6 +1,7 @@
 """Run the REFERENCE'S OWN test files against this repository's drop-in.
 
-``/root/reference/pymbar/tests/test_mbar.py`` and ``test_mbar_solvers.py`` are executed in place (nothing is copied) in
+``/root/reference/pymbar/tests/test_mbar.py``, ``test_mbar_solvers.py``, ``test_fes.py`` (the free-energy-surface class
+builds its ``pymbar.MBAR`` internally and consumes its weights) are executed in place (nothing is copied) in
 a subprocess whose ``pymbar.MBAR`` and ``pymbar.mbar_solvers`` are replaced by ``pymbar_amd.MBAR`` /
 ``pymbar_amd.mbar_solvers`` (tests/refshim/refshim_plugin.py); the device is the CPU stand-in, so this checks the
 boundary -- names, argument meaning, return types, exception classes, and the numbers the reference's tests assert
@@ -20,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pymbar", "tests")), reason="reference tree not mounted")
-@pytest.mark.parametrize("test_file,min_passed", [("test_mbar.py", 60), ("test_mbar_solvers.py", 34)])
+@pytest.mark.parametrize("test_file,min_passed", [("test_mbar.py", 60), ("test_mbar_solvers.py", 34), ("test_fes.py", 12)])
 def test_reference_tests_pass_on_the_drop_in(test_file, min_passed):
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests", "refshim"), REF, ROOT])
