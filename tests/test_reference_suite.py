@@ -33,3 +33,16 @@ def test_reference_tests_pass_on_the_drop_in(test_file, min_passed):
     m = re.search(r"(\d+) passed", tail)
     assert m and int(m.group(1)) >= min_passed, tail
     assert not re.search(r"\d+ (failed|error)", tail.splitlines()[-1])
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "examples", "harmonic-oscillators")), reason="reference tree not mounted")
+def test_reference_example_runs_on_the_drop_in(tmp_path):
+    """examples/harmonic-oscillators/harmonic-oscillators.py (1000 lines: free energies with every uncertainty method,
+    expectations, perturbed free energies, entropy / enthalpy, overlap, 1-D and 2-D free energy surfaces) runs to
+    completion with the MBAR class and solver module swapped for this repository's."""
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    script = os.path.join(REF, "examples", "harmonic-oscillators", "harmonic-oscillators.py")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "refshim", "run_example.py"), script], env=env,
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "Traceback" not in out.stderr
