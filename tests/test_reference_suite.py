@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pymbar", "tests")), reason="reference tree not mounted")
 @pytest.mark.parametrize("test_file,min_passed", [("test_mbar.py", 60), ("test_mbar_solvers.py", 34), ("test_fes.py", 12)])
 def test_reference_tests_pass_on_the_drop_in(test_file, min_passed):
-    env = dict(os.environ)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")  # nothing may be written into the reference tree
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests", "refshim"), REF, ROOT])
     cmd = [sys.executable, "-m", "pytest", os.path.join(REF, "pymbar", "tests", test_file), "-p", "refshim_plugin",
            "-p", "no:cacheprovider", "-q", "--rootdir=/tmp", "-c", "/dev/null", "-W", "ignore"]
@@ -40,7 +40,7 @@ def test_reference_example_runs_on_the_drop_in(tmp_path):
     """examples/harmonic-oscillators/harmonic-oscillators.py (1000 lines: free energies with every uncertainty method,
     expectations, perturbed free energies, entropy / enthalpy, overlap, 1-D and 2-D free energy surfaces) runs to
     completion with the MBAR class and solver module swapped for this repository's."""
-    env = dict(os.environ, TMPDIR=str(tmp_path))
+    env = dict(os.environ, TMPDIR=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
     script = os.path.join(REF, "examples", "harmonic-oscillators", "harmonic-oscillators.py")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "refshim", "run_example.py"), script], env=env,
                          cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
