@@ -74,6 +74,7 @@ int mbar_ctx_synchronize(mbar_ctx* ctx);
  *   "gram_variant"   full 128-state Gram panel: 2 = one wave per SIMD, pinned accumulator classes (default),
  *                    0 = operand exchange between paired waves, 1 = paired waves, duplicate operands
  *   "small_k_kernel" 1 = one-sample-per-lane sweep for K <= 32, single candidate (default), 0 = off
+ *   "wide_k_kernel"  1 = single-buffer sweep with four waves per CU for 129 <= K <= 256 (default), 0 = off
  *   "graph", "sci_batch", "timing"   hipGraph batching of the SCI loop; HIP-event timers (mbar_ctx_timing) */
 int mbar_ctx_set_option(mbar_ctx* ctx, const char* key, int64_t value);
 

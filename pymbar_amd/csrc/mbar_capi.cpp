@@ -98,7 +98,7 @@ struct mbar_ctx {
     int64_t sci_graph_batch = 0, sci_graph_sig = 0;
     double sci_graph_tol = 0.0;
     // options
-    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1, opt_small = 1;
+    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
     // comm
     ncclComm_t comm = nullptr;
@@ -285,6 +285,8 @@ int lse_variant_for(const mbar_ctx* c) {
     // bit 4: the context qualifies for the few-state kernel (one sample per lane, 64-sample tiles); lse_geometry
     // takes it for single-candidate sweeps of up to 32 states
     if (c->opt_small && c->opt_staging == 0 && c->Kp <= 32 && c->ld % 64 == 0) v |= 0x10;
+    // bit 5: wide panels (129..256 states) may use the single-buffer kernel (four waves per CU instead of two)
+    if (c->opt_wide && c->opt_staging == 0 && c->Kp > 128) v |= 0x20;
     return v;
 }
 int gram_variant_for(const mbar_ctx* c) { return wide_pitch(c) ? 2 : (int)c->opt_gram_variant; }
@@ -832,6 +834,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "grid_blocks") c->opt_grid = value;
     else if (k == "force_generic") c->opt_force_generic = value;
     else if (k == "small_k_kernel") c->opt_small = value;
+    else if (k == "wide_k_kernel") c->opt_wide = value;
     else if (k == "check_finite") c->opt_check_finite = value;
     else if (k == "timing") c->opt_timing = value;
     else if (k == "graph") c->opt_graph = value;

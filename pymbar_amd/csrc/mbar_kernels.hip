@@ -339,14 +339,18 @@ __device__ __forceinline__ void lse_two_groups(const char* cbuf, int rd0, int rd
     lse_math2<NB, NF>(x0, x1, c, acc, w0, w1, m2_0, m2_1, s0, s1);
 }
 
-// Single-group version for wide panels (NB > 8), where two groups in flight would spill registers.
-template <int NB, int NF>
-__device__ __forceinline__ void lse_one_group(const char* cbuf, int rd0, const double (&a)[NB],
-                                              const double (&c)[NB], double (&acc)[NF][NB], double w0, double& m2_0,
-                                              double (&s0)[NF]) {
-    double x0[NB];
+// Single-group versions for wide panels (NB > 8), where two groups in the exp pipeline at once would spill registers.
+template <int NB>
+__device__ __forceinline__ void lse_load1(const char* cbuf, int rd0, const double (&a)[NB], double (&x0)[NB]) {
 #pragma unroll
-    for (int I = 0; I < NB; ++I) x0[I] = a[I] - *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
+    for (int I = 0; I < NB; ++I) x0[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int I = 0; I < NB; ++I) x0[I] = a[I] - x0[I];
+}
+template <int NB, int NF>
+__device__ __forceinline__ void lse_math1(double (&x0)[NB], const double (&c)[NB], double (&acc)[NF][NB], double w0,
+                                          double& m2_0, double (&s0)[NF]) {
     m2_0 = row16_max(tree_max<NB>(x0)) * LOG2E_S;
 #pragma unroll
     for (int I = 0; I < NB; ++I) x0[I] = fma(x0[I], LOG2E_S, -m2_0);
@@ -358,6 +362,14 @@ __device__ __forceinline__ void lse_one_group(const char* cbuf, int rd0, const d
 #pragma unroll
         for (int I = 0; I < NB; ++I) acc[f][I] = fma(x0[I], r0, acc[f][I]);
     }
+}
+template <int NB, int NF>
+__device__ __forceinline__ void lse_one_group(const char* cbuf, int rd0, const double (&a)[NB],
+                                              const double (&c)[NB], double (&acc)[NF][NB], double w0, double& m2_0,
+                                              double (&s0)[NF]) {
+    double x0[NB];
+    lse_load1<NB>(cbuf, rd0, a, x0);
+    lse_math1<NB, NF>(x0, c, acc, w0, m2_0, s0);
 }
 // Two consecutive groups g, g+1 of a tile; (mm, ss[]) capture the (shift, sums) of the sample this lane will write.
 template <int NB, int NF>
@@ -924,6 +936,119 @@ k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         else
             obj_part[blockIdx.x] = tot;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass for wide panels (129 <= K <= 256: NB = 12 or 16).  A 16-sample tile is 24-33 KB here, so the
+// double-buffered k_lse fits only TWO waves per CU and half the SIMDs idle.  This variant gives every wave ONE tile
+// buffer (four waves per CU): groups 0 and 1 are processed straight from LDS, the operands of groups 2 and 3 are
+// pulled into registers together, and the buffer is refilled at that point -- half a tile period before it is needed.
+// ---------------------------------------------------------------------------------------------
+template <int NB, int NF>
+__global__ void __launch_bounds__(256, 1)
+k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+           const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+           double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
+           double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    exp_table_init(smem);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * TILE_BYTES;
+    const char* wslot = buf + U_BYTES;
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const RowIdentity rows{0};
+    const StageOffsets so = make_stage_offsets(ld, lane);
+    const bool has_store = logden0 != nullptr || logden1 != nullptr;  // one store instruction per tile
+
+    double a[NB], c[NB], acc[NF][NB], objl = 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        a[I] = aden[16 * I + ks];
+        c[I] = NF == 2 ? aden[ROWS + 16 * I + ks] : 1.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        settle(a[I]);
+        if (NF == 2) settle(c[I]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
+    }
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    int64_t t = gw;
+    if (t < ntiles) {
+        stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
+        stage_vec16<true>(cw, t * TS, buf + U_BYTES, lane);
+    }
+    for (; t < ntiles; t += W) {
+        if (has_store && t != gw)
+            wait_vm<1>();  // [this tile][logden store of the previous one]: vmcnt counts stores too
+        else
+            wait_vm<0>();
+        double w[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) w[g] = *reinterpret_cast<const double*>(wslot + (4 * g + ns) * 8);
+        const double wn = *reinterpret_cast<const double*>(wslot + (4 * (ks & 3) + ns) * 8);
+        const int gq = ks & 3;  // this lane keeps (shift, sums) of sample 4 gq + ns for the log below
+        double x0[NB], x1[NB], m2, sg[NF], mm = 0.0, ss[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ss[f] = 1.0;
+        auto keep = [&](int g) {
+            if (gq == g) {
+                mm = m2;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) ss[f] = sg[f];
+            }
+        };
+        lse_load1<NB>(buf, pos[0], a, x0);
+        lse_math1<NB, NF>(x0, c, acc, w[0], m2, sg);
+        keep(0);
+        lse_load1<NB>(buf, pos[1], a, x0);
+        lse_math1<NB, NF>(x0, c, acc, w[1], m2, sg);
+        keep(1);
+        lse_load1<NB>(buf, pos[2], a, x0);
+        lse_load1<NB>(buf, pos[3], a, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS operand of this tile is in registers
+        if (t + W < ntiles) {
+            stage_tile<ROWS, true, 0, 1>(u, ld, (t + W) * TS, buf, lane, so, rows);
+            stage_vec16<true>(cw, (t + W) * TS, buf + U_BYTES, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lse_math1<NB, NF>(x0, c, acc, w[2], m2, sg);
+        keep(2);
+        lse_math1<NB, NF>(x1, c, acc, w[3], m2, sg);
+        keep(3);
+        {
+            const int64_t n = t * TS + 4 * gq + ns;
+            logden_out<NF>(mm, ss, ks, n < N, n, wn, logden0, logden1, dn, objl);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(gw * NF + f) * ROWS + 16 * I + lane] = v;
+        }
+    }
+    objective_out<NF>(objl, ks, lane, obj_part, gw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1700,6 +1825,7 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
     LaunchGeom g;
     const size_t tile = (size_t)nb * 16 * TS * 8 + TS * 8;  // u tile + its 16 sample weights
     const bool small_ok = (variant & 0x10) != 0;  // set by the caller when the context qualifies (pitch, staging)
+    const bool wide_ok = (variant & 0x20) != 0;   // likewise for the single-buffer wide-panel kernel
     variant &= 0xf;
     g.variant = (nb >= 6 && variant == 0 && !(nb > 8 && nf == 2)) ? 0 : 1;  // (wide two-candidate pairs would spill)
     if (small_ok && nf == 1 && nb <= 2) {  // few states (a third block of 16 would spill the per-lane state arrays): one sample per lane, 64-sample tiles, 8 waves x 1 buffer
@@ -1714,6 +1840,19 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
         if (want < 1) want = 1;
         g.blocks = (int)(want < cap ? want : cap);
         g.nwaves = g.blocks;  // partial records: this kernel folds its 8 waves and writes one per workgroup
+        g.psum_records = g.nwaves;
+        return g;
+    }
+    if (wide_ok && nb > 8) {  // 129..256 states: one tile buffer per wave, four waves per CU
+        g.variant = 5;
+        g.waves = 4;
+        g.lds_bytes = (size_t)g.waves * tile + EXP_TABLE_BYTES;
+        int64_t want = (ntiles + g.waves - 1) / g.waves;
+        int64_t cap5 = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+        if (grid_override > 0) cap5 = grid_override;
+        if (want < 1) want = 1;
+        g.blocks = (int)(want < cap5 ? want : cap5);
+        g.nwaves = g.blocks * g.waves;
         g.psum_records = g.nwaves;
         return g;
     }
@@ -1890,6 +2029,23 @@ static hipError_t launch_lse_small_t(hipStream_t s, const LaunchGeom& g, const d
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,
                       int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
                       const double* dn, double* pp, double* op) {
+    if (g.variant == 5) {  // (geometry chose the single-buffer wide-panel kernel: nb = 12 or 16, LDS-DMA staging)
+        if (!dma) return hipErrorInvalidValue;
+        auto go = [&](auto kern) -> hipError_t {
+            if (g.lds_bytes > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+                if (e != hipSuccess) return e;
+            }
+            const int64_t ntiles = (N + TS - 1) / TS;
+            hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0, l1,
+                               dn, pp, op);
+            return hipGetLastError();
+        };
+        if (nb == 12) return nf == 1 ? go(k_lse_wide<12, 1>) : go(k_lse_wide<12, 2>);
+        if (nb == 16) return nf == 1 ? go(k_lse_wide<16, 1>) : go(k_lse_wide<16, 2>);
+        return hipErrorInvalidValue;
+    }
     if (g.variant == 4) {  // (geometry chose the few-state kernel: nf == 1, nb <= 3, LDS-DMA staging, pitch % 64 == 0)
         if (nf != 1 || !dma || (ld % TSS) != 0) return hipErrorInvalidValue;
         switch (nb) {
