@@ -85,6 +85,15 @@ int mbar_ctx_set_option(mbar_ctx* ctx, const char* key, int64_t value);
 int mbar_ctx_upload_u(mbar_ctx* ctx, const double* u_host, int64_t ld_host, int64_t col0_host,
                       int64_t ncols, int64_t col0_dev);
 int mbar_ctx_download_u(mbar_ctx* ctx, double* out, int64_t ld_out);
+/* Row-level assembly of an AUGMENTED matrix on the device -- the expectation family (mbar.py:732-1001) appends one
+ * row per new state (u_ln) and one per observable (u_ln - log A_n) to the resident u_kn; none of it needs the host
+ * N x (K + NL + S) array the reference builds (mbar.py:886-903).
+ *   upload_rows: whole rows [row0, row0 + nrows) from a C-contiguous host array rows_host[nrows][ld_host >= N_local];
+ *   copy_rows:   device-to-device from another context on the same device with the same N_local;
+ *   row_sub:     u[row][n] -= v_host[n]  (v = log A_n). */
+int mbar_ctx_upload_rows(mbar_ctx* ctx, int64_t row0, int64_t nrows, const double* rows_host, int64_t ld_host);
+int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows);
+int mbar_ctx_row_sub(mbar_ctx* ctx, int64_t row, const double* v_host);
 /* Fill the shard on the device with the synthetic harmonic ladder of SURVEY.md 8(d):
  * global sample n (n_global0 <= n < n_global0+N_local) belongs to the state given by the
  * cumulative N_k_global, x_n ~ Normal(O_s, K_s^-1/2) from a counter-based RNG keyed by

@@ -93,6 +93,7 @@ struct mbar_ctx {
     double* lognum_part = nullptr;
     size_t lognum_part_doubles = 0;
     double* f_hist = nullptr;       // SCI f history [batch][Kp]
+    double* vec_tmp = nullptr;      // staging for one N_local-vector (mbar_ctx_row_sub)
     // captured SCI batch (launch-bound loop: 3 small kernels per iteration replayed from a hipGraph)
     hipGraphExec_t sci_graph = nullptr;
     int64_t sci_graph_batch = 0, sci_graph_sig = 0;
@@ -816,6 +817,7 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->hred) (void)hipHostFree(c->hred);
     if (c->lognum_part) (void)hipFree(c->lognum_part);
     if (c->f_hist) (void)hipFree(c->f_hist);
+    if (c->vec_tmp) (void)hipFree(c->vec_tmp);
     if (c->sci_graph) (void)hipGraphExecDestroy(c->sci_graph);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -855,6 +857,45 @@ int mbar_ctx_upload_u(mbar_ctx* c, const double* u_host, int64_t ld_host, int64_
     HIPCHK(c, hipMemcpy2DAsync(c->u + col0_dev, (size_t)c->ld * sizeof(double), u_host + col0_host,
                                (size_t)ld_host * sizeof(double), (size_t)ncols * sizeof(double), (size_t)c->K,
                                hipMemcpyHostToDevice, c->stream));
+    c->u_checked = false;
+    return sync_stream(c);
+}
+
+int mbar_ctx_upload_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const double* rows_host, int64_t ld_host) {
+    if (!c || !rows_host) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > c->K || ld_host < c->N) return fail(c, MBAR_ERR_ARG, "row range out of bounds");
+    if (nrows == 0) return MBAR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(c->u + row0 * c->ld, (size_t)c->ld * sizeof(double), rows_host,
+                               (size_t)ld_host * sizeof(double), (size_t)c->N * sizeof(double), (size_t)nrows,
+                               hipMemcpyHostToDevice, c->stream));
+    c->u_checked = false;
+    return sync_stream(c);
+}
+
+int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows) {
+    if (!dst || !src) return fail(dst, MBAR_ERR_ARG, "NULL argument");
+    if (dst->device != src->device || dst->N != src->N) return fail(dst, MBAR_ERR_ARG, "contexts must share device and N_local");
+    if (nrows < 0 || dst_row0 < 0 || src_row0 < 0 || dst_row0 + nrows > dst->K || src_row0 + nrows > src->K)
+        return fail(dst, MBAR_ERR_ARG, "row range out of bounds");
+    if (nrows == 0) return MBAR_OK;
+    HIPCHK(dst, hipSetDevice(dst->device));
+    HIPCHK(dst, hipStreamSynchronize(src->stream));  // whatever produced the source rows has finished
+    HIPCHK(dst, hipMemcpy2DAsync(dst->u + dst_row0 * dst->ld, (size_t)dst->ld * sizeof(double), src->u + src_row0 * src->ld,
+                                 (size_t)src->ld * sizeof(double), (size_t)dst->N * sizeof(double), (size_t)nrows,
+                                 hipMemcpyDeviceToDevice, dst->stream));
+    dst->u_checked = false;
+    return sync_stream(dst);
+}
+
+int mbar_ctx_row_sub(mbar_ctx* c, int64_t row, const double* v_host) {
+    if (!c || !v_host) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (row < 0 || row >= c->K) return fail(c, MBAR_ERR_ARG, "row out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->vec_tmp) HIPCHK(c, hipMalloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
+    double* tmp = c->vec_tmp;
+    HIPCHK(c, hipMemcpyAsync(tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_row_sub(c->stream, c->u + row * c->ld, tmp, c->N));
     c->u_checked = false;
     return sync_stream(c);
 }

@@ -50,6 +50,7 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
 // nb8_variant (full 128-state diagonal panel only): 0 = paired waves with operand exchange, 1 = paired waves
 // that both compute every operand
 LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, int64_t grid_override, int nb8_variant);
+hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n);  // row[i] -= v[i]
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u,
                             int64_t ld, int64_t N, const double* anum /*indexed from row0*/,
                             const double* logden, int64_t row0, double* gram_part, double* psum_part);

@@ -2239,6 +2239,15 @@ hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) k_row_sub(double* __restrict__ row, const double* __restrict__ v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) row[i] -= v[i];
+}
+hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n) {
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(k_row_sub, dim3((unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096)), dim3(256), 0, s, row, v, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_sci_update(hipStream_t s, const double* part, int64_t nparts, int64_t rows, const double* Nk,
                              const double* lnNk, int64_t K, int64_t Kp, int first_state, double tol, double* f,
                              double* aden, double* f_hist, double* delta_out) {

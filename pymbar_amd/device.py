@@ -42,6 +42,11 @@ class DeviceMatrix:
 
     # ---- construction ---------------------------------------------------------------------------
     @classmethod
+    def empty(cls, K, N_local, device=None):
+        """A zero-filled resident matrix, to be assembled row by row (upload_rows / copy_rows_from / row_sub)."""
+        return cls(K, N_local, device=device)
+
+    @classmethod
     def from_host(cls, u_kn, device=None, columns=None):
         """Upload a host ``u_kn`` (K, N) -- or only its ``columns=(n0, n1)`` slice (this rank's shard)."""
         u_kn = np.asarray(u_kn)
@@ -95,6 +100,26 @@ class DeviceMatrix:
     @property
     def shape(self):
         return (self.K, self.N_local)
+
+    # ---- row-level assembly of an augmented matrix on the device (expectation family) ----------------------
+    def upload_rows(self, row0, rows):
+        """Whole rows ``[row0, row0 + len(rows))`` from a host array ``rows`` (R, N_local)."""
+        rows = np.ascontiguousarray(np.atleast_2d(rows), dtype=np.float64)
+        if rows.shape[1] != self.N_local:
+            raise ValueError("rows must have N_local columns")
+        self._check(self._lib.mbar_ctx_upload_rows(self._ctx, int(row0), rows.shape[0], _dptr(rows), rows.shape[1]))
+
+    def copy_rows_from(self, src, dst_row0=0, src_row0=0, nrows=None):
+        """Device-to-device copy of rows of another resident matrix (same device, same N_local)."""
+        nrows = src.K - src_row0 if nrows is None else nrows
+        self._check(self._lib.mbar_ctx_copy_rows(self._ctx, int(dst_row0), src._ctx, int(src_row0), int(nrows)))
+
+    def row_sub(self, row, v_n):
+        """``u[row, :] -= v_n`` on the device (v = log A_n turns a state row into an observable row)."""
+        v_n = np.ascontiguousarray(v_n, dtype=np.float64)
+        if v_n.shape != (self.N_local,):
+            raise ValueError("v_n must have N_local entries")
+        self._check(self._lib.mbar_ctx_row_sub(self._ctx, int(row), _dptr(v_n)))
 
     def set_option(self, key, value):
         self._check(self._lib.mbar_ctx_set_option(self._ctx, key.encode(), int(value)))

@@ -32,18 +32,29 @@ logger = logging.getLogger(__name__)
 _LOGFACTOR = 4.0 * np.finfo(np.float64).eps  # pymbar/mbar.py:827-832
 
 
-def _augmented_matrix(mbar, rows, device):
-    """Upload ``[u_kn; rows]`` once, the extra rows as unsampled states (N_k = 0: they do not enter the denominator)."""
+def _augmented_matrix(mbar, u_ln, L_list, state_rows, log_A, device):
+    """Assemble ``[u_kn; u_ln[L_list]; u_ln[state_rows[s]] - log_A[s]]`` ON THE DEVICE, the extra rows as unsampled states
+    (N_k = 0: they do not enter the denominator).  The resident ``u_kn`` is copied device to device; a new-state row
+    that IS a resident row (``u_ln is mbar.u_kn``, the default of compute_expectations) likewise; only genuinely new
+    rows and the S vectors ``log A_n`` cross PCIe -- never the N x (K + NL + S) host array of mbar.py:886-903."""
     from .device import DeviceMatrix
 
-    K = mbar.K
-    R = rows.shape[0]
-    aug = np.empty((K + R, mbar.u_kn.shape[1]), dtype=np.float64)
-    aug[:K] = mbar.u_kn
-    aug[K:] = rows
-    N_aug = np.zeros(K + R, dtype=np.float64)
+    K, N = mbar.K, mbar.N
+    NL, S = len(L_list), len(state_rows)
+    dm = DeviceMatrix.empty(K + NL + S, N, device=device)
+    dm.copy_rows_from(mbar._dm, 0, 0, K)
+    resident = u_ln is mbar.u_kn
+    for j, l in enumerate(L_list):
+        if resident:
+            dm.copy_rows_from(mbar._dm, K + j, int(l), 1)
+        else:
+            dm.upload_rows(K + j, u_ln[int(l)][np.newaxis, :])
+    col = {int(l): K + j for j, l in enumerate(L_list)}
+    for s in range(S):
+        dm.copy_rows_from(dm, K + NL + s, col[int(state_rows[s])], 1)
+        dm.row_sub(K + NL + s, log_A[s])
+    N_aug = np.zeros(K + NL + S, dtype=np.float64)
     N_aug[:K] = mbar.N_k
-    dm = DeviceMatrix.from_host(aug, device=device)
     dm.set_Nk(N_aug)
     return dm, N_aug
 
@@ -100,13 +111,9 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
     Theta_ij = None
     # The augmented matrix goes to the device once.  A bootstrap replicate (mbar.py:905-912 gathers
     # u_kn[:, bootstrap_rints[n]]) is the same matrix with per-sample multiplicities = draw counts.
-    rows = np.empty((NL + S, N), dtype=np.float64)
-    for j, l in enumerate(L_list):
-        rows[j] = u_ln[l]
     with np.errstate(divide="ignore"):
-        for s in range(S):
-            rows[NL + s] = u_ln[state_list[s]] - np.log(A_n[obs_list[s]])
-    dm, N_aug = _augmented_matrix(mbar, rows, getattr(mbar, "_device", None))
+        log_A = [np.log(A_n[obs_list[s]]) for s in range(S)]
+    dm, N_aug = _augmented_matrix(mbar, u_ln, L_list, state_list[:S] if S > 0 else [], log_A, getattr(mbar, "_device", None))
     try:
         for n in range(n_total):
             if n == 0:

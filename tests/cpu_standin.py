@@ -23,6 +23,10 @@ class OracleMatrix:
     shape = property(lambda self: (self.K, self.N_local))
 
     @classmethod
+    def empty(cls, K, N_local, device=None):
+        return cls(np.zeros((K, N_local)))
+
+    @classmethod
     def from_host(cls, u_kn, device=None, columns=None):
         u_kn = np.asarray(u_kn, dtype=np.float64)
         if columns is not None:
@@ -37,6 +41,17 @@ class OracleMatrix:
 
     def close(self):
         pass
+
+    def upload_rows(self, row0, rows):
+        rows = np.atleast_2d(np.asarray(rows, dtype=np.float64))
+        self.u[row0:row0 + rows.shape[0]] = rows
+
+    def copy_rows_from(self, src, dst_row0=0, src_row0=0, nrows=None):
+        nrows = src.K - src_row0 if nrows is None else nrows
+        self.u[dst_row0:dst_row0 + nrows] = src.u[src_row0:src_row0 + nrows]
+
+    def row_sub(self, row, v_n):
+        self.u[row] -= np.asarray(v_n, dtype=np.float64)
 
     def to_host(self):
         return self.u.copy()
