@@ -90,7 +90,7 @@ int mbar_ctx_download_u(mbar_ctx* ctx, double* out, int64_t ld_out);
  * N x (K + NL + S) array the reference builds (mbar.py:886-903).
  *   upload_rows: whole rows [row0, row0 + nrows) from a C-contiguous host array rows_host[nrows][ld_host >= N_local];
  *   copy_rows:   device-to-device from another context on the same device with the same N_local;
- *   row_sub:     u[row][n] -= v_host[n]  (v = log A_n). */
+ *   row_sub:     u[row][n] -= v_host[n]  (v = log A_n); v_host = NULL subtracts the vector of the previous call again. */
 int mbar_ctx_upload_rows(mbar_ctx* ctx, int64_t row0, int64_t nrows, const double* rows_host, int64_t ld_host);
 int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows);
 int mbar_ctx_row_sub(mbar_ctx* ctx, int64_t row, const double* v_host);

@@ -889,12 +889,14 @@ int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t s
 }
 
 int mbar_ctx_row_sub(mbar_ctx* c, int64_t row, const double* v_host) {
-    if (!c || !v_host) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
     if (row < 0 || row >= c->K) return fail(c, MBAR_ERR_ARG, "row out of range");
+    if (!v_host && !c->vec_tmp) return fail(c, MBAR_ERR_STATE, "mbar_ctx_row_sub: no vector has been uploaded yet");
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->vec_tmp) HIPCHK(c, hipMalloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
     double* tmp = c->vec_tmp;
-    HIPCHK(c, hipMemcpyAsync(tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (v_host)  // NULL: subtract the vector of the previous call again (one observable at many states)
+        HIPCHK(c, hipMemcpyAsync(tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_row_sub(c->stream, c->u + row * c->ld, tmp, c->N));
     c->u_checked = false;
     return sync_stream(c);

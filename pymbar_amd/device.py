@@ -114,8 +114,12 @@ class DeviceMatrix:
         nrows = src.K - src_row0 if nrows is None else nrows
         self._check(self._lib.mbar_ctx_copy_rows(self._ctx, int(dst_row0), src._ctx, int(src_row0), int(nrows)))
 
-    def row_sub(self, row, v_n):
-        """``u[row, :] -= v_n`` on the device (v = log A_n turns a state row into an observable row)."""
+    def row_sub(self, row, v_n=None):
+        """``u[row, :] -= v_n`` on the device (v = log A_n turns a state row into an observable row).
+        ``v_n=None`` subtracts the vector of the previous call again (no upload)."""
+        if v_n is None:
+            self._check(self._lib.mbar_ctx_row_sub(self._ctx, int(row), None))
+            return
         v_n = np.ascontiguousarray(v_n, dtype=np.float64)
         if v_n.shape != (self.N_local,):
             raise ValueError("v_n must have N_local entries")

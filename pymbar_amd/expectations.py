@@ -32,8 +32,8 @@ logger = logging.getLogger(__name__)
 _LOGFACTOR = 4.0 * np.finfo(np.float64).eps  # pymbar/mbar.py:827-832
 
 
-def _augmented_matrix(mbar, u_ln, L_list, state_rows, log_A, device):
-    """Assemble ``[u_kn; u_ln[L_list]; u_ln[state_rows[s]] - log_A[s]]`` ON THE DEVICE, the extra rows as unsampled states
+def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device):
+    """Assemble ``[u_kn; u_ln[L_list]; u_ln[state_rows[s]] - log A[obs_rows[s]]]`` ON THE DEVICE, the extra rows as unsampled states
     (N_k = 0: they do not enter the denominator).  The resident ``u_kn`` is copied device to device; a new-state row
     that IS a resident row (``u_ln is mbar.u_kn``, the default of compute_expectations) likewise; only genuinely new
     rows and the S vectors ``log A_n`` cross PCIe -- never the N x (K + NL + S) host array of mbar.py:886-903."""
@@ -50,9 +50,16 @@ def _augmented_matrix(mbar, u_ln, L_list, state_rows, log_A, device):
         else:
             dm.upload_rows(K + j, u_ln[int(l)][np.newaxis, :])
     col = {int(l): K + j for j, l in enumerate(L_list)}
-    for s in range(S):
-        dm.copy_rows_from(dm, K + NL + s, col[int(state_rows[s])], 1)
-        dm.row_sub(K + NL + s, log_A[s])
+    for i in np.unique(obs_rows) if S > 0 else []:  # one upload of log A_i, subtracted at every state it is evaluated at
+        with np.errstate(divide="ignore"):
+            log_A = np.log(A_n[int(i)])
+        first = True
+        for s in range(S):
+            if int(obs_rows[s]) != int(i):
+                continue
+            dm.copy_rows_from(dm, K + NL + s, col[int(state_rows[s])], 1)
+            dm.row_sub(K + NL + s, log_A if first else None)
+            first = False
     N_aug = np.zeros(K + NL + S, dtype=np.float64)
     N_aug[:K] = mbar.N_k
     dm.set_Nk(N_aug)
@@ -111,9 +118,8 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
     Theta_ij = None
     # The augmented matrix goes to the device once.  A bootstrap replicate (mbar.py:905-912 gathers
     # u_kn[:, bootstrap_rints[n]]) is the same matrix with per-sample multiplicities = draw counts.
-    with np.errstate(divide="ignore"):
-        log_A = [np.log(A_n[obs_list[s]]) for s in range(S)]
-    dm, N_aug = _augmented_matrix(mbar, u_ln, L_list, state_list[:S] if S > 0 else [], log_A, getattr(mbar, "_device", None))
+    dm, N_aug = _augmented_matrix(mbar, u_ln, L_list, state_list[:S] if S > 0 else [], A_n, obs_list,
+                                  getattr(mbar, "_device", None))
     try:
         for n in range(n_total):
             if n == 0:

@@ -50,8 +50,10 @@ class OracleMatrix:
         nrows = src.K - src_row0 if nrows is None else nrows
         self.u[dst_row0:dst_row0 + nrows] = src.u[src_row0:src_row0 + nrows]
 
-    def row_sub(self, row, v_n):
-        self.u[row] -= np.asarray(v_n, dtype=np.float64)
+    def row_sub(self, row, v_n=None):
+        if v_n is not None:
+            self._last_v = np.asarray(v_n, dtype=np.float64).copy()
+        self.u[row] -= self._last_v
 
     def to_host(self):
         return self.u.copy()
