@@ -78,3 +78,20 @@ def test_entropy_enthalpy_consistency(ho):
     fa = ts.harmonic_free_energies(K_K)
     z = (r["Delta_f"] - (fa - fa[:, None])) / (r["dDelta_f"] + np.eye(4))
     assert np.max(np.abs(z)) < 6.0
+
+
+def test_exponential_system_matches_analytical_within_error():
+    """Second model system of the reference's tests (exponential distributions with rates 1..4): f_k = ln(rate_k),
+    <x>_k = 1 / rate_k, <x^2>_k = 2 / rate_k^2."""
+    rates = np.array([1.0, 2.0, 3.0, 4.0])
+    x_n, u_kn, N_k, s_n = ts.exponential_u_kn(rates, N_K, seed=21)
+    m = pymbar_amd.MBAR(u_kn, N_k)
+    r = m.compute_free_energy_differences()
+    fa = ts.exponential_free_energies(rates)
+    z = (r["Delta_f"] - (fa - fa[:, None])) / (r["dDelta_f"] + np.eye(4))
+    assert np.max(np.abs(z)) < 6.0
+    e = m.compute_expectations(x_n)
+    assert np.max(np.abs((e["mu"] - 1.0 / rates) / e["sigma"])) < 6.0
+    e2 = m.compute_expectations(x_n ** 2)
+    assert np.max(np.abs((e2["mu"] - 2.0 / rates ** 2) / e2["sigma"])) < 6.0
+    m.close()
