@@ -512,7 +512,6 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     constexpr int ROWS = NB * 16;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
-    constexpr int NDMA = ROWS / 8 + 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
@@ -562,15 +561,17 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             const int64_t tn = t + W;
             if (tn < ntiles) {
                 char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
-                stage_tile<ROWS, true, 0, 1>(u, ld, tn * TS, nbuf, lane, so, rows);
+                // The next tile is requested in two halves -- even DMA pieces here, odd ones after the first group pair
+                // below -- which smooths the request stream of the 1024 waves (measured: -1.5 % on this sweep).
+                stage_tile<ROWS, true, 0, 2>(u, ld, tn * TS, nbuf, lane, so, rows);
                 stage_vec16<true>(cw, tn * TS, nbuf + U_BYTES, lane);
-                // vmcnt counts stores too (in issue order with the loads on gfx9): the queue here is
-                // [tile t][logden store of tile t - W][tile tn].  Waiting for "at most NDMA outstanding" would
-                // also wait for that store -- a full memory round trip exposed on every tile.
-                if (has_store && t != gw)  // (no store has been issued before the wave's first tile)
-                    wait_vm<NDMA + 1>();
+                constexpr int NEVEN = (ROWS / 8 + 1) / 2 + 1;  // even pieces + the weight slot
+                // vmcnt counts stores too (in issue order with the loads on gfx9); the queue here is
+                // [even(t)][odd(t)][logden store of tile t - W][even(tn)], and tile t is needed now:
+                if (has_store && t != gw)
+                    wait_vm<NEVEN + 1>();
                 else
-                    wait_vm<NDMA>();
+                    wait_vm<NEVEN>();
             } else {
                 wait_vm<0>();
             }
@@ -583,9 +584,13 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         double mm = 0.0, ss[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) ss[f] = 1.0;
-#pragma unroll
-        for (int g = 0; g < GROUPS; g += 2)
-            lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, rd_base, pos, g, a, c, acc, ks, ns, mm, ss);
+        lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, rd_base, pos, 0, a, c, acc, ks, ns, mm, ss);
+        if constexpr (DMA) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + W < ntiles) stage_tile<ROWS, true, 1, 2>(u, ld, (t + W) * TS, buf + (cur ^ 1) * TILE_BYTES, lane, so, rows);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, rd_base, pos, 2, a, c, acc, ks, ns, mm, ss);
         // lanes with (ks & 3) == g hold (shift, sums) of sample 4 g + ns: one log per candidate per tile
         {
             const int64_t n = t * TS + 4 * (ks & 3) + ns;
