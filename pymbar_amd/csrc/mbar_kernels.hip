@@ -781,8 +781,10 @@ __device__ __forceinline__ void sci_update_block(const double* part, int64_t npa
         const int G = 256 / KW, g = tid / KW, kk = tid % KW;
         if (act) {
             double sm = 0.0;
-            if (kk < kw)
+            if (kk < kw) {
+#pragma unroll 8  // (same summation order; the loads of eight records are in flight together)
                 for (int64_t p = g; p < nparts; p += G) sm += part[p * rows + k0 + kk];
+            }
             scr[tid] = sm;
         }
         __syncthreads();
