@@ -428,6 +428,12 @@ def solve_mbar_for_all_states(u_kn, N_k, f_k, states_with_samples, solver_protoc
                                                    copy.deepcopy(solver_protocol) if solver_protocol is not None else None)
             f_k[states_with_samples] = f_solved[states_with_samples]
         h.set_Nk(Nf)
-        f_k = -1.0 * h.lognum(f_k)
+        if np.all(Nf > 0):
+            # every state is sampled: the all-state update -lognum_k equals f_k - log(psum_k / N_k), i.e. one
+            # single-candidate sweep instead of the log-denominator sweep + the log-space reduction sweep
+            psum, _, _ = h.eval(f_k)
+            f_k = f_k - np.log(psum[0] / Nf)
+        else:
+            f_k = -1.0 * h.lognum(f_k)
     f_k -= f_k[0]
     return f_k
