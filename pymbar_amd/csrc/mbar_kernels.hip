@@ -1649,54 +1649,48 @@ k_reduce(const double* __restrict__ part, int64_t nparts, int64_t count, int64_t
 }
 
 // Robust per-state log-sum-exp over samples (log space, like the reference's second logsumexp):
-// block = 1024 samples; for every state k the block max and sum of exp(x - max) are emitted.
-constexpr int LOGNUM_CHUNK = 1024;
+// one wave = 512 consecutive samples; for every state k the wave emits its max and its sum of exp(x - max).
+constexpr int LOGNUM_CHUNK = 512;  // samples per wave: 8 per lane, no workgroup-level synchronisation
 __global__ void __launch_bounds__(256)
 k_lognum(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
          const double* __restrict__ anum, const double* __restrict__ logden,
          double* __restrict__ pmax, double* __restrict__ psum, int64_t nchunks) {
-    __shared__ double red[8];
-    const int64_t c = blockIdx.x;
+    constexpr int SPL = LOGNUM_CHUNK / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double nl[4];
-    bool ok[4];
+    const int64_t c = (int64_t)blockIdx.x * 4 + wave;  // one chunk of 512 consecutive samples per wave
+    if (c >= nchunks) return;
+    double nl[SPL];
+    bool ok[SPL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t n = c * LOGNUM_CHUNK + j * 256 + threadIdx.x;
+    for (int j = 0; j < SPL; ++j) {
+        const int64_t n = c * LOGNUM_CHUNK + j * 64 + lane;
         ok[j] = n < N;
         nl[j] = ok[j] ? -logden[n] : 0.0;
     }
     for (int64_t k = 0; k < K; ++k) {
         const double ak = anum[k];
-        double v[4];
+        double v[SPL];
         double m = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = c * LOGNUM_CHUNK + j * 256 + threadIdx.x;
+        for (int j = 0; j < SPL; ++j) {
+            const int64_t n = c * LOGNUM_CHUNK + j * 64 + lane;
             v[j] = ok[j] ? (ak + nl[j] - u[k * ld + n]) : -INFINITY;
             m = fmax(m, v[j]);
         }
         m = wave_max(m);
-        if (lane == 0) red[wave] = m;
-        __syncthreads();
-        m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
         double s = 0.0;
         if (m > -INFINITY) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += exp(v[j] - m);  // exp(-inf) = 0 for masked samples
+            for (int j = 0; j < SPL; ++j) s += exp(v[j] - m);  // exp(-inf) = 0 for masked samples
         }
         s = wave_sum(s);
-        if (lane == 0) red[4 + wave] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             pmax[k * nchunks + c] = m;
-            psum[k * nchunks + c] = red[4] + red[5] + red[6] + red[7];
+            psum[k * nchunks + c] = s;
         }
-        __syncthreads();
     }
 }
 
-// merge chunk partials of one state: out_max = max_c, out_sum = sum_c psum_c exp(pmax_c - out_max)
 __global__ void __launch_bounds__(256)
 k_lognum_merge(const double* __restrict__ pmax, const double* __restrict__ psum, int64_t nchunks,
                double* __restrict__ out_max, double* __restrict__ out_sum) {
@@ -2199,7 +2193,7 @@ int64_t lognum_chunks(int64_t N) { return (N + LOGNUM_CHUNK - 1) / LOGNUM_CHUNK;
 
 hipError_t launch_lognum(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, const double* anum,
                          const double* logden, double* pmax, double* psum, int64_t nchunks) {
-    hipLaunchKernelGGL(k_lognum, dim3((unsigned)nchunks), dim3(256), 0, s, u, ld, N, K, anum, logden, pmax, psum,
+    hipLaunchKernelGGL(k_lognum, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, s, u, ld, N, K, anum, logden, pmax, psum,
                        nchunks);
     return hipGetLastError();
 }
