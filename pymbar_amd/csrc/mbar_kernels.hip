@@ -1907,7 +1907,16 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
         if (g.variant == 0) g.lds_bytes = (size_t)4 * (tile + (size_t)GROUPS * 8 * 64 * 8) + EXP_TABLE_BYTES;  // single u buffer + operand buffer
     }
     int64_t want = (ntiles + 3) / 4;
-    int64_t cap = num_cu;  // the accumulators own the register file: one workgroup per CU
+    // Wide panels: the accumulators own the register file, one workgroup (one wave per SIMD) per CU.  Narrow diagonal
+    // panels need few registers and little LDS, so several workgroups share a CU (register occupancy of k_gram<NB,NB>:
+    // 8 / 6 / 4 / 3 / 2 waves per SIMD for NB = 1..5).
+    int64_t cap = num_cu;
+    if (diag && tile_rows <= 80) {
+        static const int occ[6] = {1, 8, 6, 4, 3, 2};
+        const int by_lds = blocks_per_cu_for(g.lds_bytes);
+        const int by_reg = occ[tile_rows / 16];
+        cap = (int64_t)num_cu * (by_lds < by_reg ? by_lds : by_reg);
+    }
     if (grid_override > 0) cap = grid_override;
     if (want < 1) want = 1;
     g.blocks = (int)(want < cap ? want : cap);
