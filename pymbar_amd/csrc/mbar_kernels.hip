@@ -1193,7 +1193,8 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     // Tiles of more than 128 rows (the rectangle stages 192) get ONE buffer per wave: every LDS operand of a tile is
     // in registers right after the loop top, so the buffer is refilled there and the DMA still has the whole tile
     // period to land.
-    constexpr int NBUF = ROWS > 128 ? 1 : 2;
+    // (also for narrow diagonal panels, NB <= 5: half the LDS lets as many workgroups share a CU as the registers allow)
+    constexpr int NBUF = (ROWS > 128 || (DIAG && NBI <= 5)) ? 1 : 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
@@ -1898,7 +1899,8 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
     g.waves = 4;
     g.variant = -1;
     const size_t tile = (size_t)tile_rows * TS * 8 + TS * 8;  // u tile + its 16 logden values
-    g.lds_bytes = (size_t)4 * (tile_rows > 128 ? 1 : 2) * tile + EXP_TABLE_BYTES;  // (192-row tiles: one buffer per wave)
+    const bool one_buffer = tile_rows > 128 || (diag && tile_rows <= 80);  // must match NBUF in k_gram
+    g.lds_bytes = (size_t)4 * (one_buffer ? 1 : 2) * tile + EXP_TABLE_BYTES;
     if (diag && tile_rows == 128 && nb8_variant == 2) {
         g.variant = 2;
     } else if (diag && tile_rows == 128) {
