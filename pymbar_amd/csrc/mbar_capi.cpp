@@ -90,6 +90,7 @@ struct mbar_ctx {
     double* red = nullptr;          // reduced outputs (contiguous: psum | obj | gram blocks)
     size_t red_doubles = 0;
     double* hred = nullptr;         // pinned host mirror of red
+    double* hstage = nullptr;       // pinned staging for the small per-sweep uploads (2 Kp doubles), no sync needed
     double* lognum_part = nullptr;
     size_t lognum_part_doubles = 0;
     double* f_hist = nullptr;       // SCI f history [batch][Kp]
@@ -557,16 +558,18 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
         if (sumlogden) std::copy(sl.begin(), sl.end(), sumlogden);
         return MBAR_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(d_aden(c), h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // h goes out of scope below; tiny copy
+    // (pinned staging: the copy is stream-ordered before the sweep and the host only touches the buffer again after
+    // the sweep's results have been read back, so no synchronisation is needed here)
+    std::copy(h.begin(), h.end(), c->hstage);
+    HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     rc = run_lse(c, nf, rows, ld0, ld1, use_off);
     if (rc) return rc;
     if (want_gram) {
         // p-mode operand: anum = aden of f[0] (Kp entries)
         std::vector<double> an((size_t)c->Kp);
         build_aden(c, f, an.data(), c->Kp);
-        HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::copy(an.begin(), an.end(), c->hstage + 2 * c->Kp);
+        HIPCHK(c, hipMemcpyAsync(d_anum(c), c->hstage + 2 * c->Kp, an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         rc = run_gram(c, d_anum(c), ld0, off_gram, plan);
         if (rc) return rc;
     }
@@ -788,6 +791,7 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
         CRT(hipStreamSynchronize(c->stream));
     }
     CRT(hipMalloc((void**)&c->small, small_doubles(c->Kp) * sizeof(double)));
+    CRT(hipHostMalloc((void**)&c->hstage, (size_t)4 * c->Kp * sizeof(double), hipHostMallocDefault));
     CRT(hipMemsetAsync(c->small, 0, small_doubles(c->Kp) * sizeof(double), c->stream));
     CRT(hipStreamSynchronize(c->stream));
 #undef CRT
@@ -817,6 +821,7 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->hred) (void)hipHostFree(c->hred);
     if (c->lognum_part) (void)hipFree(c->lognum_part);
     if (c->f_hist) (void)hipFree(c->f_hist);
+    if (c->hstage) (void)hipHostFree(c->hstage);
     if (c->vec_tmp) (void)hipFree(c->vec_tmp);
     if (c->sci_graph) (void)hipGraphExecDestroy(c->sci_graph);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1204,8 +1209,8 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
             if (rc) return rc;
             std::vector<double> an((size_t)c->Kp);
             build_aden(c, f.data(), an.data(), c->Kp);
-            HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::copy(an.begin(), an.end(), c->hstage + 2 * c->Kp);
+            HIPCHK(c, hipMemcpyAsync(d_anum(c), c->hstage + 2 * c->Kp, an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
             rc = run_gram(c, d_anum(c), c->logden[cur], 0, plan);
             if (rc) return rc;
             rc = allreduce_dev(c, c->red, (int64_t)total, 0);
