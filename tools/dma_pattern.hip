@@ -22,7 +22,7 @@ __device__ __forceinline__ void dma16(const char* base /*uniform*/, uint32_t vof
 }
 
 // MODE 0: row-major, 1: tile-major.  WPB waves per block, each wave double-buffers its own tiles.
-template <int MODE, int WPB>
+template <int MODE, int WPB, int NREAD = 4>
 __global__ void __launch_bounds__(WPB * 64) k_dma(const double* __restrict__ u, int64_t ld, int64_t ntiles, double* sink,
                                                   int delay /* x64 clocks of s_sleep per tile: stands in for the compute */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(WPB * 64) k_dma(const double* __restrict__ u, 
         }
         const char* cb = buf + cur * (ROWS * TS * 8);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc += *reinterpret_cast<const double*>(cb + (i * 64 + lane) * 8 * 8);
+        for (int i = 0; i < NREAD; ++i) acc += *reinterpret_cast<const double*>(cb + ((i * 64 + lane) * 8 * (32 / NREAD)) % (ROWS * TS * 8));
         for (int d = 0; d < delay; ++d) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
         cur ^= 1;
     }
@@ -68,16 +68,16 @@ __global__ void __launch_bounds__(256) k_stream(const double2* __restrict__ u, i
     if (acc == 12345.6789) sink[threadIdx.x] = acc;
 }
 
-template <int MODE, int WPB>
+template <int MODE, int WPB, int NREAD = 4>
 void run(const double* u, int64_t ld, int64_t ntiles, double* sink, int blocks, const char* name, int delay = 0) {
     const size_t lds = (size_t)WPB * 2 * ROWS * TS * 8;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_dma<MODE, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_dma<MODE, WPB, NREAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_dma<MODE, WPB>), dim3(blocks), dim3(WPB * 64), lds, 0, u, ld, ntiles, sink, delay);
+        hipLaunchKernelGGL((k_dma<MODE, WPB, NREAD>), dim3(blocks), dim3(WPB * 64), lds, 0, u, ld, ntiles, sink, delay);
         hipEventRecord(e1);
         hipDeviceSynchronize();
     }
@@ -106,6 +106,8 @@ int main() {
         run<1, 4>(u, ld, ntiles, sink, cus, "tile-major + per-tile delay", delay);
     for (int delay : {90, 100, 110})
         run<0, 4>(u, ld, ntiles, sink, cus, "row-major + per-tile delay", delay);
+    for (int delay : {0, 60, 80, 90})  // the whole tile is also READ from LDS (32 ds_read_b64 per lane), like the sweeps do
+        run<0, 4, 32>(u, ld, ntiles, sink, cus, "row-major + full LDS read + delay", delay);
     run<0, 2>(u, ld, ntiles, sink, 2 * cus, "row-major tiles (128 x 128 B)");
     run<1, 2>(u, ld, ntiles, sink, 2 * cus, "tile-major tiles (16 KB blocks)");
     hipEvent_t e0, e1;
