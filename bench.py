@@ -2,18 +2,26 @@
 """Benchmark of the MBAR solver hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric "MBAR solver iterations/sec + wallclock-to-converge, K=128 N=1e7"):
-config 3 -- the synthetic harmonic ladder O_k = linspace(0,4,K), K_k = linspace(1,3,K), equal N_k, K = 128,
-N = 1e7 samples PER GPU (weak scaling; 8 GPUs = 8e7 samples, config 4's regime), fp64, generated directly in
-HBM.  A step is ONE adaptive iteration (pymbar/mbar_solvers.py:575-640): a Gram/Hessian sweep on the fp64
-matrix cores at the current f, the K x K Newton solve, and one sweep evaluating the gradients of both
-candidates (f_sci, f_nr), with one all-reduce after each sweep when N > 1.  The timed region runs exactly K
-iterations with the convergence test disabled (the work per iteration does not depend on f); wall-clock
-to converge from f = 0 at tol 1e-12 is measured separately and reported in the same JSON line.
+Workload (BASELINE.json metric "MBAR solver iterations/sec + wallclock-to-converge, K=128 N=1e7, 1/2/4/8 GPUs"): the
+synthetic harmonic ladder O_k = linspace(0,4,K), K_k = linspace(1,3,K), equal N_k, K = 128, fp64, generated directly
+in HBM from a counter RNG keyed by (seed, global sample index), so every sharding sees the same data.
 
-``value`` = iterations/s x n_gpus, i.e. shard-iterations/s: every rank processes its own K x 1e7 shard each
-iteration, so at N = 1 this is the plain solver iterations/s of BASELINE.json.
+    --gpus 1, 2, 4 : config 3, N = 1e7 samples in TOTAL, column-sharded over the GPUs (strong scaling)
+    --gpus 8       : config 4, N = 1e8 samples in TOTAL = 1.25e7 per GPU
+
+A step is ONE adaptive iteration (pymbar/mbar_solvers.py:575-640): the Gram/Hessian sweep on the fp64 matrix cores at the
+current f, the K x K Newton solve, one sweep evaluating the gradients of both candidates (f_sci, f_nr), the choice --
+all device-resident -- with one ncclAllReduce after each sweep when N > 1.  The timed region is ONE solver call of
+exactly K iterations with the convergence test disabled (the work per iteration does not depend on f), including the
+solver's initial gradient sweep.  ``value`` = solver iterations per second of the whole job (NOT multiplied by the number
+of GPUs).  Wall-clock to converge from f = 0 at tol 1e-12 is measured separately and reported in the same JSON line.
+
+Ranks rendezvous through ``pymbar_amd.distributed.HostGroup`` (standard-library TCP on MASTER_ADDR / MASTER_PORT + 1);
+the data path is RCCL inside libmbar_hip.so.  If RCCL cannot be initialised the run FAILS (exit code 3) instead of
+silently measuring the host fallback; ``--allow-host-allreduce`` is for debugging only.
 """
 import argparse
 import json
@@ -32,9 +40,10 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s me
 
 
 def pmc_traffic(kernel_prefix, K, n_loc):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_fetch_write.json,
-    newest round first), corrected as MI355X_MICROARCH.md prescribes (gfx950: FETCH_SIZE x 2).  None if no
-    profile of this exact workload is committed -- PMC collection needs its own rocprofv3 run."""
+    """HBM bytes per launch of a kernel from the COMMITTED rocprofv3 PMC passes (profiles/*_pmc_fetch_write.json,
+    newest round first), corrected as MI355X_MICROARCH.md prescribes (gfx950: FETCH_SIZE x 2).  Returns
+    ``(bytes, source_file)`` or ``(None, None)`` if no profile of this exact workload is committed -- PMC collection needs
+    its own rocprofv3 run, so this number is never measured inside the bench run itself."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write.json")), reverse=True):
@@ -46,7 +55,25 @@ def pmc_traffic(kernel_prefix, K, n_loc):
             continue
         for name, v in d["kernels"].items():
             if kernel_prefix in name and "FETCH_SIZE_KB_mean_per_launch" in v:
-                return (2.0 * v["FETCH_SIZE_KB_mean_per_launch"] + v.get("WRITE_SIZE_KB_mean_per_launch", 0.0)) * 1024.0
+                b = (2.0 * v["FETCH_SIZE_KB_mean_per_launch"] + v.get("WRITE_SIZE_KB_mean_per_launch", 0.0)) * 1024.0
+                return b, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def reference_build_host_baseline(K):
+    """The UNMODIFIED reference (pymbar numpy path) timed on the build container by tools/time_reference.py; committed
+    under profiles/ because /root/reference does not exist on the GPU box."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_cpu_timing.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("K") == K:
+            d = dict(d)
+            d["source"] = os.path.relpath(path, ROOT)
+            return d
     return None
 
 
@@ -86,7 +113,31 @@ def cpu_baseline(dm_factory, K, N_full, n_sample, seed):
                   f"BLAS threads = all cores) on the first {n_sample} of {N_full} columns, K={K}: "
                   f"{t_iter:.2f} s measured (gradient alone {t_grad:.2f} s), scaled linearly by {N_full / n_sample:.0f}x",
         "seconds_per_iteration_extrapolated": t_iter * N_full / n_sample,
+        "reference_build_host": reference_build_host_baseline(K),
     }
+
+
+def api_end_to_end(K, N_total, seed, dev, O_k, K_k, N_k):
+    """What a user of ``MBAR(u_kn, N_k)`` sees: a HOST (K, N) array in, PCIe upload + NaN scan + default solver protocol
+    + ``compute_free_energy_differences()`` (covariance sweep on the matrix cores), wall clock."""
+    import pymbar_amd
+    from pymbar_amd.device import DeviceMatrix
+
+    with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=seed, n_global0=0, N_local=N_total, device=dev) as gen:
+        u_host = gen.to_host()  # pageable host memory, like any numpy array a user would pass
+    t0 = time.perf_counter()
+    mbar = pymbar_amd.MBAR(u_host, N_k, device=dev)
+    t_ctor = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    r = mbar.compute_free_energy_differences()
+    t_diff = time.perf_counter() - t1
+    total = time.perf_counter() - t0
+    ok = bool(np.all(np.isfinite(r["dDelta_f"])))
+    stats = dict(getattr(mbar, "upload_stats", {}) or {})
+    mbar.close()
+    del u_host
+    return {"api_end_to_end_s": total, "constructor_s": t_ctor, "compute_free_energy_differences_s": t_diff,
+            "host_bytes": 8.0 * K * N_total, "finite": ok, **stats}
 
 
 def main():
@@ -95,15 +146,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--K", type=int, default=128)
-    ap.add_argument("--n-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--n-total", type=int, default=0,
+                    help="samples in total (default: 1e7 = config 3 for 1, 2, 4 GPUs; 1e8 = config 4 for 8 GPUs)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="columns for the CPU baseline (0 = skip)")
+    ap.add_argument("--api-e2e", type=int, default=1, help="also time MBAR(u_kn_host, N_k) end to end (1 GPU only; 0 = skip)")
     ap.add_argument("--staging", type=int, default=0)
     ap.add_argument("--lse-variant", type=int, default=1)
     ap.add_argument("--gram-variant", type=int, default=2)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak (default, the driver's contract): --n-per-gpu samples on EVERY GPU, value = solver it/s x GPUs; "
-                         "strong: --n-per-gpu samples in TOTAL, split over the GPUs, value = solver it/s")
+    ap.add_argument("--device-loop", type=int, default=1, help="0 = host-driven adaptive loop (A/B)")
+    ap.add_argument("--allow-host-allreduce", action="store_true", help="debugging only: do not fail when RCCL is unavailable")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,55 +164,48 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    from pymbar_amd import _lib
     from pymbar_amd import testsystems as ts
     from pymbar_amd.device import DeviceMatrix, device_info
+    from pymbar_amd.distributed import HostGroup, attach_allreduce, shard_bounds
 
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")  # rendezvous + barriers only; the data path is RCCL inside libmbar_hip
-
-    def barrier_sync(dm):
-        if dist is not None:
-            dist.barrier()
-        dm.synchronize()
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
+    group = HostGroup.from_env() if world > 1 else None
 
     K = args.K
-    if args.scaling == "weak":
-        n_loc = args.n_per_gpu
-        N_total = n_loc * world
-    else:  # the same problem on more GPUs: contiguous 16-aligned column shards
-        from pymbar_amd.distributed import shard_bounds
-
-        N_total = args.n_per_gpu
-        n0_strong, n1_strong = shard_bounds(N_total, rank, world)
-        n_loc = n1_strong - n0_strong
+    N_total = args.n_total if args.n_total > 0 else (100_000_000 if world >= 8 else 10_000_000)
+    config_name = "config4" if N_total == 100_000_000 else ("config3" if N_total == 10_000_000 else "custom")
+    n0, n1 = shard_bounds(N_total, rank, world)
+    n_loc = n1 - n0
     O_k, K_k, N_k = ts.config3_params(K=K, N=N_total)
     N_k = N_k.copy()
     N_k[-1] += N_total - int(N_k.sum())  # keep sum(N_k) == N_total when K does not divide it
 
-    from pymbar_amd import _lib
-
     ndev = max(1, _lib.device_count())
     dev = local_rank % ndev  # one rank per GPU under the launcher; wraps only when ranks outnumber devices (testing)
     info = device_info(dev)
-    n_global0 = rank * n_loc if args.scaling == "weak" else n0_strong
-    dm = DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=n_global0, N_local=n_loc, device=dev)
+    dm = DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=n0, N_local=n_loc, device=dev)
     dm.set_option("staging", args.staging)
     dm.set_option("lse_variant", args.lse_variant)
     dm.set_option("gram_variant", args.gram_variant)
+    dm.set_option("device_loop", args.device_loop)
+    dm.set_option("graph", 0)  # eager launches: per-kernel HIP-event timers inside the timed region (the GPU queue never
+    #                            runs dry at this size: an iteration is ~5 ms of kernels against ~0.1 ms of enqueueing)
     dm.set_Nk(N_k)
     allreduce = "none"
     if world > 1:
-        from pymbar_amd.distributed import attach_allreduce
+        allreduce = attach_allreduce(dm, group)
+        if allreduce != "rccl" and not args.allow_host_allreduce:
+            if rank == 0:
+                print(f"bench.py: RCCL could not be initialised on every rank (transport would be '{allreduce}'); refusing to "
+                      "measure the host fallback", file=sys.stderr)
+            dm.close()
+            group.close()
+            sys.exit(3)
 
-        allreduce = attach_allreduce(dm)
+    def barrier_sync():
+        if group is not None:
+            group.barrier()
+        dm.device_synchronize()
 
     f0 = np.zeros(K)
     # ---- warm-up (untimed) ----
@@ -168,22 +213,23 @@ def main():
         dm.solve_adaptive(f0, tol=1e-12, maxiter=args.warmup, min_sc_iter=0, check_convergence=False)
     # ---- timed: exactly `steps` adaptive iterations ----
     dm.timing_reset()
-    barrier_sync(dm)
+    barrier_sync()
     t0 = time.perf_counter()
     f_end, res = dm.solve_adaptive(f0, tol=1e-12, maxiter=args.steps, min_sc_iter=0, check_convergence=False)
-    barrier_sync(dm)
+    barrier_sync()
     elapsed = time.perf_counter() - t0
     timing = dm.timing()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if group is not None:
+        t = np.array([elapsed])
+        group.allreduce(t, "max")
+        elapsed = float(t[0])
+    assert res["iterations"] == args.steps, res
 
     # ---- wall-clock to converge from f = 0 (reported, not the headline value) ----
-    barrier_sync(dm)
+    barrier_sync()
     t0 = time.perf_counter()
     f_conv, conv = dm.solve_adaptive(f0, tol=1e-12, maxiter=10000, min_sc_iter=0, check_convergence=True)
-    barrier_sync(dm)
+    barrier_sync()
     t_conv = time.perf_counter() - t0
     err_analytic = float(np.max(np.abs(f_conv - ts.harmonic_free_energies(K_k))))
 
@@ -193,7 +239,13 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         def factory(n):
             return DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=0, N_local=n, device=dev)
-        cpu = cpu_baseline(factory, K, n_loc, min(args.cpu_sample, n_loc), args.seed)
+        cpu = cpu_baseline(factory, K, N_total, min(args.cpu_sample, n_loc), args.seed)
+
+    e2e = None
+    if rank == 0 and world == 1 and args.api_e2e:
+        dm.close()  # the end-to-end run owns its own device copy
+        dm = None
+        e2e = api_end_to_end(K, N_total, args.seed, dev, O_k, K_k, N_k)
 
     if rank == 0:
         it_per_s = args.steps / elapsed
@@ -201,43 +253,50 @@ def main():
         lse_ms, lse_n = timing["lse"]
         gram_avg = gram_ms / max(1, gram_n)
         lse_avg = lse_ms / max(1, lse_n)
-        flops = float(n_loc) * K * (K + 1)           # symmetric Gram: K(K+1)/2 entries x 2 flop x N
+        flops = float(n_loc) * K * (K + 1)           # symmetric Gram: K(K+1)/2 entries x 2 flop x N (this rank's shard)
         bytes_pass = 8.0 * K * n_loc                 # one read of the shard per sweep
         # the adaptive loop issues 1 single-f sweep (initial gradient) + `steps` two-candidate sweeps
         achieved_tf = flops / (gram_avg * 1e-3) * 1e-12 if gram_avg > 0 else 0.0
         achieved_gbs = bytes_pass / (lse_avg * 1e-3) * 1e-9 if lse_avg > 0 else 0.0
+        ms_step = 1e3 * elapsed / args.steps
+        tr_g, src_g = pmc_traffic("k_gram<", K, n_loc)
+        tr_l, src_l = pmc_traffic("k_lse<8, 2", K, n_loc)
         out = {
             "metric": "mbar_adaptive_iterations_per_sec",
-            "value": it_per_s * (world if args.scaling == "weak" else 1),
+            "value": it_per_s,
             "unit": "iter/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": "strong" if N_total == 10_000_000 or world == 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"config3: harmonic ladder K={K}, N={n_loc} per GPU (N_total={N_total}), adaptive NR/SCI "
-                            f"iteration = MFMA Gram sweep + 2-candidate gradient sweep, fp64, generated in HBM",
+                "workload": f"{config_name}: harmonic ladder K={K}, N_total={N_total} ({n_loc} per GPU), adaptive NR/SCI "
+                            f"iteration = MFMA Gram sweep + K x K Newton solve + 2-candidate gradient sweep, device-resident, "
+                            f"fp64, generated in HBM",
                 "K": K, "N_per_gpu": n_loc, "N_total": N_total, "parallelism": f"N-sharded x{world}",
-                "allreduce": allreduce, "device": info["name"], "solver_iterations_per_sec": it_per_s,
+                "allreduce": allreduce, "device": info["name"], "adaptive_loop": "device-resident" if args.device_loop else "host-driven",
             },
             "roofline": {
                 "kernel": ({0: "k_gram_xchg<8>", 1: "k_gram_pair<8>"}.get(args.gram_variant, "k_gram<8,8> one wave per SIMD") + " (fp64 MFMA W^T W)") if K == 128 else "k_gram",
                 "bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("k_gram<", K, n_loc),
+                "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": tr_g,
+                "traffic_source": f"committed PMC pass {src_g} (not collected in this run)" if src_g else None,
                 "avg_launch_ms": gram_avg, "launches": gram_n, "algorithmic_flop_per_launch": flops,
                 "measured_mfma_f64_peak_tflops": mfma_peak,
             },
             "roofline_lse": {
                 "kernel": "k_lse<8,2> (log-sum-exp + per-state sums, 2 candidates per sweep, one exp per element)",
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("k_lse<8, 2", K, n_loc),
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": tr_l,
+                "traffic_source": f"committed PMC pass {src_l} (not collected in this run)" if src_l else None,
                 "avg_launch_ms": lse_avg, "launches": lse_n, "algorithmic_bytes_per_launch": bytes_pass,
             },
+            "ms_per_step_outside_the_two_sweeps": ms_step - gram_avg - lse_avg,
             "cpu_baseline": cpu,
             "wallclock_to_converge_s": t_conv,
             "iterations_to_converge": int(conv["iterations"]),
@@ -245,14 +304,16 @@ def main():
             "nr_iterations": int(conv["nr_iter"]), "sci_iterations": int(conv["sci_iter"]),
             "max_abs_error_vs_analytic_f": err_analytic,
             "gnorm_at_solution": float(conv["gnorm"]),
+            "api_end_to_end": e2e,
         }
         if cpu is not None:
             out["speedup_vs_cpu_baseline"] = it_per_s / cpu["value"]
         print(json.dumps(out))
-    dm.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if dm is not None:
+        dm.close()
+    if group is not None:
+        group.barrier()
+        group.close()
 
 
 if __name__ == "__main__":

@@ -64,6 +64,8 @@ int mbar_device_info(int device, char* name, int name_len, int* compute_units, i
 int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local);
 void mbar_ctx_destroy(mbar_ctx* ctx);
 int mbar_ctx_synchronize(mbar_ctx* ctx);
+/* hipDeviceSynchronize on `device` (every stream of every context): the bracket of a timed region. */
+int mbar_device_synchronize(int device);
 /* Tuning / test knobs (defaults are the measured best; every variant is parity-tested):
  *   "staging"        0 = LDS-DMA tiles (default), 1 = through registers
  *   "grid_blocks"    0 = auto
@@ -75,7 +77,9 @@ int mbar_ctx_synchronize(mbar_ctx* ctx);
  *                    0 = operand exchange between paired waves, 1 = paired waves, duplicate operands
  *   "small_k_kernel" 1 = one-sample-per-lane sweep for K <= 32, single candidate (default), 0 = off
  *   "wide_k_kernel"  1 = single-buffer sweep with four waves per CU for 129 <= K <= 256 (default), 0 = off
- *   "graph", "sci_batch", "timing"   hipGraph batching of the SCI loop; HIP-event timers (mbar_ctx_timing) */
+ *   "device_loop"    1 = adaptive iterations run device-resident where possible (default), 0 = host-driven loop
+ *   "adapt_batch"    adaptive iterations enqueued between two looks at the control words (default 8)
+ *   "graph", "sci_batch", "timing"   hipGraph batching of the solver loops; HIP-event timers (mbar_ctx_timing) */
 int mbar_ctx_set_option(mbar_ctx* ctx, const char* key, int64_t value);
 
 /* ---- data ---------------------------------------------------------------------------------- */
@@ -115,7 +119,11 @@ int mbar_ctx_comm_init(mbar_ctx* ctx, const void* id128, int rank, int nranks); 
 /* Fallback transport: fn(buf, count, op, user) must all-reduce `count` doubles in place
  * (op 0 = sum, 1 = max) across ranks on the host. */
 typedef int (*mbar_allreduce_fn)(double* buf, int64_t count, int op, void* user);
+/* Replaces an RCCL communicator if one is attached (the two transports never coexist on a context). */
 int mbar_ctx_set_host_allreduce(mbar_ctx* ctx, mbar_allreduce_fn fn, void* user, int rank, int nranks);
+/* Detach whatever transport is attached (RCCL communicator destroyed); the context is single-rank again.  When
+ * RCCL cannot be initialised on EVERY rank, every rank must call this before falling back to the host transport. */
+int mbar_ctx_comm_destroy(mbar_ctx* ctx);
 
 /* ---- L1 evaluation (replaces mbar_solvers.py L1 functions) -------- */
 /* One fused sweep of u_kn for nf (1 or 2) free-energy vectors f[nf][K]:
@@ -154,7 +162,12 @@ typedef struct mbar_solve_result {
 
 /* Adaptive NR/SCI on the states with N_k > 0 (others are left untouched).  f_inout[K].
  * history (may be NULL): rows of 4 doubles {choice(0 sci,1 nr), |g_sci|, |g_nr|, max_delta}.
- * check_convergence = 0 runs exactly maxiter iterations (benchmarking). */
+ * check_convergence = 0 runs exactly maxiter iterations (benchmarking).
+ * Up to 128 states the whole iteration is device-resident (Gram sweep, K x K Newton solve in one workgroup, candidate
+ * construction, two-candidate sweep, choice and convergence test; the host reads 8 control words per batch of
+ * iterations, replayed from a hipGraph on a single rank, with ncclAllReduce on the stream across ranks).  With the
+ * host all-reduce transport, above 128 states, or when the device hands a solve back (Newton system not positive
+ * definite, candidates > 300 kT apart, non-finite candidate) the same iteration runs host-driven. */
 int mbar_solve_adaptive(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxiter,
                         int64_t min_sc_iter, double gamma, int check_convergence,
                         double* history, int64_t history_rows, mbar_solve_result* result);

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mbar_ctx_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int64, C.c_int64]),
     "mbar_ctx_destroy": (None, [_ctx]),
     "mbar_ctx_synchronize": (C.c_int, [_ctx]),
+    "mbar_device_synchronize": (C.c_int, [C.c_int]),
     "mbar_ctx_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int64]),
     "mbar_ctx_upload_u": (C.c_int, [_ctx, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "mbar_ctx_download_u": (C.c_int, [_ctx, _dp, C.c_int64]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "mbar_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mbar_ctx_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "mbar_ctx_set_host_allreduce": (C.c_int, [_ctx, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]),
+    "mbar_ctx_comm_destroy": (C.c_int, [_ctx]),
     "mbar_eval": (C.c_int, [_ctx, _dp, C.c_int, C.c_uint, _dp, _dp, _dp]),
     "mbar_ctx_set_objective_offset": (C.c_int, [_ctx, _dp]),
     "mbar_lognum": (C.c_int, [_ctx, _dp, _dp]),

@@ -99,9 +99,18 @@ struct mbar_ctx {
     hipGraphExec_t sci_graph = nullptr;
     int64_t sci_graph_batch = 0, sci_graph_sig = 0;
     double sci_graph_tol = 0.0;
+    // device-resident adaptive loop: solver state (f, psum, candidates, ratio, parameters, history), control words and
+    // the sampled-state list live on the device; a batch of whole iterations can be replayed from a hipGraph
+    double* ad = nullptr;
+    int64_t ad_hist_cap = 0;
+    int* ad_ints = nullptr;         // ctl[CTL_WORDS] | sampled[Kp]
+    int* h_ctl = nullptr;           // pinned mirror of the control words
+    hipGraphExec_t ad_graph = nullptr;
+    int64_t ad_graph_batch = 0, ad_graph_sig = 0;
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8;
     // comm
     ncclComm_t comm = nullptr;
     mbar_allreduce_fn host_reduce = nullptr;
@@ -184,12 +193,23 @@ int sync_stream(mbar_ctx* c) {
 int refresh_poison(mbar_ctx* c);
 
 // ---- device buffer helpers -------------------------------------------------------------------
-int ensure(mbar_ctx* c, double** p, size_t* have, size_t want) {
-    if (*have >= want) return MBAR_OK;
-    if (c->sci_graph) {  // a captured SCI batch holds the old pointers
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+int drop_graphs(mbar_ctx* c) {  // captured batches hold buffer pointers, sizes and the sampled-state set
+    if (c->sci_graph || c->ad_graph) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->sci_graph) {
         HIPCHK(c, hipGraphExecDestroy(c->sci_graph));
         c->sci_graph = nullptr;
+    }
+    if (c->ad_graph) {
+        HIPCHK(c, hipGraphExecDestroy(c->ad_graph));
+        c->ad_graph = nullptr;
+    }
+    return MBAR_OK;
+}
+int ensure(mbar_ctx* c, double** p, size_t* have, size_t want) {
+    if (*have >= want) return MBAR_OK;
+    {
+        int rc = drop_graphs(c);
+        if (rc) return rc;
     }
     if (*p) HIPCHK(c, hipFree(*p));
     *p = nullptr;
@@ -208,6 +228,7 @@ inline double* d_delta(mbar_ctx* c) { return c->small + 6 * c->Kp; }         // 
 inline double* d_misc(mbar_ctx* c) { return c->small + 6 * c->Kp + 256; }    // [4*Kp]
 inline size_t small_doubles(int64_t Kp) { return (size_t)(10 * Kp + 256); }
 
+int allreduce_host(mbar_ctx* c, double* host, int64_t count, int op);
 int refresh_poison(mbar_ctx* c) {
     if (c->u_checked) return MBAR_OK;
     int* dflags = reinterpret_cast<int*>(d_delta(c) + 255);
@@ -216,6 +237,14 @@ int refresh_poison(mbar_ctx* c) {
     int h = 0;
     HIPCHK(c, hipMemcpyAsync(&h, dflags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->nranks > 1) {
+        // a NaN in ONE shard poisons the sums of every rank: agree on the flag, so that all ranks take the same early
+        // return (a clean rank would otherwise wait in the all-reduce of a sweep the poisoned rank never launches)
+        double v = (double)h;
+        int rc = allreduce_host(c, &v, 1, 1);
+        if (rc) return rc;
+        h = (int)v;
+    }
     c->u_poison = h != 0;
     c->u_checked = true;
     return MBAR_OK;
@@ -487,6 +516,10 @@ void unpack_gram(const GramPlan& plan, const double* blocks, int64_t K, double* 
 
 int ensure_red(mbar_ctx* c, size_t want) {
     if (c->red_doubles >= want) return MBAR_OK;
+    {
+        int rc = drop_graphs(c);
+        if (rc) return rc;
+    }
     if (c->red) HIPCHK(c, hipFree(c->red));
     if (c->hred) HIPCHK(c, hipHostFree(c->hred));
     c->red = nullptr;
@@ -707,6 +740,378 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// ---- adaptive loop -------------------------------------------------------------------------------
+// Host-driven loop (mbar_solvers.py:575-640): the K x K solve, the candidate construction and the convergence test run
+// on the host between the two sweeps.  Used with the host all-reduce transport, for more than 128 states, for the
+// non-default kernel variants, and as the continuation when the device-resident loop hands a solve back.
+// `res` carries the counters of the iterations already executed; `f` in/out; psum at the returned f in `psum`.
+int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t maxiter, int64_t min_sc_iter, double gamma,
+                       int check_convergence, double* history, int64_t history_rows, mbar_solve_result& res,
+                       std::vector<double>& psum, double& max_delta) {
+    const int64_t K = c->K;
+    const int m = (int)c->sampled.size();
+    const int first = c->sampled[0];
+    std::vector<double> f_old(K), cand(2 * (size_t)K), psum2(2 * (size_t)K);
+    std::vector<double> gram((size_t)K * K), H((size_t)m * m), g(m), x;
+    psum.assign(K, 0.0);
+    int cur = 0;  // logden slot of the current f
+    // initial gradient (mbar_solvers.py:570)
+    int rc = eval_core(c, f.data(), 1, 0, c->logden[cur], nullptr, psum.data(), nullptr, nullptr);
+    if (rc) return rc;
+    bool done = false;
+    const GramPlan plan = gram_plan(c->Kp);
+    const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
+    double tA = 0, tH = 0, tB = 0;
+    const int64_t it0 = res.iterations;
+    const double t0 = now_ms();
+    for (int64_t it = it0; it < maxiter && !done; ++it) {
+        // ---- pass A: Gram at f with the known logden -> Hessian (mbar_solvers.py:581) ----
+        const double t_a0 = now_ms();
+        {
+            const size_t n_gram = plan.total_blocks * 256, total = n_gram;
+            rc = ensure_red(c, total);
+            if (rc) return rc;
+            std::vector<double> an((size_t)c->Kp);
+            build_aden(c, f.data(), an.data(), c->Kp);
+            std::copy(an.begin(), an.end(), c->hstage + 2 * c->Kp);
+            HIPCHK(c, hipMemcpyAsync(d_anum(c), c->hstage + 2 * c->Kp, an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            rc = run_gram(c, d_anum(c), c->logden[cur], 0, plan);
+            if (rc) return rc;
+            rc = allreduce_dev(c, c->red, (int64_t)total, 0);
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            rc = sync_stream(c);
+            if (rc) return rc;
+            unpack_gram(plan, c->hred, K, gram.data());
+        }
+        const double t_a1 = now_ms();
+        for (int i = 0; i < m; ++i) {
+            const int ki = c->sampled[i];
+            g[i] = psum[ki] - c->Nk[ki];
+            for (int j = 0; j < m; ++j) H[(size_t)i * m + j] = -gram[(size_t)ki * K + c->sampled[j]];
+            H[(size_t)i * m + i] += psum[ki];
+        }
+        newton_direction(H, g, m, x);  // :582-583
+        double* f_sci = cand.data();
+        double* f_nr = cand.data() + K;
+        std::copy(f.begin(), f.end(), f_sci);
+        std::copy(f.begin(), f.end(), f_nr);
+        for (int i = 0; i < m; ++i) {
+            const int k = c->sampled[i];
+            f_nr[k] = f[k] - gamma * x[i];                         // :584
+            f_sci[k] = f[k] - std::log(psum[k] / c->Nk[k]);        // :587 via s_k
+        }
+        const double shift = f_sci[first];
+        for (int i = 0; i < m; ++i) f_sci[c->sampled[i]] -= shift;  // :588
+        // ---- pass B: both candidates in one sweep (:589-594) ----
+        const double t_b0 = now_ms();
+        const int sA = (cur + 1) % 3, sB = (cur + 2) % 3;
+        rc = eval_core(c, cand.data(), 2, 0, c->logden[sA], c->logden[sB], psum2.data(), nullptr, nullptr);
+        if (rc) return rc;
+        const double t_b1 = now_ms();
+        tA += t_a1 - t_a0; tH += t_b0 - t_a1; tB += t_b1 - t_b0;
+        double gn_sci = 0.0, gn_nr = 0.0;
+        for (int i = 0; i < m; ++i) {
+            const int k = c->sampled[i];
+            const double a = psum2[k] - c->Nk[k], b = psum2[K + k] - c->Nk[k];
+            gn_sci += a * a;
+            gn_nr += b * b;
+        }
+        f_old = f;
+        int choice;
+        // (every rank holds bit-identical reduced sums, so this choice needs no collective; only the loop exit below
+        // is agreed on explicitly, because a desynchronised exit would strand the other ranks in an all-reduce)
+        const bool take_sci = gn_sci < gn_nr || res.sci_iter < min_sc_iter;
+        if (take_sci) {  // :607
+            std::copy(f_sci, f_sci + K, f.begin());
+            std::copy(psum2.begin(), psum2.begin() + K, psum.begin());
+            cur = sA;
+            res.sci_iter++;
+            choice = 0;
+        } else {
+            std::copy(f_nr, f_nr + K, f.begin());
+            std::copy(psum2.begin() + K, psum2.end(), psum.begin());
+            cur = sB;
+            res.nr_iter++;
+            choice = 1;
+        }
+        // convergence measures on the sampled states except the first (:627-633)
+        const double small = std::min(1e-8, tol);
+        max_delta = 0.0;
+        double max_diff = 0.0;
+        bool nan_seen = false;
+        for (int i = 1; i < m; ++i) {
+            const int k = c->sampled[i];
+            const double div = std::fabs(f[k]) < small ? 1.0 : std::fabs(f[k]);
+            const double d1 = std::fabs(f[k] - f_old[k]) / div, d2 = std::fabs(f_sci[k] - f_nr[k]) / div;
+            if (std::isnan(d1)) nan_seen = true;
+            max_delta = std::max(max_delta, d1);
+            max_diff = std::max(max_diff, d2);
+        }
+        if (nan_seen) max_delta = std::numeric_limits<double>::quiet_NaN();
+        res.iterations = it + 1;
+        if (history && it < history_rows) {
+            history[4 * it + 0] = choice;
+            history[4 * it + 1] = std::sqrt(gn_sci);
+            history[4 * it + 2] = std::sqrt(gn_nr);
+            history[4 * it + 3] = max_delta;
+        }
+        double stop = (check_convergence && (std::isnan(max_delta) || (max_delta < tol && max_diff < std::sqrt(tol)))) ? 1.0 : 0.0;  // :636
+        if (check_convergence) {
+            rc = agree_with_rank0(c, &stop, 1);
+            if (rc) return rc;
+        }
+        if (stop > 0.5) {
+            res.success = 1;
+            done = true;
+        }
+    }
+    const int64_t nit = res.iterations - it0;
+    if (dbg && nit > 0)
+        std::fprintf(stderr, "[mbar] adaptive (host loop): %lld it, per it: passA %.3f ms, host solve %.3f ms, passB %.3f ms, total %.3f ms\n",
+                     (long long)nit, tA / nit, tH / nit, tB / nit, (now_ms() - t0) / nit);
+    return MBAR_OK;
+}
+
+// Device-resident loop: one iteration = {Gram sweep, reduction, [all-reduce], k_newton, two-candidate sweep, reduction,
+// [all-reduce], k_select}, enqueued back to back (or replayed from a hipGraph in batches); f, the candidates, the choice
+// and the convergence test never leave the device, and the host reads eight control words per batch.  Iterations
+// enqueued past convergence are no-ops (every kernel looks at CTL_DONE first).
+bool device_loop_eligible(const mbar_ctx* c) {
+    if (!c->opt_device_loop || !use_fast(c) || c->Kp > 128) return false;
+    if (c->nranks > 1 && !c->comm) return false;  // the host transport needs the host in the loop
+    if (c->Kp == 128 && gram_variant_for(c) != 2) return false;
+    const int64_t ntiles = (c->N + TS - 1) / TS;
+    const LaunchGeom gl = lse_geometry((int)(c->Kp / 16), 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+    return gl.variant == 1;
+}
+
+inline size_t ad_off_f(const mbar_ctx*) { return 0; }
+inline size_t ad_off_psum(const mbar_ctx* c) { return (size_t)c->Kp; }
+inline size_t ad_off_cand(const mbar_ctx* c) { return (size_t)2 * c->Kp; }
+inline size_t ad_off_ratio(const mbar_ctx* c) { return (size_t)4 * c->Kp; }
+inline size_t ad_off_prm(const mbar_ctx* c) { return (size_t)5 * c->Kp; }
+inline size_t ad_off_state(const mbar_ctx* c) { return (size_t)5 * c->Kp + 4; }
+inline size_t ad_off_hist(const mbar_ctx* c) { return (size_t)5 * c->Kp + 8; }
+
+int ensure_ad(mbar_ctx* c, int64_t hist_rows) {
+    const int64_t cap = std::max<int64_t>(1024, std::min<int64_t>(hist_rows, 1 << 20));
+    if (!c->ad || c->ad_hist_cap < cap) {
+        int rc = drop_graphs(c);
+        if (rc) return rc;
+        if (c->ad) HIPCHK(c, hipFree(c->ad));
+        c->ad = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->ad, (ad_off_hist(c) + (size_t)4 * cap) * sizeof(double)));
+        c->ad_hist_cap = cap;
+    }
+    if (!c->ad_ints) HIPCHK(c, hipMalloc((void**)&c->ad_ints, (size_t)(CTL_WORDS + c->Kp) * sizeof(int)));
+    if (!c->h_ctl) HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, (size_t)CTL_WORDS * sizeof(int), hipHostMallocDefault));
+    return MBAR_OK;
+}
+
+// Returns MBAR_OK with handed_back = true when the loop stopped early for the host loop to continue (f, res updated).
+int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t maxiter, int64_t min_sc_iter, double gamma,
+                         int check_convergence, double* history, int64_t history_rows, mbar_solve_result& res,
+                         std::vector<double>& psum, double& max_delta, bool& handed_back) {
+    const int64_t K = c->K, Kp = c->Kp;
+    const int m = (int)c->sampled.size();
+    const int nb = (int)(Kp / 16);
+    const int64_t ntiles = (c->N + TS - 1) / TS;
+    const bool dma = c->opt_staging == 0;
+    handed_back = false;
+    // initial gradient (mbar_solvers.py:570); leaves logden(f) in slot 0
+    psum.assign(K, 0.0);
+    int rc = eval_core(c, f.data(), 1, 0, c->logden[0], nullptr, psum.data(), nullptr, nullptr);
+    if (rc) return rc;
+    rc = ensure_ad(c, history ? history_rows : 0);
+    if (rc) return rc;
+    // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
+    const LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
+    const LaunchGeom gl = lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+    const size_t rec_g = (size_t)nb * (nb + 1) / 2 * 256;
+    const size_t rec_l = (size_t)2 * Kp;
+    const size_t off_gram = rec_l + 2;
+    rc = ensure_red(c, off_gram + rec_g);
+    if (rc) return rc;
+    rc = ensure(c, &c->part, &c->part_doubles, std::max((size_t)gg.nwaves * rec_g, (size_t)gl.nwaves * (rec_l + 2)));
+    if (rc) return rc;
+    rc = ensure(c, &c->scratch, &c->scratch_doubles,
+                std::max(((size_t)gg.nwaves / 32 + 1) * rec_g, ((size_t)gl.nwaves / 32 + 1) * (rec_l + 2)));
+    if (rc) return rc;
+    if (c->weighted && !c->lden_eff) return fail(c, MBAR_ERR_STATE, "weighted context without its logden buffer");
+
+    // ---- solver state to the device ----
+    {
+        std::vector<double> h(ad_off_hist(c), 0.0);
+        for (int64_t k = 0; k < K; ++k) {
+            h[ad_off_f(c) + k] = f[k];
+            h[ad_off_psum(c) + k] = psum[k];
+        }
+        h[ad_off_prm(c) + 0] = gamma;
+        h[ad_off_prm(c) + 1] = tol;
+        h[ad_off_prm(c) + 2] = (double)std::min<int64_t>(min_sc_iter, 1 << 30);
+        h[ad_off_prm(c) + 3] = check_convergence ? 1.0 : 0.0;
+        h[ad_off_state(c)] = std::numeric_limits<double>::quiet_NaN();
+        std::vector<int> hi((size_t)CTL_WORDS + Kp, 0);
+        hi[CTL_ITER] = (int)res.iterations;
+        hi[CTL_SCI] = (int)res.sci_iter;
+        hi[CTL_NR] = (int)res.nr_iter;
+        for (int i = 0; i < m; ++i) hi[CTL_WORDS + i] = c->sampled[i];
+        std::vector<double> an((size_t)Kp);
+        build_aden(c, f.data(), an.data(), Kp);
+        HIPCHK(c, hipMemcpyAsync(c->ad, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ad_ints, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    AdaptArgs q;
+    q.gram_red = c->red + off_gram;
+    q.lse_red = c->red;
+    q.f = c->ad + ad_off_f(c);
+    q.psum = c->ad + ad_off_psum(c);
+    q.cand = c->ad + ad_off_cand(c);
+    q.ratio = c->ad + ad_off_ratio(c);
+    q.aden = d_aden(c);
+    q.anum = d_anum(c);
+    q.Nk = d_Nk(c);
+    q.lnNk = d_lnNk(c);
+    q.sampled = c->ad_ints + CTL_WORDS;
+    q.m = m;
+    q.K = (int)K;
+    q.Kp = (int)Kp;
+    q.ctl = c->ad_ints;
+    q.prm = c->ad + ad_off_prm(c);
+    q.state = c->ad + ad_off_state(c);
+    q.hist = c->ad + ad_off_hist(c);
+    q.hist_cap = c->ad_hist_cap;
+    const LoopCtl lc_slot{c->ad_ints, c->ld}, lc_flat{c->ad_ints, 0};
+
+    auto enqueue_iteration = [&](bool timed) -> int {
+        // ---- pass A: Gram at f with the known logden (the slot of the accepted candidate) ----
+        const double* lden = c->logden[0];
+        LoopCtl lca = lc_slot;
+        if (c->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent
+            HIPCHK(c, launch_shift_logden(c->stream, c->logden[0], c->cw, 0.5, c->N, c->lden_eff, lc_slot));
+            lden = c->lden_eff;
+            lca = lc_flat;
+        }
+        {
+            TimerPair tp{nullptr, nullptr, MBAR_TIMER_GRAM};
+            if (timed) { tp.a = get_event(c); tp.b = get_event(c); }
+            if (tp.a && tp.b) (void)hipEventRecord(tp.a, c->stream);
+            HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, c->u, c->ld, c->N, d_anum(c), lden, 0, c->part, nullptr, lca));
+            if (tp.a && tp.b) { (void)hipEventRecord(tp.b, c->stream); c->pending.push_back(tp); }
+        }
+        HIPCHK(c, launch_reduce(c->stream, c->part, gg.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
+        if (c->comm) {
+            int r2 = allreduce_dev(c, c->red + off_gram, (int64_t)rec_g, 0);
+            if (r2) return r2;
+        }
+        HIPCHK(c, launch_newton(c->stream, q));
+        // ---- pass B: both candidates in one sweep ----
+        double* psum_part = c->part;
+        double* obj_part = c->part + (size_t)gl.nwaves * rec_l;
+        {
+            TimerPair tp{nullptr, nullptr, MBAR_TIMER_LSE};
+            if (timed) { tp.a = get_event(c); tp.b = get_event(c); }
+            if (tp.a && tp.b) (void)hipEventRecord(tp.a, c->stream);
+            HIPCHK(c, launch_lse(c->stream, nb, 2, dma, gl, c->u, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, nullptr,
+                                 psum_part, obj_part, lc_slot));
+            if (tp.a && tp.b) { (void)hipEventRecord(tp.b, c->stream); c->pending.push_back(tp); }
+        }
+        HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, obj_part, 2, gl.nwaves, c->scratch, c->red, c->red + rec_l));
+        if (c->comm) {
+            int r2 = allreduce_dev(c, c->red, (int64_t)(rec_l + 2), 0);
+            if (r2) return r2;
+        }
+        HIPCHK(c, launch_select(c->stream, q));
+        return MBAR_OK;
+    };
+
+    const int64_t batch = c->opt_adapt_batch;
+    const bool use_graph = c->opt_graph && !c->comm && (maxiter - res.iterations) >= batch;
+    if (use_graph) {
+        const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 8) ^ (c->weighted ? 4 : 0) ^
+                            (c->opt_staging ? 2 : 0) ^ (int64_t)nb;
+        if (!c->ad_graph || c->ad_graph_batch != batch || c->ad_graph_sig != sig) {
+            if (c->ad_graph) HIPCHK(c, hipGraphExecDestroy(c->ad_graph));
+            c->ad_graph = nullptr;
+            // eager warm-up with the stop flag raised: every kernel is launched once outside the capture (function
+            // attributes, module loading) and does nothing
+            int one = 1;
+            HIPCHK(c, hipMemcpyAsync(c->ad_ints + CTL_DONE, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+            rc = enqueue_iteration(false);
+            if (rc) return rc;
+            int zero = 0;
+            HIPCHK(c, hipMemcpyAsync(c->ad_ints + CTL_DONE, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipGraph_t graph = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int crc = MBAR_OK;
+            for (int64_t b = 0; b < batch && crc == MBAR_OK; ++b) crc = enqueue_iteration(false);
+            hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+            if (crc) return crc;
+            if (ee != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+            ee = hipGraphInstantiate(&c->ad_graph, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ee != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ee));
+            c->ad_graph_batch = batch;
+            c->ad_graph_sig = sig;
+        }
+    }
+    int64_t it = res.iterations;
+    bool done = false;
+    while (it < maxiter && !done) {
+        const int64_t nbat = std::min(batch, maxiter - it);
+        if (use_graph && nbat == batch) {
+            HIPCHK(c, hipGraphLaunch(c->ad_graph, c->stream));
+        } else {
+            for (int64_t b = 0; b < nbat; ++b) {
+                rc = enqueue_iteration(c->opt_timing != 0);
+                if (rc) return rc;
+            }
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ad_ints, CTL_WORDS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        rc = sync_stream(c);
+        if (rc) return rc;
+        const int64_t it_new = c->h_ctl[CTL_ITER];
+        if (c->h_ctl[CTL_DONE] == 1) {
+            res.success = 1;
+            done = true;
+        } else if (c->h_ctl[CTL_DONE] == 2) {
+            handed_back = true;
+            done = true;
+        } else if (it_new != it + nbat) {
+            return fail(c, MBAR_ERR_STATE, "device-resident adaptive loop lost count of its iterations");
+        }
+        it = it_new;
+    }
+    // ---- results back ----
+    {
+        std::vector<double> h(ad_off_hist(c));
+        HIPCHK(c, hipMemcpyAsync(h.data(), c->ad, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        const int64_t rows = history ? std::min<int64_t>(std::min<int64_t>(it, history_rows), c->ad_hist_cap) : 0;
+        if (rows > 0)
+            HIPCHK(c, hipMemcpyAsync(history, c->ad + ad_off_hist(c), (size_t)rows * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t k = 0; k < K; ++k) {
+            f[k] = h[ad_off_f(c) + k];
+            psum[k] = h[ad_off_psum(c) + k];
+        }
+        if (it > res.iterations) max_delta = h[ad_off_state(c)];
+    }
+    res.iterations = it;
+    res.sci_iter = c->h_ctl[CTL_SCI];
+    res.nr_iter = c->h_ctl[CTL_NR];
+    if (handed_back) {
+        static const char* why[] = {"", "the Newton system is not positive definite", "the candidates are too far apart for the fused sweep",
+                                    "a candidate is not finite"};
+        const int r = c->h_ctl[CTL_REASON];
+        c->error = std::string("device-resident adaptive loop handed back to the host loop: ") + why[(r >= 1 && r <= 3) ? r : 0];
+    }
+    return MBAR_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -779,10 +1184,11 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
     const size_t ubytes = (size_t)c->Kp * c->ld * sizeof(double);
     CRT(hipMalloc((void**)&c->u, ubytes));
     CRT(hipMemsetAsync(c->u, 0, ubytes, c->stream));
-    for (int i = 0; i < 3; ++i) {
-        CRT(hipMalloc((void**)&c->logden[i], (size_t)c->ld * sizeof(double)));
-        CRT(hipMemsetAsync(c->logden[i], 0, (size_t)c->ld * sizeof(double), c->stream));
-    }
+    // three logden vectors in ONE allocation: the device-resident loop addresses them as base + slot * ld
+    CRT(hipMalloc((void**)&c->logden[0], (size_t)3 * c->ld * sizeof(double)));
+    CRT(hipMemsetAsync(c->logden[0], 0, (size_t)3 * c->ld * sizeof(double), c->stream));
+    c->logden[1] = c->logden[0] + c->ld;
+    c->logden[2] = c->logden[0] + 2 * c->ld;
     CRT(hipMalloc((void**)&c->cw, (size_t)c->ld * sizeof(double)));
     CRT(hipMemsetAsync(c->cw, 0, (size_t)c->ld * sizeof(double), c->stream));
     {
@@ -809,8 +1215,11 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->u) (void)hipFree(c->u);
-    for (int i = 0; i < 3; ++i)
-        if (c->logden[i]) (void)hipFree(c->logden[i]);
+    if (c->logden[0]) (void)hipFree(c->logden[0]);
+    if (c->ad) (void)hipFree(c->ad);
+    if (c->ad_ints) (void)hipFree(c->ad_ints);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->ad_graph) (void)hipGraphExecDestroy(c->ad_graph);
     if (c->dn) (void)hipFree(c->dn);
     if (c->cw) (void)hipFree(c->cw);
     if (c->lden_eff) (void)hipFree(c->lden_eff);
@@ -834,6 +1243,13 @@ int mbar_ctx_synchronize(mbar_ctx* c) {
     return sync_stream(c);
 }
 
+int mbar_device_synchronize(int device) {
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(nullptr, MBAR_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
+    return MBAR_OK;
+}
+
 int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return fail(c, MBAR_ERR_ARG, "NULL argument");
     const std::string k(key);
@@ -848,6 +1264,8 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "lse_variant") c->opt_lse_variant = value;
     else if (k == "gram_variant") c->opt_gram_variant = value;
     else if (k == "sci_batch") c->opt_sci_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
+    else if (k == "device_loop") c->opt_device_loop = value;
+    else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;
 }
@@ -947,6 +1365,10 @@ int mbar_ctx_set_Nk(mbar_ctx* c, const double* N_k) {
     }
     if (c->sampled.empty()) return fail(c, MBAR_ERR_ARG, "at least one state must have samples");
     HIPCHK(c, hipSetDevice(c->device));
+    {
+        int rc = drop_graphs(c);  // the captured adaptive batch bakes in the sampled-state count
+        if (rc) return rc;
+    }
     std::vector<double> h(2 * (size_t)c->Kp, 0.0);
     for (int64_t k = 0; k < c->Kp; ++k) {
         h[k] = k < c->K ? c->Nk[k] : 0.0;
@@ -1006,11 +1428,35 @@ int mbar_ctx_comm_init(mbar_ctx* c, const void* id128, int rank, int nranks) {
     c->comm = comm;
     c->rank = rank;
     c->nranks = nranks;
+    c->u_checked = false;  // the NaN / -inf flag of the matrix becomes a cross-rank property
     return MBAR_OK;
+}
+
+int mbar_ctx_comm_destroy(mbar_ctx* c) {
+    if (!c) return fail(c, MBAR_ERR_ARG, "ctx is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+    c->host_reduce = nullptr;
+    c->host_reduce_user = nullptr;
+    c->rank = 0;
+    c->nranks = 1;
+    c->u_checked = false;
+    return drop_graphs(c);
 }
 
 int mbar_ctx_set_host_allreduce(mbar_ctx* c, mbar_allreduce_fn fn, void* user, int rank, int nranks) {
     if (!c || nranks < 1 || rank < 0 || rank >= nranks || (!fn && nranks > 1)) return fail(c, MBAR_ERR_ARG, "bad argument");
+    if (c->comm) {
+        // the host transport REPLACES an RCCL communicator: a rank that kept issuing ncclAllReduce while its peers
+        // reduce on the host would deadlock every later sweep
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->u_checked = false;
     c->host_reduce = fn;
     c->host_reduce_user = user;
     c->rank = rank;
@@ -1185,123 +1631,26 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_ms();
     const int64_t K = c->K;
-    const int m = (int)c->sampled.size();
-    const int first = c->sampled[0];
-    std::vector<double> f(f_inout, f_inout + K), f_old(K), cand(2 * (size_t)K), psum(K), psum2(2 * (size_t)K);
-    std::vector<double> gram((size_t)K * K), H((size_t)m * m), g(m), x;
+    std::vector<double> f(f_inout, f_inout + K), psum;
     mbar_solve_result res;
     std::memset(&res, 0, sizeof(res));
-    int cur = 0;  // logden slot of the current f
-    // initial gradient (mbar_solvers.py:570)
-    int rc = eval_core(c, f.data(), 1, 0, c->logden[cur], nullptr, psum.data(), nullptr, nullptr);
-    if (rc) return rc;
     double max_delta = std::numeric_limits<double>::quiet_NaN();
-    bool done = false;
-    const GramPlan plan = gram_plan(c->Kp);
-    const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
-    double tA = 0, tH = 0, tB = 0;
-    for (int64_t it = 0; it < maxiter && !done; ++it) {
-        // ---- pass A: Gram at f with the known logden -> Hessian (mbar_solvers.py:581) ----
-        const double t_a0 = now_ms();
-        {
-            const size_t n_gram = plan.total_blocks * 256, total = n_gram;
-            rc = ensure_red(c, total);
-            if (rc) return rc;
-            std::vector<double> an((size_t)c->Kp);
-            build_aden(c, f.data(), an.data(), c->Kp);
-            std::copy(an.begin(), an.end(), c->hstage + 2 * c->Kp);
-            HIPCHK(c, hipMemcpyAsync(d_anum(c), c->hstage + 2 * c->Kp, an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            rc = run_gram(c, d_anum(c), c->logden[cur], 0, plan);
-            if (rc) return rc;
-            rc = allreduce_dev(c, c->red, (int64_t)total, 0);
-            if (rc) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            rc = sync_stream(c);
-            if (rc) return rc;
-            unpack_gram(plan, c->hred, K, gram.data());
-        }
-        const double t_a1 = now_ms();
-        for (int i = 0; i < m; ++i) {
-            const int ki = c->sampled[i];
-            g[i] = psum[ki] - c->Nk[ki];
-            for (int j = 0; j < m; ++j) H[(size_t)i * m + j] = -gram[(size_t)ki * K + c->sampled[j]];
-            H[(size_t)i * m + i] += psum[ki];
-        }
-        newton_direction(H, g, m, x);  // :582-583
-        double* f_sci = cand.data();
-        double* f_nr = cand.data() + K;
-        std::copy(f.begin(), f.end(), f_sci);
-        std::copy(f.begin(), f.end(), f_nr);
-        for (int i = 0; i < m; ++i) {
-            const int k = c->sampled[i];
-            f_nr[k] = f[k] - gamma * x[i];                         // :584
-            f_sci[k] = f[k] - std::log(psum[k] / c->Nk[k]);        // :587 via s_k
-        }
-        const double shift = f_sci[first];
-        for (int i = 0; i < m; ++i) f_sci[c->sampled[i]] -= shift;  // :588
-        // ---- pass B: both candidates in one sweep (:589-594) ----
-        const double t_b0 = now_ms();
-        const int sA = (cur + 1) % 3, sB = (cur + 2) % 3;
-        rc = eval_core(c, cand.data(), 2, 0, c->logden[sA], c->logden[sB], psum2.data(), nullptr, nullptr);
+    int rc = refresh_poison(c);
+    if (rc) return rc;
+    bool on_device = device_loop_eligible(c) && !c->u_poison && f_is_finite(c, f.data(), 1) && maxiter > 0;
+    if (on_device) {
+        bool handed_back = false;
+        rc = adaptive_device_loop(c, f, tol, maxiter, min_sc_iter, gamma, check_convergence, history, history_rows, res, psum,
+                                  max_delta, handed_back);
         if (rc) return rc;
-        const double t_b1 = now_ms();
-        tA += t_a1 - t_a0; tH += t_b0 - t_a1; tB += t_b1 - t_b0;
-        double gn_sci = 0.0, gn_nr = 0.0;
-        for (int i = 0; i < m; ++i) {
-            const int k = c->sampled[i];
-            const double a = psum2[k] - c->Nk[k], b = psum2[K + k] - c->Nk[k];
-            gn_sci += a * a;
-            gn_nr += b * b;
-        }
-        f_old = f;
-        int choice;
-        // (every rank holds bit-identical reduced sums, so this choice needs no collective; only the loop exit below
-        // is agreed on explicitly, because a desynchronised exit would strand the other ranks in an all-reduce)
-        const bool take_sci = gn_sci < gn_nr || res.sci_iter < min_sc_iter;
-        if (take_sci) {  // :607
-            std::copy(f_sci, f_sci + K, f.begin());
-            std::copy(psum2.begin(), psum2.begin() + K, psum.begin());
-            cur = sA;
-            res.sci_iter++;
-            choice = 0;
-        } else {
-            std::copy(f_nr, f_nr + K, f.begin());
-            std::copy(psum2.begin() + K, psum2.end(), psum.begin());
-            cur = sB;
-            res.nr_iter++;
-            choice = 1;
-        }
-        // convergence measures on the sampled states except the first (:627-633)
-        const double small = std::min(1e-8, tol);
-        max_delta = 0.0;
-        double max_diff = 0.0;
-        bool nan_seen = false;
-        for (int i = 1; i < m; ++i) {
-            const int k = c->sampled[i];
-            const double div = std::fabs(f[k]) < small ? 1.0 : std::fabs(f[k]);
-            const double d1 = std::fabs(f[k] - f_old[k]) / div, d2 = std::fabs(f_sci[k] - f_nr[k]) / div;
-            if (std::isnan(d1)) nan_seen = true;
-            max_delta = std::max(max_delta, d1);
-            max_diff = std::max(max_diff, d2);
-        }
-        if (nan_seen) max_delta = std::numeric_limits<double>::quiet_NaN();
-        res.iterations = it + 1;
-        if (history && it < history_rows) {
-            history[4 * it + 0] = choice;
-            history[4 * it + 1] = std::sqrt(gn_sci);
-            history[4 * it + 2] = std::sqrt(gn_nr);
-            history[4 * it + 3] = max_delta;
-        }
-        double stop = (check_convergence && (std::isnan(max_delta) || (max_delta < tol && max_diff < std::sqrt(tol)))) ? 1.0 : 0.0;  // :636
-        if (check_convergence) {
-            rc = agree_with_rank0(c, &stop, 1);
-            if (rc) return rc;
-        }
-        if (stop > 0.5) {
-            res.success = 1;
-            done = true;
-        }
+        on_device = !handed_back;
     }
+    if (!on_device && !res.success) {
+        rc = adaptive_host_loop(c, f, tol, maxiter, min_sc_iter, gamma, check_convergence, history, history_rows, res, psum,
+                                max_delta);
+        if (rc) return rc;
+    }
+    const int m = (int)c->sampled.size();
     double gn = 0.0;
     for (int i = 0; i < m; ++i) {
         const int k = c->sampled[i];
@@ -1310,10 +1659,9 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     res.gnorm = std::sqrt(gn);
     res.max_delta = max_delta;
     res.wall_ms = now_ms() - t0;
-    if (dbg && res.iterations > 0)
-        std::fprintf(stderr, "[mbar] adaptive: %lld it, per it: passA %.3f ms, host solve %.3f ms, passB %.3f ms, total %.3f ms\n",
-                     (long long)res.iterations, tA / res.iterations, tH / res.iterations, tB / res.iterations,
-                     res.wall_ms / res.iterations);
+    if (std::getenv("MBAR_DEBUG_TIMING") && res.iterations > 0)
+        std::fprintf(stderr, "[mbar] adaptive: %lld iterations, %.3f ms per iteration (%s loop)\n", (long long)res.iterations,
+                     res.wall_ms / res.iterations, on_device ? "device-resident" : "host-driven");
     std::copy(f.begin(), f.end(), f_inout);
     if (result) *result = res;
     return MBAR_OK;

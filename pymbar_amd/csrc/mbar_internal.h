@@ -24,6 +24,25 @@ inline int lse_nb_for(int64_t Kp) {
     return 0;
 }
 
+// Control words of the device-resident solver loop (ints in device memory).  Kernels that are handed a pointer to them
+// exit at once when CTL_DONE is set (iterations enqueued past convergence are no-ops) and pick the logden vector of the
+// current f from three rotating slots (base + slot * slot_stride), so that a whole iteration can be enqueued -- or
+// replayed from a hipGraph -- without the host knowing which candidate the previous one accepted.
+enum : int {
+    CTL_SLOT = 0,    // logden slot of the current f
+    CTL_DONE = 1,    // 0 = running, 1 = converged, 2 = handed back to the host (CTL_REASON says why)
+    CTL_ITER = 2,    // iterations executed
+    CTL_SCI = 3,     // ... of which self-consistent steps were accepted
+    CTL_NR = 4,      // ... of which Newton-Raphson steps were accepted
+    CTL_REASON = 5,  // 1 = Newton system not positive definite, 2 = candidates too far apart for the fused sweep,
+                     // 3 = non-finite candidate
+    CTL_WORDS = 8
+};
+struct LoopCtl {
+    const int* ctl = nullptr;
+    int64_t slot_stride = 0;
+};
+
 struct LaunchGeom {
     int blocks;        // grid size
     int waves;         // waves per block
@@ -41,7 +60,7 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g,
                       const double* u, int64_t ld, int64_t N, const double* aden /*[nf][16nb]*/,
                       const double* cw, double* logden0, double* logden1, const double* dn,
-                      double* psum_part, double* obj_part);
+                      double* psum_part, double* obj_part, const LoopCtl& lc = LoopCtl());
 
 // ---- Gram pass (known logden) ------------------------------------------------------------------
 // Diagonal panel: states [row0, row0+16nb) against themselves, nblk = nb(nb+1)/2 blocks, block b
@@ -53,7 +72,8 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
 hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n);  // row[i] -= v[i]
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u,
                             int64_t ld, int64_t N, const double* anum /*indexed from row0*/,
-                            const double* logden, int64_t row0, double* gram_part, double* psum_part);
+                            const double* logden, int64_t row0, double* gram_part, double* psum_part,
+                            const LoopCtl& lc = LoopCtl());
 hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
                            int64_t N, const double* anum_i, const double* anum_j, const double* logden,
                            int64_t row_i0, int64_t row_j0, double* gram_part);
@@ -67,7 +87,7 @@ hipError_t launch_colsum_generic(hipStream_t s, int num_cu, const double* u, int
                                  double* psum_part /*[blocks_x][K]*/, int* blocks_out);
 // out[n] = logden[n] - alpha ln cw[n] (+inf where cw = 0)
 hipError_t launch_shift_logden(hipStream_t s, const double* logden, const double* cw, double alpha, int64_t N,
-                               double* out);
+                               double* out, const LoopCtl& lc = LoopCtl());
 
 // ---- reductions / small kernels ----------------------------------------------------------------
 // out[i] = sum_p part[p*count + i]; scratch must hold ceil(nparts/32)*count doubles.
@@ -95,5 +115,35 @@ hipError_t launch_sci_update(hipStream_t s, const double* part, int64_t nparts, 
 hipError_t launch_reduce_level1(hipStream_t s, const double* part, int64_t nparts, int64_t count, double* out,
                                 int64_t* nchunks);
 hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink);
+// Two partial-record arrays with the same number of records reduced by one pair of launches (same summation order as
+// launch_reduce on each): outA[i] = sum_p partA[p*countA + i], outB likewise.  scratch: ceil(nparts/32)*(countA+countB).
+hipError_t launch_reduce2(hipStream_t s, const double* partA, int64_t countA, const double* partB, int64_t countB,
+                          int64_t nparts, double* scratch, double* outA, double* outB);
+
+// ---- device-resident adaptive iteration (mbar_solvers.py:575-640 without the host in the loop) --------------------
+// State of one solve, all in device memory.  Up to 128 padded states (one diagonal Gram panel).
+struct AdaptArgs {
+    const double* gram_red;  // reduced Gram blocks of the panel, block b = (I, J), I <= J, row-major 16 x 16 each
+    const double* lse_red;   // reduced outputs of the two-candidate sweep: psum[2][Kp], then 2 objective sums
+    double* f;               // [Kp] current free energies
+    double* psum;            // [Kp] sum_n p_nk at f
+    double* cand;            // [2][Kp] f_sci, f_nr
+    double* ratio;           // [Kp] exp(aden_nr - aden_sci): the fused sweep returns the second candidate's sums unscaled
+    double* aden;            // [2][Kp] input of the sweep: aden of f_sci, then ratio
+    double* anum;            // [Kp] f + ln N_k (-inf for unsampled / padded states): operand constant of the Gram pass
+    const double* Nk;        // [Kp]
+    const double* lnNk;      // [Kp]
+    const int* sampled;      // [m] states with N_k > 0, ascending
+    int m, K, Kp;
+    int* ctl;                // CTL_WORDS ints
+    const double* prm;       // gamma, tol, min_sc_iter, check_convergence
+    double* state;           // [0] max_delta of the last iteration
+    double* hist;            // rows of 4 doubles {choice, |g_sci|, |g_nr|, max_delta}
+    int64_t hist_cap;
+};
+// K x K Newton system (gauge-fixed, Gauss-Jordan in registers, one workgroup) + both candidates + sweep inputs
+hipError_t launch_newton(hipStream_t s, const AdaptArgs& a);
+// gradient norms of both candidates, choice (mbar_solvers.py:607), convergence test (:627-640), next Gram operand
+hipError_t launch_select(hipStream_t s, const AdaptArgs& a);
 
 }  // namespace mbar

@@ -507,8 +507,14 @@ __global__ void __launch_bounds__(256)
 k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
       const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
       double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
-      double* __restrict__ obj_part) {
+      double* __restrict__ obj_part, const int* __restrict__ ctl, int64_t slot_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl) {  // device-resident solver loop: stop flag + rotating logden slots (logden0 = base of the three vectors)
+        if (ctl[CTL_DONE] != 0) return;
+        const int s = ctl[CTL_SLOT];
+        logden1 = logden0 + (int64_t)((s + 2) % 3) * slot_stride;
+        logden0 = logden0 + (int64_t)((s + 1) % 3) * slot_stride;
+    }
     constexpr int ROWS = NB * 16;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
@@ -1177,8 +1183,13 @@ __global__ void __launch_bounds__(256, 1)
 k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
        const double* __restrict__ anum_i, const double* __restrict__ anum_j,
        const double* __restrict__ logden, int64_t row_i0, int64_t row_j0,
-       double* __restrict__ gram_part, double* __restrict__ psum_part) {
+       double* __restrict__ gram_part, double* __restrict__ psum_part, const int* __restrict__ ctl,
+       int64_t slot_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl) {  // device-resident solver loop: stop flag + the logden slot of the current f
+        if (ctl[CTL_DONE] != 0) return;
+        logden += (int64_t)ctl[CTL_SLOT] * slot_stride;
+    }
     constexpr int NBT = DIAG ? NBI : NBI + NBJ;  // blocks of 16 states staged per tile
     constexpr int ROWS = NBT * 16;
     constexpr int U_BYTES = ROWS * TS * 8;
@@ -1748,7 +1759,11 @@ k_check_u(const double* __restrict__ u, int64_t ld, int64_t N, int* __restrict__
 // per-state reduction).  c_n = 0 gives +inf, i.e. weight zero.
 __global__ void __launch_bounds__(256)
 k_shift_logden(const double* __restrict__ logden, const double* __restrict__ cw, double alpha, int64_t N,
-               double* __restrict__ out) {
+               double* __restrict__ out, const int* __restrict__ ctl, int64_t slot_stride) {
+    if (ctl) {
+        if (ctl[CTL_DONE] != 0) return;
+        logden += (int64_t)ctl[CTL_SLOT] * slot_stride;
+    }
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
         const double c = cw[n];
         out[n] = c > 0.0 ? logden[n] - alpha * log(c) : INFINITY;
@@ -1812,6 +1827,253 @@ __global__ void k_mfma_peak(int iters, double* sink) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v += c[i][0] + c[i][3];
     if (v == 12345.678) sink[threadIdx.x] = v;  // never true: keeps the loop alive
+}
+
+// Same reduction as k_reduce for TWO partial-record arrays with the same number of records in one launch
+// (blocks [0, gxA) work on A, the rest on B; identical summation order).
+__global__ void __launch_bounds__(256)
+k_reduce2(const double* __restrict__ partA, int64_t countA, const double* __restrict__ partB, int64_t countB,
+          int64_t nparts, int64_t chunk, double* __restrict__ outA, double* __restrict__ outB) {
+    const int64_t gxA = (countA + 255) / 256;
+    const bool isB = (int64_t)blockIdx.x >= gxA;
+    const double* part = isB ? partB : partA;
+    const int64_t count = isB ? countB : countA;
+    double* out = isB ? outB : outA;
+    const int64_t i = ((int64_t)blockIdx.x - (isB ? gxA : 0)) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t p0 = (int64_t)blockIdx.y * chunk;
+    const int64_t p1 = p0 + chunk < nparts ? p0 + chunk : nparts;
+    double s = 0.0;
+#pragma unroll 8
+    for (int64_t p = p0; p < p1; ++p) s += part[p * count + i];
+    out[(int64_t)blockIdx.y * count + i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident adaptive iteration (mbar_solvers.py:575-640): the K x K work between the two sweeps.
+// ---------------------------------------------------------------------------------------------
+// Element (ki, kj) of the reduced Gram panel.  Only the upper triangle is read (like the host-side unpack).
+__device__ __forceinline__ double gram_elem(const double* __restrict__ g, int nb, int ki, int kj) {
+    if (ki > kj) {
+        const int t = ki;
+        ki = kj;
+        kj = t;
+    }
+    const int I = ki >> 4, J = kj >> 4;
+    const int b = I * nb - (I * (I - 1)) / 2 + (J - I);
+    return g[(int64_t)b * 256 + (ki & 15) * 16 + (kj & 15)];
+}
+
+// Newton direction + both candidates, ONE workgroup of T x T threads (T = 8, 16, 32: up to 31 / 63 / 127 unknowns).
+//   H = diag(psum) - G on the sampled states, g = psum - N_k (:581, :284-292); gauge x[first] = 0, so the system is the
+//   (m-1) x (m-1) SPD block of H -- the same vector as lstsq(H, g) minus its first component (:582-583).
+// The augmented matrix [A | b] lives in REGISTERS, a 4 x 4 tile per thread (thread (ty, tx): rows 4 ty.., columns
+// 4 tx..; column 4T-1 holds b).  Gauss-Jordan without pivoting (A is SPD; the pivots are the squares of the Cholesky
+// diagonal, so "pivot <= 0" is exactly the Cholesky breakdown test of the host path): step j needs only column j, which
+// its owners publish through a double-buffered LDS vector -- row j of the trailing block is the same vector by
+// symmetry -- so a step is one barrier, ~10 LDS reads and 16 FMAs per thread, and there are no triangular solves.
+// Afterwards x_i = b_i / A_ii.  A non-positive pivot, candidates more than 300 kT apart (the fused two-candidate
+// sweep shares one shift) or a non-finite candidate hand the solve back to the host loop (CTL_DONE = 2).
+// Outputs: cand = (f_sci, f_nr), ratio = exp(aden_nr - aden_sci), aden = (aden_sci, ratio) for the sweep.
+template <int T>
+__global__ void __launch_bounds__(T * T)
+k_newton(AdaptArgs q) {
+    constexpr int NC = 4 * T;
+    __shared__ double colbuf[2][NC];
+    __shared__ double bbuf[2];
+    __shared__ double dg[NC], rh[NC], xs[NC + 1];
+    if (q.ctl[CTL_DONE] != 0) return;
+    const int tid = threadIdx.x, ty = tid / T, tx = tid % T;
+    const int M = q.m - 1, nb = q.Kp / 16;
+
+    double A[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = 4 * ty + r, k = 4 * tx + c;
+            double v = 0.0;
+            if (i < M) {
+                const int ki = q.sampled[i + 1];
+                if (k < M) {
+                    const int kj = q.sampled[k + 1];
+                    v = -gram_elem(q.gram_red, nb, ki, kj);
+                    if (i == k) v += q.psum[ki];
+                } else if (k == NC - 1) {
+                    v = q.psum[ki] - q.Nk[ki];
+                }
+            } else if (i == k && k != NC - 1) {
+                v = 1.0;  // padding rows: identity, never a pivot, multiplier 0
+            }
+            A[r][c] = v;
+        }
+    }
+    if (M > 0) {
+        if (tx == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) colbuf[0][4 * ty + r] = A[r][0];
+        }
+        if (tx == T - 1 && ty == 0) bbuf[0] = A[0][3];
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int j0 = 0; j0 < M; j0 += 4) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int j = j0 + c4;
+            if (j < M) {  // (uniform)
+                const double* cb = colbuf[c4 & 1];  // == colbuf[j & 1]
+                const double piv = cb[j];
+                if (!(piv > 0.0) || !isfinite(piv)) bad = true;  // the same value in every thread
+                const double inv = recip_fast(piv);
+                if (tx >= (j >> 2)) {  // columns left of the pivot are already eliminated (tx = T-1 owns b)
+                    double mr[4], rv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * ty + r;
+                        mr[r] = (i == j) ? 0.0 : cb[i] * inv;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = 4 * tx + c;
+                        rv[c] = (k == NC - 1) ? bbuf[c4 & 1] : (k >= j ? cb[k] : 0.0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) A[r][c] = fma(-mr[r], rv[c], A[r][c]);
+                }
+                const int jn = j + 1;
+                if (jn < M) {
+                    if (tx == (jn >> 2)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) colbuf[(c4 + 1) & 1][4 * ty + r] = A[r][(c4 + 1) & 3];
+                    }
+                    if (tx == T - 1 && ty == (jn >> 2)) bbuf[(c4 + 1) & 1] = A[(c4 + 1) & 3][3];
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (tx == ty) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dg[4 * ty + r] = A[r][r];
+    }
+    if (tx == T - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rh[4 * ty + r] = A[r][3];
+    }
+    __syncthreads();
+    if (tid == 0) xs[0] = 0.0;
+    if (tid < M) xs[tid + 1] = rh[tid] / dg[tid];
+    __syncthreads();
+
+    const double gamma = q.prm[0];
+    const int first = q.sampled[0];
+    const double shift = q.f[first] - log(q.psum[first] / q.Nk[first]);
+    int flags = bad ? 1 : 0;
+    if (tid < q.Kp) {
+        const int k = tid;
+        const bool smp = k < q.K && q.Nk[k] > 0.0;
+        const double fk = k < q.K ? q.f[k] : 0.0;
+        double fs = fk, fn = fk, a0 = -INFINITY, rt = 1.0;
+        if (smp) {
+            int lo = 0, hi = q.m - 1;  // position of k in the (ascending) sampled list
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (q.sampled[mid] < k) lo = mid + 1; else hi = mid;
+            }
+            fn = fk - gamma * xs[lo];                            // :584
+            fs = (fk - log(q.psum[k] / q.Nk[k])) - shift;        // :587-588
+            a0 = fs + q.lnNk[k];
+            const double d = (fn + q.lnNk[k]) - a0;
+            rt = exp(d);
+            if (!(fabs(d) < 300.0)) flags |= 2;
+            if (!isfinite(fs) || !isfinite(fn)) flags |= 4;
+        }
+        q.cand[k] = fs;
+        q.cand[q.Kp + k] = fn;
+        q.ratio[k] = rt;
+        q.aden[k] = a0;
+        q.aden[q.Kp + k] = rt;
+    }
+    flags = __syncthreads_or(flags);
+    if (flags != 0 && tid == 0) {
+        q.ctl[CTL_REASON] = (flags & 1) ? 1 : ((flags & 4) ? 3 : 2);
+        q.ctl[CTL_DONE] = 2;
+    }
+}
+
+// Choice between the candidates and convergence test, one workgroup.  The scalar reductions run serially in thread 0
+// in the host loop's order (at most 128 terms), so both loops take the same decisions from the same sums.
+__global__ void __launch_bounds__(256)
+k_select(AdaptArgs q) {
+    __shared__ double ps[2][256], d1[256], d2[256];
+    __shared__ int s_choice;
+    __shared__ double s_gn[2];
+    int* ctl = q.ctl;
+    if (ctl[CTL_DONE] != 0) return;
+    const int tid = threadIdx.x, Kp = q.Kp;
+    const double tol = q.prm[1];
+    const int min_sc = (int)q.prm[2];
+    const bool check = q.prm[3] != 0.0;
+    if (tid < Kp) {
+        ps[0][tid] = q.lse_red[tid];
+        ps[1][tid] = q.lse_red[Kp + tid] * q.ratio[tid];  // the sweep accumulates e_k / s' : times c_k = its psum
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double gs = 0.0, gn = 0.0;
+        for (int i = 0; i < q.m; ++i) {
+            const int k = q.sampled[i];
+            const double a = ps[0][k] - q.Nk[k], b = ps[1][k] - q.Nk[k];
+            gs += a * a;
+            gn += b * b;
+        }
+        s_gn[0] = gs;
+        s_gn[1] = gn;
+        s_choice = (gs < gn || ctl[CTL_SCI] < min_sc) ? 0 : 1;  // :607
+    }
+    __syncthreads();
+    const int ch = s_choice;
+    if (tid < Kp) {
+        const double fo = q.f[tid];
+        const double fs = q.cand[tid], fn = q.cand[Kp + tid];
+        const double fnew = ch == 0 ? fs : fn;
+        const bool smp = tid < q.K && q.Nk[tid] > 0.0;
+        q.f[tid] = fnew;
+        q.psum[tid] = ps[ch][tid];
+        q.anum[tid] = smp ? fnew + q.lnNk[tid] : -INFINITY;
+        const double small = tol < 1e-8 ? tol : 1e-8;
+        const double div = fabs(fnew) < small ? 1.0 : fabs(fnew);
+        d1[tid] = fabs(fnew - fo) / div;   // :627-631
+        d2[tid] = fabs(fs - fn) / div;     // :632-633
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double max_delta = 0.0, max_diff = 0.0;
+        bool nan_seen = false;
+        for (int i = 1; i < q.m; ++i) {  // the first sampled state is the gauge
+            const int k = q.sampled[i];
+            if (d1[k] != d1[k]) nan_seen = true;
+            max_delta = max_delta < d1[k] ? d1[k] : max_delta;
+            max_diff = max_diff < d2[k] ? d2[k] : max_diff;
+        }
+        if (nan_seen) max_delta = NAN;
+        const int it = ctl[CTL_ITER];
+        if (it < q.hist_cap) {
+            q.hist[4 * (int64_t)it + 0] = ch;
+            q.hist[4 * (int64_t)it + 1] = sqrt(s_gn[0]);
+            q.hist[4 * (int64_t)it + 2] = sqrt(s_gn[1]);
+            q.hist[4 * (int64_t)it + 3] = max_delta;
+        }
+        q.state[0] = max_delta;
+        const bool stop = check && (max_delta != max_delta || (max_delta < tol && max_diff < sqrt(tol)));  // :636
+        ctl[CTL_ITER] = it + 1;
+        if (ch == 0) ctl[CTL_SCI] += 1; else ctl[CTL_NR] += 1;
+        ctl[CTL_SLOT] = (ctl[CTL_SLOT] + (ch == 0 ? 1 : 2)) % 3;
+        if (stop) ctl[CTL_DONE] = 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1932,7 +2194,7 @@ static bool stage_offsets_wide(int64_t ld) { return (uint64_t)ld * 56u + 128u >=
 template <typename Kern>
 static hipError_t launch_kernel_lse(Kern kern, hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                                     const double* aden, const double* cw, double* l0, double* l1, const double* dn,
-                                    double* psum_part, double* obj_part) {
+                                    double* psum_part, double* obj_part, const LoopCtl& lc) {
     if (g.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
@@ -1940,25 +2202,17 @@ static hipError_t launch_kernel_lse(Kern kern, hipStream_t s, const LaunchGeom& 
     }
     const int64_t ntiles = (N + TS - 1) / TS;
     hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
-                       l1, dn, psum_part, obj_part);
+                       l1, dn, psum_part, obj_part, lc.ctl, lc.slot_stride);
     return hipGetLastError();
 }
 
 template <int NB, int NF, bool DMA>
 static hipError_t launch_lse_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                                const double* aden, const double* cw, double* l0, double* l1, const double* dn,
-                               double* psum_part, double* obj_part) {
-    if (stage_offsets_wide(ld)) return launch_kernel_lse(k_lse<NB, NF, DMA, true>, s, g, u, ld, N, aden, cw, l0, l1, dn, psum_part, obj_part);
-    auto kern = k_lse<NB, NF, DMA, false>;
-    if (g.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    const int64_t ntiles = (N + TS - 1) / TS;
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
-                       l1, dn, psum_part, obj_part);
-    return hipGetLastError();
+                               double* psum_part, double* obj_part, const LoopCtl& lc) {
+    if (stage_offsets_wide(ld))
+        return launch_kernel_lse(k_lse<NB, NF, DMA, true>, s, g, u, ld, N, aden, cw, l0, l1, dn, psum_part, obj_part, lc);
+    return launch_kernel_lse(k_lse<NB, NF, DMA, false>, s, g, u, ld, N, aden, cw, l0, l1, dn, psum_part, obj_part, lc);
 }
 
 template <int NB, int NF, bool DMA>
@@ -1996,7 +2250,8 @@ static hipError_t launch_lse_early_t(hipStream_t s, const LaunchGeom& g, const d
 template <int NB>
 static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeom& g, const double* u,
                                 int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
-                                const double* dn, double* pp, double* op) {
+                                const double* dn, double* pp, double* op, const LoopCtl& lc) {
+    if (lc.ctl && g.variant != 1) return hipErrorInvalidValue;  // only the default sweep honours the control words
     if constexpr (NB >= 5 && NB <= 8) {
         if (g.variant >= 2) {
             if (!dma) return hipErrorInvalidValue;  // (the caller selects these variants only with LDS-DMA staging)
@@ -2017,10 +2272,10 @@ static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeo
         }
     }
     if (nf == 1)
-        return dma ? launch_lse_t<NB, 1, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
-                   : launch_lse_t<NB, 1, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
-    return dma ? launch_lse_t<NB, 2, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op)
-               : launch_lse_t<NB, 2, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
+        return dma ? launch_lse_t<NB, 1, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc)
+                   : launch_lse_t<NB, 1, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
+    return dma ? launch_lse_t<NB, 2, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc)
+               : launch_lse_t<NB, 2, false>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
 }
 
 template <int NB>
@@ -2041,7 +2296,8 @@ static hipError_t launch_lse_small_t(hipStream_t s, const LaunchGeom& g, const d
 
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,
                       int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
-                      const double* dn, double* pp, double* op) {
+                      const double* dn, double* pp, double* op, const LoopCtl& lc) {
+    if (lc.ctl && (g.variant == 5 || g.variant == 4)) return hipErrorInvalidValue;
     if (g.variant == 5) {  // (geometry chose the single-buffer wide-panel kernel: nb = 12 or 16, LDS-DMA staging)
         if (!dma) return hipErrorInvalidValue;
         auto go = [&](auto kern) -> hipError_t {
@@ -2069,7 +2325,7 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
     }
     switch (nb) {
 #define MBAR_CASE(NB_) \
-    case NB_: return launch_lse_nb<NB_>(s, nf, dma, g, u, ld, N, aden, cw, l0, l1, dn, pp, op);
+    case NB_: return launch_lse_nb<NB_>(s, nf, dma, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
         MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7)
         MBAR_CASE(8) MBAR_CASE(12) MBAR_CASE(16)
 #undef MBAR_CASE
@@ -2080,7 +2336,7 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
 template <int NBI, int NBJ, bool DIAG, bool DMA>
 static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                                 const double* ai, const double* aj, const double* logden, int64_t ri,
-                                int64_t rj, double* gp, double* pp) {
+                                int64_t rj, double* gp, double* pp, const LoopCtl& lc = LoopCtl()) {
     auto launch = [&](auto kern) -> hipError_t {
         if (g.lds_bytes > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -2089,7 +2345,7 @@ static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double
         }
         const int64_t ntiles = (N + TS - 1) / TS;
         hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, ai, aj,
-                           logden, ri, rj, gp, pp);
+                           logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride);
         return hipGetLastError();
     };
     return stage_offsets_wide(ld) ? launch(k_gram<NBI, NBJ, DIAG, DMA, true>) : launch(k_gram<NBI, NBJ, DIAG, DMA, false>);
@@ -2127,11 +2383,12 @@ static hipError_t launch_gram_xchg_t(hipStream_t s, const LaunchGeom& g, const d
 
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
                             int64_t N, const double* anum, const double* logden, int64_t row0, double* gp,
-                            double* pp) {
+                            double* pp, const LoopCtl& lc) {
     if (nb == 8 && g.variant == 2)  // one wave per SIMD owns all 36 blocks (accumulator classes pinned by hand)
-        return dma ? launch_gram_t<8, 8, true, true>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp)
-                   : launch_gram_t<8, 8, true, false>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp);
+        return dma ? launch_gram_t<8, 8, true, true>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp, lc)
+                   : launch_gram_t<8, 8, true, false>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp, lc);
     if (nb == 8) {  // paired-wave variants: g.nwaves counts tile streams (4 per workgroup)
+        if (lc.ctl) return hipErrorInvalidValue;  // (only k_gram honours the control words)
         if (g.variant == 0)
             return dma ? launch_gram_xchg_t<8, true>(s, g, u, ld, N, anum, logden, row0, gp, pp)
                        : launch_gram_xchg_t<8, false>(s, g, u, ld, N, anum, logden, row0, gp, pp);
@@ -2141,8 +2398,8 @@ hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g
     switch (nb) {
 #define MBAR_CASE(NB_)                                                                                  \
     case NB_:                                                                                           \
-        return dma ? launch_gram_t<NB_, NB_, true, true>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp) \
-                   : launch_gram_t<NB_, NB_, true, false>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp);
+        return dma ? launch_gram_t<NB_, NB_, true, true>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp, lc) \
+                   : launch_gram_t<NB_, NB_, true, false>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp, lc);
         MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7)
 #undef MBAR_CASE
         default: return hipErrorInvalidValue;
@@ -2233,11 +2490,11 @@ hipError_t launch_check_u(hipStream_t s, const double* u, int64_t ld, int64_t N,
 }
 
 hipError_t launch_shift_logden(hipStream_t s, const double* logden, const double* cw, double alpha, int64_t N,
-                               double* out) {
+                               double* out, const LoopCtl& lc) {
     int64_t bx = (N + 255) / 256;
     if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(k_shift_logden, dim3((unsigned)bx), dim3(256), 0, s, logden, cw, alpha, N, out);
+    hipLaunchKernelGGL(k_shift_logden, dim3((unsigned)bx), dim3(256), 0, s, logden, cw, alpha, N, out, lc.ctl, lc.slot_stride);
     return hipGetLastError();
 }
 
@@ -2282,6 +2539,41 @@ hipError_t launch_reduce_level1(hipStream_t s, const double* part, int64_t npart
 
 hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink) {
     hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, s, iters, sink);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce2(hipStream_t s, const double* partA, int64_t countA, const double* partB, int64_t countB,
+                          int64_t nparts, double* scratch, double* outA, double* outB) {
+    const unsigned gx = (unsigned)((countA + 255) / 256 + (countB + 255) / 256);
+    if (nparts <= 32) {
+        hipLaunchKernelGGL(k_reduce2, dim3(gx, 1), dim3(256), 0, s, partA, countA, partB, countB, nparts, nparts, outA, outB);
+        return hipGetLastError();
+    }
+    const int64_t chunk = 32;
+    const int64_t n1 = (nparts + chunk - 1) / chunk;
+    double* sA = scratch;
+    double* sB = scratch + n1 * countA;
+    hipLaunchKernelGGL(k_reduce2, dim3(gx, (unsigned)n1), dim3(256), 0, s, partA, countA, partB, countB, nparts, chunk, sA, sB);
+    hipLaunchKernelGGL(k_reduce2, dim3(gx, 1), dim3(256), 0, s, (const double*)sA, countA, (const double*)sB, countB, n1, n1,
+                       outA, outB);
+    return hipGetLastError();
+}
+
+hipError_t launch_newton(hipStream_t s, const AdaptArgs& a) {
+    const int M = a.m - 1;
+    if (M > 127 || a.Kp > 128) return hipErrorInvalidValue;
+    if (M <= 31 && a.Kp <= 64)
+        hipLaunchKernelGGL(k_newton<8>, dim3(1), dim3(64), 0, s, a);
+    else if (M <= 63)
+        hipLaunchKernelGGL(k_newton<16>, dim3(1), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_newton<32>, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_select(hipStream_t s, const AdaptArgs& a) {
+    if (a.Kp > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

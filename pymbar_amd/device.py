@@ -177,6 +177,18 @@ class DeviceMatrix:
         self._check(self._lib.mbar_ctx_set_host_allreduce(self._ctx, self._cb, None, rank, nranks))
         self.rank, self.nranks, self.allreduce_kind = rank, nranks, "host"
 
+    def comm_destroy(self):
+        """Detach the cross-rank transport (destroys an RCCL communicator); the matrix is single-rank again."""
+        self._check(self._lib.mbar_ctx_comm_destroy(self._ctx))
+        self._cb = None
+        self.rank, self.nranks, self.allreduce_kind = 0, 1, "none"
+
+    def device_synchronize(self):
+        """``hipDeviceSynchronize`` on this matrix's GPU (all streams)."""
+        rc = self._lib.mbar_device_synchronize(self.device)
+        if rc != _lib.MBAR_OK:
+            raise _lib.MbarHipError(rc, _lib.last_error(None))
+
     # ---- L1 ---------------------------------------------------------------------------------------
     def eval(self, f, gram=False, use_offset=False):
         """One fused sweep for 1 or 2 free-energy vectors.  Returns ``(psum, sumlogden, gram)`` with

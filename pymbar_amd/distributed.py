@@ -1,18 +1,31 @@
-"""One process per GPU: attach the cross-rank all-reduce to a :class:`DeviceMatrix`.
+"""One process per GPU: rendezvous of the ranks and the cross-rank all-reduce of a :class:`DeviceMatrix`.
 
-The sample axis N is sharded over ranks; every pass ends with ONE small all-reduce (K+1 doubles for
-an evaluation pass, K(K+1)/2-ish blocks of 256 doubles + K for a Gram pass) done by RCCL on the
-device buffers inside ``libmbar_hip.so`` (``ncclAllReduce`` over xGMI).  ``torch.distributed`` is used
-only as the rendezvous that carries the 128-byte ``ncclUniqueId`` from rank 0 to the others (the
-launcher contract is ``python -m torch.distributed.run``); if RCCL cannot be initialised the
-all-reduce falls back to the host through the same process group, and says so.
+The sample axis N is sharded over ranks; every pass ends with ONE small all-reduce (K+1 doubles for an
+evaluation pass, K(K+1)/2-ish blocks of 256 doubles for a Gram pass) done by RCCL on the device buffers
+inside ``libmbar_hip.so`` (``ncclAllReduce`` over xGMI, on the compute stream).  What the ranks need from
+the host side is tiny: the 128-byte ``ncclUniqueId`` has to travel from rank 0 to the others, and the
+launcher contract wants a barrier and a max-over-ranks of the elapsed time.  :class:`HostGroup` does that
+with the standard library only (TCP sockets; rank 0 is the hub of a star) from the launcher's environment
+(``RANK`` / ``WORLD_SIZE`` / ``MASTER_ADDR`` / ``MASTER_PORT``, as set by the driver's elastic launcher or any other
+one) -- this package imports no ML framework, not even for the rendezvous.
+
+If RCCL cannot be initialised on every rank, ALL ranks drop their communicator and the same reduction runs on
+the host through the :class:`HostGroup` (``"host"``); callers that must not fall back (``bench.py``) check the
+returned kind.
 """
+import hashlib
 import logging
 import os
+import socket
+import struct
+import time
 
 import numpy as np
 
 logger = logging.getLogger(__name__)
+
+_MAGIC = b"MBARRDZV1"
+_PORT_SPAN = 24  # ports tried above the base port
 
 
 def shard_bounds(N_total, rank, nranks, align=16):
@@ -24,58 +37,228 @@ def shard_bounds(N_total, rank, nranks, align=16):
     return n0, n1
 
 
-def init_process_group_from_env(backend="gloo"):
-    """Join the launcher's process group (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
-    import torch.distributed as dist
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous connection")
+        buf.extend(chunk)
+    return bytes(buf)
 
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend)
-    return dist.get_rank(), dist.get_world_size()
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<q", len(payload)) + payload)
 
 
-def attach_allreduce(dm, prefer="rccl"):
-    """Give ``dm`` its cross-rank reduction.  Returns "none", "rccl" or "host"."""
-    import torch
-    import torch.distributed as dist
+def _recv_msg(sock):
+    (n,) = struct.unpack("<q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n) if n else b""
 
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+
+class HostGroup:
+    """Minimal process group over TCP (standard library only): rank 0 listens, the others connect.
+
+    Collectives are star-shaped and reduce in rank order on rank 0, so every rank receives bit-identical
+    results.  Meant for the rendezvous traffic of a single node (a few hundred bytes per call) and as the
+    fallback transport of the per-pass all-reduce (a few KB); the data path proper is RCCL.
+
+    Port: the launcher's ``MASTER_PORT`` usually belongs to the launcher's own store (the elastic launcher keeps it
+    bound), so rank 0 binds the first free port in ``[base, base + 24)`` with ``base = MASTER_PORT + 1``
+    (or ``MBAR_RDZV_PORT``) and the clients probe the same range; a handshake token derived from the launch
+    (address, port, run id, world size) tells this group's hub from anything else listening there."""
+
+    def __init__(self, rank, world, addr="127.0.0.1", base_port=29501, token="", timeout=120.0):
+        self.rank, self.world = int(rank), int(world)
+        self._socks = {}     # rank 0: peer rank -> socket
+        self._sock = None    # other ranks: socket to rank 0
+        self._listener = None
+        if self.world <= 1:
+            return
+        tok = hashlib.sha256(f"{token}|{self.world}".encode()).digest()[:16]
+        deadline = time.time() + timeout
+        if self.rank == 0:
+            bind_addr = addr if addr in ("127.0.0.1", "localhost", "::1") else ""
+            if bind_addr == "localhost":
+                bind_addr = "127.0.0.1"
+            last = None
+            for port in range(base_port, base_port + _PORT_SPAN):
+                try:
+                    ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    ls.bind((bind_addr, port))
+                    ls.listen(self.world)
+                    self._listener = ls
+                    break
+                except OSError as exc:
+                    last = exc
+                    ls.close()
+            if self._listener is None:
+                raise RuntimeError(f"rendezvous: no free port in [{base_port}, {base_port + _PORT_SPAN}): {last}")
+            self._listener.settimeout(1.0)
+            while len(self._socks) < self.world - 1:
+                if time.time() > deadline:
+                    raise TimeoutError(f"rendezvous: {self.world - 1 - len(self._socks)} rank(s) never connected")
+                try:
+                    conn, _ = self._listener.accept()
+                except socket.timeout:
+                    continue
+                try:
+                    conn.settimeout(5.0)
+                    hello = _recv_exact(conn, len(_MAGIC) + 16 + 4)
+                    peer = struct.unpack("<i", hello[-4:])[0]
+                    if hello[: len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):-4] != tok or not (0 < peer < self.world) \
+                            or peer in self._socks:
+                        conn.close()
+                        continue
+                    conn.sendall(b"OK")
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self._socks[peer] = conn
+                except (OSError, ConnectionError, struct.error):
+                    conn.close()
+        else:
+            hello = _MAGIC + tok + struct.pack("<i", self.rank)
+            host = "127.0.0.1" if addr == "localhost" else addr
+            while self._sock is None:
+                for port in range(base_port, base_port + _PORT_SPAN):
+                    try:
+                        s = socket.create_connection((host, port), timeout=2.0)
+                    except OSError:
+                        continue
+                    try:
+                        s.settimeout(3.0)
+                        s.sendall(hello)
+                        if _recv_exact(s, 2) == b"OK":
+                            s.settimeout(timeout)
+                            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                            self._sock = s
+                            break
+                    except (OSError, ConnectionError):
+                        pass
+                    s.close()
+                if self._sock is None:
+                    if time.time() > deadline:
+                        raise TimeoutError("rendezvous: rank 0 could not be reached")
+                    time.sleep(0.05)
+
+    # ---- construction from the launcher's environment ------------------------------------------------
+    @classmethod
+    def from_env(cls, timeout=120.0):
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        mport = int(os.environ.get("MASTER_PORT", "29500"))
+        base = int(os.environ.get("MBAR_RDZV_PORT", mport + 1))
+        token = f"{addr}:{mport}:{os.environ.get('TORCHELASTIC_RUN_ID', '')}"
+        return cls(rank, world, addr=addr, base_port=base, token=token, timeout=timeout)
+
+    # ---- collectives -----------------------------------------------------------------------------------
+    def broadcast_bytes(self, payload, src=0):
+        """``payload`` of rank ``src`` (bytes, or None meaning "nothing") on every rank."""
+        if self.world <= 1:
+            return payload
+        if src != 0:  # route through the hub
+            if self.rank == src:
+                _send_msg(self._sock, b"\x01" + payload if payload is not None else b"\x00")
+            if self.rank == 0:
+                m = _recv_msg(self._socks[src])
+                payload = m[1:] if m[:1] == b"\x01" else None
+        if self.rank == 0:
+            msg = b"\x01" + payload if payload is not None else b"\x00"
+            for r in sorted(self._socks):
+                _send_msg(self._socks[r], msg)
+            return payload
+        m = _recv_msg(self._sock)
+        return m[1:] if m[:1] == b"\x01" else None
+
+    def allreduce(self, arr, op="sum"):
+        """In-place all-reduce of a float64 numpy array (``op`` "sum", "max" or "min"); rank order on the hub."""
+        if self.world <= 1:
+            return arr
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.rank == 0:
+            acc = a.copy()
+            for r in sorted(self._socks):
+                other = np.frombuffer(_recv_msg(self._socks[r]), dtype=np.float64).reshape(a.shape)
+                if op == "sum":
+                    acc += other
+                elif op == "max":
+                    np.fmax(acc, other, out=acc)   # (like ncclMax: the non-NaN operand wins)
+                elif op == "min":
+                    np.fmin(acc, other, out=acc)
+                else:
+                    raise ValueError(op)
+            out = acc.tobytes()
+            for r in sorted(self._socks):
+                _send_msg(self._socks[r], out)
+            res = acc
+        else:
+            _send_msg(self._sock, a.tobytes())
+            res = np.frombuffer(_recv_msg(self._sock), dtype=np.float64).reshape(a.shape)
+        arr[...] = res
+        return arr
+
+    def barrier(self):
+        if self.world > 1:
+            self.allreduce(np.zeros(1), "sum")
+
+    def close(self):
+        for s in list(self._socks.values()) + [self._sock, self._listener]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:  # pragma: no cover
+                    pass
+        self._socks, self._sock, self._listener = {}, None, None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def attach_allreduce(dm, group, prefer="rccl"):
+    """Give ``dm`` its cross-rank reduction over the ranks of ``group``.  Returns "none", "rccl" or "host".
+
+    ``group`` is a :class:`HostGroup` (or any object with ``rank``, ``world``, ``broadcast_bytes`` and
+    ``allreduce(array, op)``).  Collective: every rank of the group must call it."""
+    if group is None or group.world <= 1:
         return "none"
-    rank, nranks = dist.get_rank(), dist.get_world_size()
+    rank, nranks = group.rank, group.world
     if prefer == "rccl":
-        ok = True
         if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
             # single-node rendezvous: RCCL's bootstrap sockets may use the loopback interface (it is skipped by
             # default, and a network-less container has no other one); the data path is xGMI either way
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        payload = [None]
+        payload = None
         if rank == 0:  # a failure here must still reach the broadcast below, or the other ranks wait forever
             try:
-                from . import _lib
                 import ctypes as C
+
+                from . import _lib
 
                 buf = C.create_string_buffer(128)
                 _lib.check(_lib.load_library().mbar_comm_unique_id(buf))
-                payload = [bytes(buf.raw)]
+                payload = bytes(buf.raw)
             except Exception as exc:  # pragma: no cover - needs RCCL
                 logger.warning("RCCL unique id could not be created (%s); using the host all-reduce", exc)
-        dist.broadcast_object_list(payload, src=0)
-        if payload[0] is None:
-            ok = False
-        else:
+        payload = group.broadcast_bytes(payload, src=0)
+        ok = payload is not None
+        if ok:
             try:
-                dm.comm_init_rccl(payload[0], rank, nranks)
+                dm.comm_init_rccl(payload, rank, nranks)
             except Exception as exc:  # pragma: no cover - needs several GPUs
                 logger.warning("RCCL initialisation failed on rank %d (%s); using the host all-reduce", rank, exc)
                 ok = False
-        flag = torch.tensor([1 if ok else 0])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        flag = np.array([1.0 if ok else 0.0])
+        group.allreduce(flag, "min")
+        if flag[0] == 1.0:
             return "rccl"
+        # not every rank has a communicator: NOBODY may keep one (a rank that still issued ncclAllReduce while the
+        # others reduce on the host would deadlock every later sweep)
+        dm.comm_destroy()
 
-    def host_allreduce(arr, op):
-        t = torch.from_numpy(arr)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
-
-    dm.set_host_allreduce(host_allreduce, rank, nranks)
+    dm.set_host_allreduce(group.allreduce, rank, nranks)
     return "host"

@@ -134,8 +134,11 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
                 if S > 0:
                     result_vals["observables"] = A_i + (A_min[obs_list] - logfactors[obs_list])
                 if return_theta:
-                    G, _ = dm.gram_w(f_full)
-                    Theta_ij = mbar._theta_from_gram(G, N_aug.astype(np.int64), uncertainty_method, dm=dm, f_full=f_full)
+                    # (the column sums go along: like the reference's check_w_normalized on the augmented W, weights that
+                    # do not sum to one raise instead of silently producing a Theta)
+                    G, wsum = dm.gram_w(f_full)
+                    Theta_ij = mbar._theta_from_gram(G, N_aug.astype(np.int64), uncertainty_method, wsum=wsum, dm=dm,
+                                                     f_full=f_full)
                 result_vals["f"] = f_states
             else:
                 A_i_bootstrap[n - 1, :] = A_i + (A_min[obs_list] - logfactors[obs_list]) if S > 0 else 0.0

@@ -68,7 +68,14 @@ class MBAR:
         self.N = int(np.sum(self.N_k))
         if len(np.shape(u_kn)) == 3:
             u_kn = kln_to_kn(u_kn, N_k=self.N_k)
-        self.u_kn = np.array(u_kn, dtype=np.float64)
+        # The OWNED copy of the matrix is the device-resident one (uploaded below, kept for the object's lifetime).  On
+        # the host ``self.u_kn`` REFERENCES the caller's array when it already is a float64 C-contiguous ndarray (the
+        # reference makes a second host copy here, mbar.py:243 -- 10 GB and several seconds at K=128, N=1e7); it is
+        # only read again by initialize="BAR" / "mean-reduced-potential", the verbose same-state scan and as the
+        # default ``u_kn`` of the expectation family, never written.
+        self.u_kn = np.ascontiguousarray(u_kn, dtype=np.float64)
+        if self.u_kn.ndim != 2:
+            raise ParameterError("u_kn must be a K x N (or K x L x N_max) array.")
         K, N = self.u_kn.shape
         if verbose:
             logger.info("K (total states) = {:d}, total samples = {:d}".format(K, N))
@@ -124,7 +131,12 @@ class MBAR:
 
         # the matrix goes to HBM once and stays there for the lifetime of the object
         self._device = device
+        import time as _time
+
+        _t0 = _time.perf_counter()
         self._dm = DeviceMatrix.from_host(self.u_kn, device=device)
+        _dt = _time.perf_counter() - _t0
+        self.upload_stats = dict(upload_s=_dt, upload_GBps=8.0 * K * N / _dt * 1e-9 if _dt > 0 else float("inf"))
         self.f_k = mbar_solvers.solve_mbar_for_all_states(self._dm, self.N_k, self.f_k, self.states_with_samples,
                                                           solver_protocol)
 
@@ -140,9 +152,13 @@ class MBAR:
                     rints[k_indices] = k_indices[self.rng.integers(int(self.N_k[k]), size=int(self.N_k[k]))]
                 # a replicate is the vector of draw counts: the resident matrix is re-used, nothing is gathered
                 self._dm.set_sample_weights(np.bincount(rints, minlength=self.N))
+                f_k_init = self.f_k.copy()
+                if initialize == "BAR":  # the reference re-runs the BAR chain on every resampled matrix (mbar.py:435-436)
+                    # (on a copy: the reference hands over self.f_k itself, which its BAR chain then overwrites in place)
+                    f_k_init = self._initialize_with_bar(self.u_kn[:, rints], f_k_init=self.f_k.copy())
                 try:
                     self.f_k_boots[b, :] = mbar_solvers.solve_mbar_for_all_states(
-                        self._dm, self.N_k, self.f_k.copy(), self.states_with_samples, bootstrap_solver_protocol)
+                        self._dm, self.N_k, f_k_init, self.states_with_samples, bootstrap_solver_protocol)
                 finally:
                     self._dm.set_sample_weights(None)
                 self.bootstrap_rints[b, :] = rints
@@ -164,6 +180,10 @@ class MBAR:
         if self._Log_W_nk is None:
             self._Log_W_nk = mbar_solvers.mbar_log_W_nk(self._dm, self.N_k, self.f_k)
         return self._Log_W_nk
+
+    @Log_W_nk.setter
+    def Log_W_nk(self, value):  # a plain attribute in the reference (mbar.py:455): assignment must work
+        self._Log_W_nk = value
 
     @property
     def W_nk(self):
