@@ -996,11 +996,15 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             lca = lc_flat;
         }
         {
+            // opt_timing 2: the events ride on the kernel dispatch itself; 1: event records around the launch
             TimerPair tp{nullptr, nullptr, MBAR_TIMER_GRAM};
             if (timed) { tp.a = get_event(c); tp.b = get_event(c); }
-            if (tp.a && tp.b) (void)hipEventRecord(tp.a, c->stream);
+            const bool ext = tp.a && tp.b && c->opt_timing == 2;
+            if (ext) { lca.ev_start = tp.a; lca.ev_stop = tp.b; }
+            if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
             HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, c->u, c->ld, c->N, d_anum(c), lden, 0, c->part, nullptr, lca));
-            if (tp.a && tp.b) { (void)hipEventRecord(tp.b, c->stream); c->pending.push_back(tp); }
+            if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
+            if (tp.a && tp.b) c->pending.push_back(tp);
         }
         HIPCHK(c, launch_reduce(c->stream, c->part, gg.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
         if (c->comm) {
@@ -1014,10 +1018,14 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         {
             TimerPair tp{nullptr, nullptr, MBAR_TIMER_LSE};
             if (timed) { tp.a = get_event(c); tp.b = get_event(c); }
-            if (tp.a && tp.b) (void)hipEventRecord(tp.a, c->stream);
+            const bool ext = tp.a && tp.b && c->opt_timing == 2;
+            LoopCtl lcb = lc_slot;
+            if (ext) { lcb.ev_start = tp.a; lcb.ev_stop = tp.b; }
+            if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
             HIPCHK(c, launch_lse(c->stream, nb, 2, dma, gl, c->u, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, nullptr,
-                                 psum_part, obj_part, lc_slot));
-            if (tp.a && tp.b) { (void)hipEventRecord(tp.b, c->stream); c->pending.push_back(tp); }
+                                 psum_part, obj_part, lcb));
+            if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
+            if (tp.a && tp.b) c->pending.push_back(tp);
         }
         HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, obj_part, 2, gl.nwaves, c->scratch, c->red, c->red + rec_l));
         if (c->comm) {

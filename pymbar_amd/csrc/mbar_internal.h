@@ -41,6 +41,9 @@ enum : int {
 struct LoopCtl {
     const int* ctl = nullptr;
     int64_t slot_stride = 0;
+    // optional: events bound to the kernel dispatch itself (hipExtLaunchKernelGGL): start / stop time stamps of the
+    // kernel with no marker packets in the stream (an event record between two kernels costs ~6 us of idle queue)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
 struct LaunchGeom {

@@ -18,6 +18,7 @@
 // the number of waves in the grid) with a one-tile DMA prefetch.
 #include "mbar_internal.h"
 
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <type_traits>
 
@@ -1867,126 +1868,127 @@ __device__ __forceinline__ double gram_elem(const double* __restrict__ g, int nb
 // Newton direction + both candidates, ONE workgroup of T x T threads (T = 8, 16, 32: up to 31 / 63 / 127 unknowns).
 //   H = diag(psum) - G on the sampled states, g = psum - N_k (:581, :284-292); gauge x[first] = 0, so the system is the
 //   (m-1) x (m-1) SPD block of H -- the same vector as lstsq(H, g) minus its first component (:582-583).
-// The augmented matrix [A | b] lives in REGISTERS, a 4 x 4 tile per thread (thread (ty, tx): rows 4 ty.., columns
-// 4 tx..; column 4T-1 holds b).  Gauss-Jordan without pivoting (A is SPD; the pivots are the squares of the Cholesky
-// diagonal, so "pivot <= 0" is exactly the Cholesky breakdown test of the host path): step j needs only column j, which
-// its owners publish through a double-buffered LDS vector -- row j of the trailing block is the same vector by
-// symmetry -- so a step is one barrier, ~10 LDS reads and 16 FMAs per thread, and there are no triangular solves.
-// Afterwards x_i = b_i / A_ii.  A non-positive pivot, candidates more than 300 kT apart (the fused two-candidate
-// sweep shares one shift) or a non-finite candidate hand the solve back to the host loop (CTL_DONE = 2).
+// The augmented matrix [A | b] lives in REGISTERS, a 4 x 4 tile per thread in a CYCLIC layout (thread (ty, tx): rows
+// ty + T r, columns tx + T c; column 4T-1 holds b).  Gauss-Jordan without pivoting (A is SPD; the pivots are the
+// squares of the Cholesky diagonal, so "pivot <= 0" is exactly the Cholesky breakdown test of the host path): step j
+// needs only column j, which its owners publish through a double-buffered LDS vector -- row j of the live block is the
+// same vector by symmetry -- so a step is one barrier, ~10 LDS reads and at most 16 FMAs per thread, and there are no
+// triangular solves: x_i = b_i / pivot_i at the end.  The whole kernel is bound by the fp64 issue rate of ONE compute
+// unit, so it is written for instruction count:
+//   * columns left of the pivot are never read again; they are left stale (whole tile columns c < j / T: skipped
+//     statically, the step loop is unrolled over j / T) or take garbage, and the pivots are kept in their own vector;
+//   * b_j travels in slot 4T-1 of the column vector (row 4T-1 is always padding: its multiplier is then garbage, which
+//     only ever touches that row), so the b column needs no special case;
+//   * the pivot row is excluded by zeroing ONE multiplier under a compare, not by a select per row.
+// A non-positive pivot, candidates more than 300 kT apart (the fused two-candidate sweep shares one shift) or a
+// non-finite candidate hand the solve back to the host loop (CTL_DONE = 2).
 // Outputs: cand = (f_sci, f_nr), ratio = exp(aden_nr - aden_sci), aden = (aden_sci, ratio) for the sweep.
 template <int T>
 __global__ void __launch_bounds__(T * T)
 k_newton(AdaptArgs q) {
-    constexpr int NC = 4 * T;
+    constexpr int NC = 4 * T, NT = T * T;
     __shared__ double colbuf[2][NC];
-    __shared__ double bbuf[2];
-    __shared__ double dg[NC], rh[NC], xs[NC + 1];
+    __shared__ double pv[NC], rh[NC], xs[NC + 1];
+    __shared__ double s_f[128], s_ps[128], s_nk[128], s_ln[128];  // per-state vectors (Kp <= 128)
+    __shared__ int smp[NC + 1], pos[128];                          // sampled list (m <= NC) and its inverse
     if (q.ctl[CTL_DONE] != 0) return;
     const int tid = threadIdx.x, ty = tid / T, tx = tid % T;
     const int M = q.m - 1, nb = q.Kp / 16;
+    // Everything the kernel indexes indirectly goes through LDS first: a dependent global load costs ~1 us, and the
+    // tile set-up below would otherwise chain two of them in front of each of its 16 Gram loads.
+    for (int k = tid; k < q.Kp; k += NT) {
+        s_f[k] = k < q.K ? q.f[k] : 0.0;
+        s_ps[k] = q.psum[k];
+        s_nk[k] = q.Nk[k];
+        s_ln[k] = q.lnNk[k];
+        pos[k] = 0;
+    }
+    for (int i = tid; i < q.m; i += NT) smp[i] = q.sampled[i];
+    __syncthreads();
+    for (int i = tid; i < q.m; i += NT) pos[smp[i]] = i;
 
+    int ki[4], kj[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ty + T * r, k = tx + T * r;
+        ki[r] = i < M ? smp[i + 1] : 0;
+        kj[r] = k < M ? smp[k + 1] : 0;
+    }
     double A[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)  // 16 independent loads (always a valid address; masked below)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) A[r][c] = -gram_elem(q.gram_red, nb, ki[r], kj[c]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int i = 4 * ty + r, k = 4 * tx + c;
-            double v = 0.0;
+            const int i = ty + T * r, k = tx + T * c;
+            double v = A[r][c];
             if (i < M) {
-                const int ki = q.sampled[i + 1];
                 if (k < M) {
-                    const int kj = q.sampled[k + 1];
-                    v = -gram_elem(q.gram_red, nb, ki, kj);
-                    if (i == k) v += q.psum[ki];
-                } else if (k == NC - 1) {
-                    v = q.psum[ki] - q.Nk[ki];
+                    if (i == k) v += s_ps[ki[r]];
+                } else {
+                    v = (k == NC - 1) ? s_ps[ki[r]] - s_nk[ki[r]] : 0.0;
                 }
-            } else if (i == k && k != NC - 1) {
-                v = 1.0;  // padding rows: identity, never a pivot, multiplier 0
+            } else {
+                v = (i == k && k != NC - 1) ? 1.0 : 0.0;  // padding rows: identity, never a pivot, multiplier 0
             }
             A[r][c] = v;
         }
     }
-    if (M > 0) {
-        if (tx == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) colbuf[0][4 * ty + r] = A[r][0];
-        }
-        if (tx == T - 1 && ty == 0) bbuf[0] = A[0][3];
-    }
-    __syncthreads();
     bool bad = false;
-    for (int j0 = 0; j0 < M; j0 += 4) {
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-            const int j = j0 + c4;
-            if (j < M) {  // (uniform)
-                const double* cb = colbuf[c4 & 1];  // == colbuf[j & 1]
-                const double piv = cb[j];
-                if (!(piv > 0.0) || !isfinite(piv)) bad = true;  // the same value in every thread
-                const double inv = recip_fast(piv);
-                if (tx >= (j >> 2)) {  // columns left of the pivot are already eliminated (tx = T-1 owns b)
-                    double mr[4], rv[4];
+    for (int jc = 0; jc < 4; ++jc) {
+        const int jend = M < T * (jc + 1) ? M : T * (jc + 1);
+        for (int j = T * jc; j < jend; ++j) {
+            const int jt = j - T * jc;
+            double* cb = colbuf[j & 1];
+            if (tx == jt) {  // owners of column j
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 4 * ty + r;
-                        mr[r] = (i == j) ? 0.0 : cb[i] * inv;
-                    }
+                for (int r = 0; r < 4; ++r)
+                    if (r < 3 || ty != T - 1) cb[ty + T * r] = A[r][jc];  // (slot NC-1 belongs to b_j)
+            }
+            if (ty == jt && tx == T - 1) cb[NC - 1] = A[jc][3];  // b_j
+            __syncthreads();
+            const double piv = cb[j];
+            if (tid == 0) pv[j] = piv;
+            if (!(piv > 0.0) || !isfinite(piv)) bad = true;  // the same value in every thread
+            const double inv = recip_fast(piv);
+            double mr[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int k = 4 * tx + c;
-                        rv[c] = (k == NC - 1) ? bbuf[c4 & 1] : (k >= j ? cb[k] : 0.0);
-                    }
+            for (int r = 0; r < 4; ++r) mr[r] = cb[ty + T * r] * inv;
+            if (ty == jt) mr[jc] = 0.0;  // the pivot row itself
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+            for (int c = jc; c < 4; ++c) {
+                const double rv = cb[tx + T * c];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) A[r][c] = fma(-mr[r], rv[c], A[r][c]);
-                }
-                const int jn = j + 1;
-                if (jn < M) {
-                    if (tx == (jn >> 2)) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) colbuf[(c4 + 1) & 1][4 * ty + r] = A[r][(c4 + 1) & 3];
-                    }
-                    if (tx == T - 1 && ty == (jn >> 2)) bbuf[(c4 + 1) & 1] = A[(c4 + 1) & 3][3];
-                }
-                __syncthreads();
+                for (int r = 0; r < 4; ++r) A[r][c] = fma(-mr[r], rv, A[r][c]);
             }
         }
-    }
-    if (tx == ty) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dg[4 * ty + r] = A[r][r];
     }
     if (tx == T - 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rh[4 * ty + r] = A[r][3];
+        for (int r = 0; r < 4; ++r) rh[ty + T * r] = A[r][3];
     }
     __syncthreads();
     if (tid == 0) xs[0] = 0.0;
-    if (tid < M) xs[tid + 1] = rh[tid] / dg[tid];
+    if (tid < M) xs[tid + 1] = rh[tid] / pv[tid];
     __syncthreads();
 
     const double gamma = q.prm[0];
-    const int first = q.sampled[0];
-    const double shift = q.f[first] - log(q.psum[first] / q.Nk[first]);
+    const int first = smp[0];
+    const double shift = s_f[first] - log(s_ps[first] / s_nk[first]);
     int flags = bad ? 1 : 0;
-    if (tid < q.Kp) {
-        const int k = tid;
-        const bool smp = k < q.K && q.Nk[k] > 0.0;
-        const double fk = k < q.K ? q.f[k] : 0.0;
+    for (int k = tid; k < q.Kp; k += NT) {
+        const bool sampled = k < q.K && s_nk[k] > 0.0;
+        const double fk = s_f[k];
         double fs = fk, fn = fk, a0 = -INFINITY, rt = 1.0;
-        if (smp) {
-            int lo = 0, hi = q.m - 1;  // position of k in the (ascending) sampled list
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (q.sampled[mid] < k) lo = mid + 1; else hi = mid;
-            }
-            fn = fk - gamma * xs[lo];                            // :584
-            fs = (fk - log(q.psum[k] / q.Nk[k])) - shift;        // :587-588
-            a0 = fs + q.lnNk[k];
-            const double d = (fn + q.lnNk[k]) - a0;
+        if (sampled) {
+            fn = fk - gamma * xs[pos[k]];                        // :584
+            fs = (fk - log(s_ps[k] / s_nk[k])) - shift;          // :587-588
+            a0 = fs + s_ln[k];
+            const double d = (fn + s_ln[k]) - a0;
             rt = exp(d);
             if (!(fabs(d) < 300.0)) flags |= 2;
             if (!isfinite(fs) || !isfinite(fn)) flags |= 4;
@@ -2004,67 +2006,66 @@ k_newton(AdaptArgs q) {
     }
 }
 
-// Choice between the candidates and convergence test, one workgroup.  The scalar reductions run serially in thread 0
-// in the host loop's order (at most 128 terms), so both loops take the same decisions from the same sums.
+// Choice between the candidates and convergence test, one workgroup of 256 threads (one state per thread).  The two
+// gradient norms are fixed-order tree sums (deterministic; the host loop adds the same terms serially, so a round-off
+// tie between the candidates may fall differently there), the convergence measures are maxima.
+__device__ __forceinline__ double block256_sum(double v, double* red /*[4]*/) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double block256_max(double v, double* red /*[4]*/) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
 __global__ void __launch_bounds__(256)
 k_select(AdaptArgs q) {
-    __shared__ double ps[2][256], d1[256], d2[256];
-    __shared__ int s_choice;
-    __shared__ double s_gn[2];
+    __shared__ double red[4];
     int* ctl = q.ctl;
     if (ctl[CTL_DONE] != 0) return;
     const int tid = threadIdx.x, Kp = q.Kp;
     const double tol = q.prm[1];
     const int min_sc = (int)q.prm[2];
     const bool check = q.prm[3] != 0.0;
-    if (tid < Kp) {
-        ps[0][tid] = q.lse_red[tid];
-        ps[1][tid] = q.lse_red[Kp + tid] * q.ratio[tid];  // the sweep accumulates e_k / s' : times c_k = its psum
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double gs = 0.0, gn = 0.0;
-        for (int i = 0; i < q.m; ++i) {
-            const int k = q.sampled[i];
-            const double a = ps[0][k] - q.Nk[k], b = ps[1][k] - q.Nk[k];
-            gs += a * a;
-            gn += b * b;
-        }
-        s_gn[0] = gs;
-        s_gn[1] = gn;
-        s_choice = (gs < gn || ctl[CTL_SCI] < min_sc) ? 0 : 1;  // :607
-    }
-    __syncthreads();
-    const int ch = s_choice;
-    if (tid < Kp) {
-        const double fo = q.f[tid];
-        const double fs = q.cand[tid], fn = q.cand[Kp + tid];
-        const double fnew = ch == 0 ? fs : fn;
-        const bool smp = tid < q.K && q.Nk[tid] > 0.0;
+    const int first = q.sampled[0];
+    const bool in = tid < Kp;
+    const double nk = in ? q.Nk[tid] : 0.0;
+    const bool sampled = in && tid < q.K && nk > 0.0;
+    const double ps0 = in ? q.lse_red[tid] : 0.0;
+    const double ps1 = in ? q.lse_red[Kp + tid] * q.ratio[tid] : 0.0;  // the sweep accumulates e_k / s' : times c_k = its psum
+    const double fo = in ? q.f[tid] : 0.0, fs = in ? q.cand[tid] : 0.0, fn = in ? q.cand[Kp + tid] : 0.0;
+    const double lnk = in ? q.lnNk[tid] : 0.0;
+    const double ga = sampled ? ps0 - nk : 0.0, gb = sampled ? ps1 - nk : 0.0;
+    const double gs = block256_sum(ga * ga, red);
+    const double gn = block256_sum(gb * gb, red);
+    const int ch = (gs < gn || ctl[CTL_SCI] < min_sc) ? 0 : 1;  // :607 (every thread holds the same sums)
+    const double fnew = ch == 0 ? fs : fn;
+    if (in) {
         q.f[tid] = fnew;
-        q.psum[tid] = ps[ch][tid];
-        q.anum[tid] = smp ? fnew + q.lnNk[tid] : -INFINITY;
-        const double small = tol < 1e-8 ? tol : 1e-8;
-        const double div = fabs(fnew) < small ? 1.0 : fabs(fnew);
-        d1[tid] = fabs(fnew - fo) / div;   // :627-631
-        d2[tid] = fabs(fs - fn) / div;     // :632-633
+        q.psum[tid] = ch == 0 ? ps0 : ps1;
+        q.anum[tid] = sampled ? fnew + lnk : -INFINITY;
     }
-    __syncthreads();
+    // convergence measures over the sampled states except the gauge state (:627-633); NaN: see the host loop
+    const bool counts = sampled && tid != first;
+    const double small = tol < 1e-8 ? tol : 1e-8;
+    const double div = fabs(fnew) < small ? 1.0 : fabs(fnew);
+    const double d1 = counts ? fabs(fnew - fo) / div : 0.0;
+    const double d2 = counts ? fabs(fs - fn) / div : 0.0;
+    const double nan_seen = block256_max((d1 != d1) ? 1.0 : 0.0, red);
+    double max_delta = block256_max(d1 != d1 ? 0.0 : d1, red);
+    const double max_diff = block256_max(d2 != d2 ? 0.0 : d2, red);
+    if (nan_seen > 0.0) max_delta = NAN;
     if (tid == 0) {
-        double max_delta = 0.0, max_diff = 0.0;
-        bool nan_seen = false;
-        for (int i = 1; i < q.m; ++i) {  // the first sampled state is the gauge
-            const int k = q.sampled[i];
-            if (d1[k] != d1[k]) nan_seen = true;
-            max_delta = max_delta < d1[k] ? d1[k] : max_delta;
-            max_diff = max_diff < d2[k] ? d2[k] : max_diff;
-        }
-        if (nan_seen) max_delta = NAN;
         const int it = ctl[CTL_ITER];
         if (it < q.hist_cap) {
             q.hist[4 * (int64_t)it + 0] = ch;
-            q.hist[4 * (int64_t)it + 1] = sqrt(s_gn[0]);
-            q.hist[4 * (int64_t)it + 2] = sqrt(s_gn[1]);
+            q.hist[4 * (int64_t)it + 1] = sqrt(gs);
+            q.hist[4 * (int64_t)it + 2] = sqrt(gn);
             q.hist[4 * (int64_t)it + 3] = max_delta;
         }
         q.state[0] = max_delta;
@@ -2201,8 +2202,12 @@ static hipError_t launch_kernel_lse(Kern kern, hipStream_t s, const LaunchGeom& 
         if (e != hipSuccess) return e;
     }
     const int64_t ntiles = (N + TS - 1) / TS;
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
-                       l1, dn, psum_part, obj_part, lc.ctl, lc.slot_stride);
+    if (lc.ev_start && lc.ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, u, ld, N,
+                              ntiles, aden, cw, l0, l1, dn, psum_part, obj_part, lc.ctl, lc.slot_stride);
+    else
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
+                           l1, dn, psum_part, obj_part, lc.ctl, lc.slot_stride);
     return hipGetLastError();
 }
 
@@ -2344,8 +2349,12 @@ static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double
             if (e != hipSuccess) return e;
         }
         const int64_t ntiles = (N + TS - 1) / TS;
-        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, ai, aj,
-                           logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride);
+        if (lc.ev_start && lc.ev_stop)
+            hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, u, ld,
+                                  N, ntiles, ai, aj, logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride);
+        else
+            hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, ai, aj,
+                               logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride);
         return hipGetLastError();
     };
     return stage_offsets_wide(ld) ? launch(k_gram<NBI, NBJ, DIAG, DMA, true>) : launch(k_gram<NBI, NBJ, DIAG, DMA, false>);
@@ -2562,7 +2571,7 @@ hipError_t launch_reduce2(hipStream_t s, const double* partA, int64_t countA, co
 hipError_t launch_newton(hipStream_t s, const AdaptArgs& a) {
     const int M = a.m - 1;
     if (M > 127 || a.Kp > 128) return hipErrorInvalidValue;
-    if (M <= 31 && a.Kp <= 64)
+    if (M <= 31)
         hipLaunchKernelGGL(k_newton<8>, dim3(1), dim3(64), 0, s, a);
     else if (M <= 63)
         hipLaunchKernelGGL(k_newton<16>, dim3(1), dim3(256), 0, s, a);
