@@ -1521,7 +1521,7 @@ int mbar_lognum(mbar_ctx* c, const double* f, double* lognum) {
         std::fill(lognum, lognum + c->K, std::numeric_limits<double>::quiet_NaN());
         return MBAR_OK;
     }
-    const int64_t nch = lognum_chunks(c->N);
+    const int64_t nch = lognum_chunks(c->N, c->K);
     rc = ensure(c, &c->lognum_part, &c->lognum_part_doubles, (size_t)2 * c->K * nch + 2 * c->K);
     if (rc) return rc;
     double* pmax = c->lognum_part;

@@ -100,7 +100,7 @@ hipError_t launch_reduce(hipStream_t s, const double* part, int64_t nparts, int6
 hipError_t launch_lognum(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K,
                          const double* anum, const double* logden,
                          double* pmax /*[K][nchunks]*/, double* psum /*[K][nchunks]*/, int64_t nchunks);
-int64_t lognum_chunks(int64_t N);
+int64_t lognum_chunks(int64_t N, int64_t K);
 hipError_t launch_lognum_merge(hipStream_t s, const double* pmax, const double* psum, int64_t K,
                                int64_t nchunks, double* out_max /*[K]*/, double* out_sum /*[K]*/);
 hipError_t launch_logw(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K,

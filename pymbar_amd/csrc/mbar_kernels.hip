@@ -503,8 +503,12 @@ struct RowTwoPanels {
 // One exp per matrix element in total: e = exp(x - max) is kept in registers, normalised by the reciprocal of
 // its sum, and re-used for the second candidate through the per-state ratio c_k.
 // ---------------------------------------------------------------------------------------------
+// Waves per workgroup of the default sweep: a 16-sample tile of few states is small, so more waves fit into LDS next to
+// the tables and the SIMDs get 2-4 waves each to hide the latency of the tile stream (K <= 64 ran one wave per SIMD at
+// 4.9 TB/s).
+constexpr int lse_waves(int nb) { return nb <= 2 ? 16 : (nb <= 4 ? 8 : (nb <= 8 ? 4 : 2)); }
 template <int NB, int NF, bool DMA, bool WIDE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * lse_waves(NB))
 k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
       const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
       double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
@@ -1661,45 +1665,75 @@ k_reduce(const double* __restrict__ part, int64_t nparts, int64_t count, int64_t
     out[(int64_t)blockIdx.y * count + i] = s;
 }
 
-// Robust per-state log-sum-exp over samples (log space, like the reference's second logsumexp):
-// one wave = 512 consecutive samples; for every state k the wave emits its max and its sum of exp(x - max).
-constexpr int LOGNUM_CHUNK = 512;  // samples per wave: 8 per lane, no workgroup-level synchronisation
+// Robust per-state log-sum-exp over samples (log space, like the reference's second logsumexp, mbar_solvers.py:240-241):
+//   lognum_k = log sum_n exp(anum_k - u_kn - logden_n)   for ALL states (unsampled ones have no usable shift a priori).
+// One wave owns LN_ROWS state rows x a contiguous range of samples, ONE SAMPLE PER LANE per 64-sample tile, and keeps a
+// running (max, scaled sum) per state in registers:  d = x - m;  e = exp(-|d|);  s = d > 0 ? s e + 1 : s + e;  m = max(m, x)
+// -- one table exponential per matrix element, no cross-lane traffic inside the loop (the previous version reduced
+// across the wave twice per state per 512 samples and called the library exp: VALU-bound at 3.8 TB/s).  The LN_ROWS
+// row loads of a tile are independent 512-byte requests; two tiles are in flight per wave.  Each wave emits one
+// (max, sum) record per state; k_lognum_merge combines them.
+constexpr int LN_ROWS = 8;
+constexpr int LN_TILE = 64;
+template <bool MASKED>
+__device__ __forceinline__ void lognum_tile(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K, int64_t k0,
+                                            int64_t n, const double* __restrict__ logden, const double (&a)[LN_ROWS],
+                                            double (&m)[LN_ROWS], double (&s)[LN_ROWS]) {
+    const bool ok = !MASKED || n < N;
+    const int64_t nn = ok ? n : 0;
+    double v[LN_ROWS];
+#pragma unroll
+    for (int i = 0; i < LN_ROWS; ++i) v[i] = (k0 + i < K) ? u[(k0 + i) * ld + nn] : 0.0;
+    const double nl = -logden[nn];
+#pragma unroll
+    for (int i = 0; i < LN_ROWS; ++i) {
+        double x = (a[i] + nl) - v[i];
+        if (MASKED && !ok) x = -INFINITY;
+        const double d = x - m[i];  // NaN only for -inf - -inf: laundered to e = 0 by the clamp, and "d > 0" is false
+        const double e = exp2s_fast(-fabs(d) * LOG2E_S);
+        s[i] = d > 0.0 ? fma(s[i], e, 1.0) : s[i] + e;
+        m[i] = fmax(m[i], x);
+    }
+}
 __global__ void __launch_bounds__(256)
 k_lognum(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
          const double* __restrict__ anum, const double* __restrict__ logden,
-         double* __restrict__ pmax, double* __restrict__ psum, int64_t nchunks) {
-    constexpr int SPL = LOGNUM_CHUNK / 64;
+         double* __restrict__ pmax, double* __restrict__ psum, int64_t nchunks, int64_t tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    exp_table_init(smem);
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t c = (int64_t)blockIdx.x * 4 + wave;  // one chunk of 512 consecutive samples per wave
+    const int64_t nsb = (K + LN_ROWS - 1) / LN_ROWS;
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;  // neighbouring waves: same sample range, different state rows
+    const int64_t c = w / nsb, k0 = (w % nsb) * LN_ROWS;
     if (c >= nchunks) return;
-    double nl[SPL];
-    bool ok[SPL];
+    double a[LN_ROWS], m[LN_ROWS], s[LN_ROWS];
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-        const int64_t n = c * LOGNUM_CHUNK + j * 64 + lane;
-        ok[j] = n < N;
-        nl[j] = ok[j] ? -logden[n] : 0.0;
+    for (int i = 0; i < LN_ROWS; ++i) {
+        a[i] = (k0 + i < K) ? anum[k0 + i] : 0.0;
+        m[i] = -INFINITY;
+        s[i] = 0.0;
     }
-    for (int64_t k = 0; k < K; ++k) {
-        const double ak = anum[k];
-        double v[SPL];
-        double m = -INFINITY;
+    const int64_t ntiles = (N + LN_TILE - 1) / LN_TILE;
+    const int64_t t0 = c * tiles_per_chunk;
+    int64_t t1 = t0 + tiles_per_chunk;
+    if (t1 > ntiles) t1 = ntiles;
+    const int64_t tfull = (t1 * LN_TILE <= N) ? t1 : t1 - 1;  // only the very last tile of the matrix can be ragged
+    int64_t t = t0;
+    for (; t + 1 < tfull; t += 2) {
+        lognum_tile<false>(u, ld, N, K, k0, t * LN_TILE + lane, logden, a, m, s);
+        lognum_tile<false>(u, ld, N, K, k0, (t + 1) * LN_TILE + lane, logden, a, m, s);
+    }
+    for (; t < tfull; ++t) lognum_tile<false>(u, ld, N, K, k0, t * LN_TILE + lane, logden, a, m, s);
+    for (; t < t1; ++t) lognum_tile<true>(u, ld, N, K, k0, t * LN_TILE + lane, logden, a, m, s);
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            const int64_t n = c * LOGNUM_CHUNK + j * 64 + lane;
-            v[j] = ok[j] ? (ak + nl[j] - u[k * ld + n]) : -INFINITY;
-            m = fmax(m, v[j]);
-        }
-        m = wave_max(m);
-        double s = 0.0;
-        if (m > -INFINITY) {
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) s += exp(v[j] - m);  // exp(-inf) = 0 for masked samples
-        }
-        s = wave_sum(s);
-        if (lane == 0) {
-            pmax[k * nchunks + c] = m;
-            psum[k * nchunks + c] = s;
+    for (int i = 0; i < LN_ROWS; ++i) {
+        const double mw = wave_max(m[i]);
+        const double sc = (m[i] > -INFINITY) ? s[i] * exp(m[i] - mw) : 0.0;  // (mw = -inf only if every lane's m is)
+        const double sw = wave_sum(sc);
+        if (lane == 0 && k0 + i < K) {
+            pmax[(k0 + i) * nchunks + c] = mw;
+            psum[(k0 + i) * nchunks + c] = sw;
         }
     }
 }
@@ -2144,7 +2178,7 @@ LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid
         g.blocks = (int)(want < cap ? want : cap);
         g.nwaves = g.blocks * streams * 2;  // one partial record per wave
     } else {
-        g.waves = nb <= 8 ? 4 : 2;
+        g.waves = lse_waves(nb);
         g.lds_bytes = (size_t)g.waves * 2 * tile + EXP_TABLE_BYTES;
         int64_t want = (ntiles + g.waves - 1) / g.waves;
         cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
@@ -2466,12 +2500,28 @@ hipError_t launch_reduce(hipStream_t s, const double* part, int64_t nparts, int6
     return hipGetLastError();
 }
 
-int64_t lognum_chunks(int64_t N) { return (N + LOGNUM_CHUNK - 1) / LOGNUM_CHUNK; }
+// Sample ranges of the per-state log-space reduction: enough waves (state-row groups x ranges) to fill the chip a few
+// times over, each with a long run of tiles.
+static int64_t lognum_tiles_per_chunk(int64_t N, int64_t K) {
+    const int64_t ntiles = (N + LN_TILE - 1) / LN_TILE;
+    const int64_t nsb = (K + LN_ROWS - 1) / LN_ROWS;
+    int64_t target = 16384 / nsb;
+    if (target < 1) target = 1;
+    int64_t tpc = (ntiles + target - 1) / target;
+    return tpc < 1 ? 1 : tpc;
+}
+int64_t lognum_chunks(int64_t N, int64_t K) {
+    const int64_t ntiles = (N + LN_TILE - 1) / LN_TILE;
+    const int64_t tpc = lognum_tiles_per_chunk(N, K);
+    return (ntiles + tpc - 1) / tpc;
+}
 
 hipError_t launch_lognum(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, const double* anum,
                          const double* logden, double* pmax, double* psum, int64_t nchunks) {
-    hipLaunchKernelGGL(k_lognum, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, s, u, ld, N, K, anum, logden, pmax, psum,
-                       nchunks);
+    const int64_t nsb = (K + LN_ROWS - 1) / LN_ROWS;
+    const int64_t waves = nsb * nchunks;
+    hipLaunchKernelGGL(k_lognum, dim3((unsigned)((waves + 3) / 4)), dim3(256), EXP_TABLE_BYTES, s, u, ld, N, K, anum, logden, pmax,
+                       psum, nchunks, lognum_tiles_per_chunk(N, K));
     return hipGetLastError();
 }
 

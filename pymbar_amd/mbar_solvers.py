@@ -344,11 +344,16 @@ def solve_mbar_once(u_kn_nonzero, N_k_nonzero, f_k_nonzero, method="adaptive", t
     u_kn_nonzero, N_k_nonzero, f_k_nonzero = validate_inputs(u_kn_nonzero, np.asarray(N_k_nonzero), f_k_nonzero)
     f_k_nonzero = f_k_nonzero - f_k_nonzero[0]
     N_k_nonzero = 1.0 * N_k_nonzero
-    if np.any(N_k_nonzero <= 0):
-        raise ParameterError("solve_mbar_once requires N_k > 0 for every state; drop the unsampled states first")
     options = dict() if options is None else options
+    # The reference does not check N_k here (its caller passes sampled states only, mbar_solvers.py:1002-1006); states
+    # with N_k <= 0 are tolerated like it tolerates them: they carry no weight in any sum, are left out of the unknowns
+    # and keep the f_k they came with.
+    sampled = np.where(N_k_nonzero > 0)[0]
+    if sampled.size == 0:
+        raise ParameterError("solve_mbar_once needs at least one state with N_k > 0")
+    N_k_nonzero = np.where(N_k_nonzero > 0, N_k_nonzero, 0.0)
+    f_k_nonzero = f_k_nonzero - f_k_nonzero[sampled[0]]  # gauge on the first state that has samples
     with _Resident(u_kn_nonzero) as h:
-        sampled = np.arange(h.shape[0])
         return _solve_once_resident(h, N_k_nonzero, f_k_nonzero, sampled, method, tol, options)
 
 

@@ -122,6 +122,21 @@ def test_all_states_with_unsampled_state(golden):
     np.testing.assert_allclose(f2 - f2[1], g["f_k"][[2, 0, 1, 3]] - g["f_k"][0], rtol=1e-9, atol=1e-9)
 
 
+def test_solve_mbar_once_tolerates_unsampled_states(golden):
+    """The reference's solve_mbar_once does not check N_k (mbar_solvers.py:738-883): a state with N_k = 0 carries no
+    weight; here it is left out of the unknowns and keeps its f_k, the sampled states get the reference's solution."""
+    g = golden("ho_unsampled_K4_N2300.npz")
+    N_k = g["N_k"]
+    assert np.any(N_k == 0)
+    sws = np.where(N_k != 0)[0]
+    for method in ("adaptive", "hybr", "L-BFGS-B"):
+        f, res = ms.solve_mbar_once(OracleMatrix(g["u_kn"]), N_k, np.zeros(4), method=method, tol=1e-12)
+        np.testing.assert_allclose(f[sws] - f[sws[0]], g["f_k"][sws] - g["f_k"][sws[0]], rtol=1e-8, atol=1e-9)
+        assert np.all(f[N_k == 0] == 0.0)
+    with pytest.raises(ParameterError):
+        ms.solve_mbar_once(OracleMatrix(g["u_kn"]), np.zeros(4), np.zeros(4))
+
+
 def test_single_sampled_state():
     x_n, u_kn, N_k, s_n = ts.harmonic_u_kn([0, 1], [1, 2], [50, 0], seed=1)
     f = ms.solve_mbar_for_all_states(OracleMatrix(u_kn), N_k, np.zeros(2), np.array([0]), ms.DEFAULT_SOLVER_PROTOCOL)

@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Time the UNMODIFIED reference (pymbar's numpy/scipy solver path, pymbar/mbar_solvers.py:76-87) on this host.
+
+Run it with the reference on the path and the interpreter the survey found fastest (recipe A):
+
+    PYTHONPATH=/root/reference /opt/conda/bin/python3.9 tools/time_reference.py --out profiles/r2_reference_cpu_timing.json
+
+The workload is bench.py's: the harmonic ladder O_k = linspace(0, 4, K), K_k = linspace(1, 3, K), equal N_k, K = 128, drawn
+by the reference's own HarmonicOscillatorsTestCase (so the matrix is the reference's, not ours).  K = 128, N = 1e7 needs
+~45 GB for one gradient call of the reference, so -- as SURVEY.md 8(d) prescribes -- N in {1e6, 2e6, 4e6} is timed and
+the per-iteration cost is extrapolated linearly in N (every sweep is O(K N); the iteration count does not depend on N).
+
+Timed per N: mbar_gradient, mbar_hessian, self_consistent_update (one call each), ONE adaptive iteration assembled from
+the reference's own functions exactly as mbar_solvers.py:575-607 does (Hessian, lstsq, SCI update, two gradients), and --
+for the smallest N -- the full solve_mbar_once(method="adaptive", tol=1e-12, min_sc_iter=0) with its iteration count.
+
+bench.py quotes the JSON written here as ``cpu_baseline.reference_build_host`` (the reference tree is not available
+on the GPU box, so this number is measured on the build container and committed).
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--K", type=int, default=128)
+    ap.add_argument("--N", type=int, nargs="+", default=[1_000_000, 2_000_000, 4_000_000])
+    ap.add_argument("--full-solve-N", type=int, default=1_000_000)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+
+    import pymbar
+    from pymbar import mbar_solvers as ref
+    from pymbar.testsystems import harmonic_oscillators
+
+    assert os.path.realpath(pymbar.__file__).startswith("/root/reference"), pymbar.__file__
+    import scipy
+
+    K = args.K
+    O_k = np.linspace(0.0, 4.0, K)
+    K_k = np.linspace(1.0, 3.0, K)
+    rows = []
+    for N in args.N:
+        N_k = np.full(K, N // K, dtype=np.int64)
+        tc = harmonic_oscillators.HarmonicOscillatorsTestCase(O_k, K_k)
+        x_n, u_kn, N_k_out, s_n = tc.sample(N_k, mode="u_kn", seed=0)
+        u_kn = np.ascontiguousarray(u_kn, dtype=np.float64)
+        Nf = N_k.astype(np.float64)
+        f = tc.analytical_free_energies()
+        f = 0.9 * (f - f[0])
+
+        def timed(fn, *a):
+            t0 = time.perf_counter()
+            out = fn(*a)
+            return out, time.perf_counter() - t0
+
+        g, t_grad = timed(ref.mbar_gradient, u_kn, Nf, f)
+        H, t_hess = timed(ref.mbar_hessian, u_kn, Nf, f)
+        fs, t_sci = timed(ref.self_consistent_update, u_kn, Nf, f)
+        # one adaptive iteration, the reference's own statements (mbar_solvers.py:581-607); g at f is carried over
+        t0 = time.perf_counter()
+        H = ref.mbar_hessian(u_kn, Nf, f)
+        Hinvg = np.linalg.lstsq(H, g, rcond=-1)[0]
+        Hinvg -= Hinvg[0]
+        f_nr = f - Hinvg
+        f_sci = ref.self_consistent_update(u_kn, Nf, f)
+        f_sci = f_sci - f_sci[0]
+        g_sci = ref.mbar_gradient(u_kn, Nf, f_sci)
+        g_nr = ref.mbar_gradient(u_kn, Nf, f_nr)
+        _ = np.dot(g_sci, g_sci) < np.dot(g_nr, g_nr)
+        t_iter = time.perf_counter() - t0
+        row = dict(N=N, mbar_gradient_s=t_grad, mbar_hessian_s=t_hess, self_consistent_update_s=t_sci,
+                   adaptive_iteration_s=t_iter)
+        if N == args.full_solve_N:
+            t0 = time.perf_counter()
+            f_out, res = ref.solve_mbar_once(u_kn, Nf, np.zeros(K), method="adaptive", tol=1e-12,
+                                             options=dict(min_sc_iter=0, maxiter=10000, verbose=False))
+            row["full_solve_s"] = time.perf_counter() - t0
+            row["full_solve_success"] = bool(res["success"])
+            row["full_solve_max_abs_error_vs_analytic"] = float(np.max(np.abs((f_out - f_out[0]) - (f / 0.9))))
+        print(json.dumps(row), flush=True)
+        rows.append(row)
+        del u_kn, x_n
+
+    per_sample = np.mean([r["adaptive_iteration_s"] / r["N"] for r in rows])
+    out = {
+        "what": "UNMODIFIED reference pymbar (numpy backend, scipy logsumexp) timed on the build container",
+        "K": K,
+        "rows": rows,
+        "adaptive_iteration_seconds_per_sample": per_sample,
+        "adaptive_iteration_s_extrapolated_N1e7": per_sample * 1e7,
+        "value_iter_per_s_extrapolated_N1e7": 1.0 / (per_sample * 1e7),
+        "unit": "iter/s",
+        "kind": "reference",
+        "cores": os.cpu_count(),
+        "host": platform.processor() or platform.machine(),
+        "python": sys.version.split()[0], "numpy": np.__version__, "scipy": scipy.__version__,
+        "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS", os.environ.get("OMP_NUM_THREADS", "default (all cores)")),
+        "extrapolation": "linear in N from the rows above (every sweep is O(K N))",
+    }
+    print(json.dumps(out))
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
