@@ -98,6 +98,12 @@ int mbar_ctx_download_u(mbar_ctx* ctx, double* out, int64_t ld_out);
 int mbar_ctx_upload_rows(mbar_ctx* ctx, int64_t row0, int64_t nrows, const double* rows_host, int64_t ld_host);
 int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows);
 int mbar_ctx_row_sub(mbar_ctx* ctx, int64_t row, const double* v_host);
+/* Free-energy-surface histograms (fes.py:1383-1402: one extra column of W per populated bin, W[n, K+i] = exp(log_w_n + f_i)
+ * on the bin's samples and 0 elsewhere): rows [row0, row0 + nrows) of the augmented matrix become
+ *   u[row0 + i][n] = label[n] == i ? v[n] : +inf      (v = the target potential u_n; label[n] = bin of sample n, -1 = none)
+ * built on the device from ONE vector and ONE label array -- the N x (K + nbins) host matrix of the reference is never
+ * formed.  A +inf entry is a sample of weight zero in that state. */
+int mbar_ctx_fill_masked_rows(mbar_ctx* ctx, int64_t row0, int64_t nrows, const double* v_host, const int32_t* label_host);
 /* Fill the shard on the device with the synthetic harmonic ladder of SURVEY.md 8(d):
  * global sample n (n_global0 <= n < n_global0+N_local) belongs to the state given by the
  * cumulative N_k_global, x_n ~ Normal(O_s, K_s^-1/2) from a counter-based RNG keyed by

@@ -1333,6 +1333,25 @@ int mbar_ctx_row_sub(mbar_ctx* c, int64_t row, const double* v_host) {
     return sync_stream(c);
 }
 
+int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const double* v_host, const int32_t* label_host) {
+    if (!c || !v_host || !label_host) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > c->K) return fail(c, MBAR_ERR_ARG, "row range out of bounds");
+    if (nrows == 0) return MBAR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->vec_tmp) HIPCHK(c, hipMalloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
+    int* dlabel = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dlabel, (size_t)c->N * sizeof(int)));
+    hipError_t e = hipMemcpyAsync(c->vec_tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dlabel, label_host, (size_t)c->N * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_fill_masked_rows(c->stream, c->u + row0 * c->ld, c->ld, c->N, nrows, c->vec_tmp, dlabel);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dlabel);
+    if (e != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("mbar_ctx_fill_masked_rows: ") + hipGetErrorString(e));
+    c->u_checked = false;
+    flush_timers(c);
+    return MBAR_OK;
+}
+
 int mbar_ctx_download_u(mbar_ctx* c, double* out, int64_t ld_out) {
     if (!c || !out || ld_out < c->N) return fail(c, MBAR_ERR_ARG, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));

@@ -73,6 +73,9 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
 // that both compute every operand
 LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, int64_t grid_override, int nb8_variant);
 hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n);  // row[i] -= v[i]
+// rows[i][k] = label[k] == i ? v[k] : +inf,  i < nrows (row pitch ld)
+hipError_t launch_fill_masked_rows(hipStream_t s, double* rows, int64_t ld, int64_t n, int64_t nrows, const double* v,
+                                   const int* label);
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u,
                             int64_t ld, int64_t N, const double* anum /*indexed from row0*/,
                             const double* logden, int64_t row0, double* gram_part, double* psum_part,

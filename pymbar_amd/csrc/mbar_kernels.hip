@@ -2568,6 +2568,24 @@ hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_
     return hipGetLastError();
 }
 
+// rows[i][n] = (label[n] == i) ? v[n] : +inf  for i < nrows: one "state" per histogram bin whose only samples are the
+// bin's own (a +inf reduced potential is weight zero).  grid.y = row.
+__global__ void __launch_bounds__(256)
+k_fill_masked_rows(double* __restrict__ rows, int64_t ld, int64_t n, const double* __restrict__ v,
+                   const int* __restrict__ label) {
+    const int i = blockIdx.y;
+    double* row = rows + (int64_t)i * ld;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+        row[k] = label[k] == i ? v[k] : INFINITY;
+}
+hipError_t launch_fill_masked_rows(hipStream_t s, double* rows, int64_t ld, int64_t n, int64_t nrows, const double* v,
+                                   const int* label) {
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(k_fill_masked_rows, dim3((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048), (unsigned)nrows), dim3(256),
+                       0, s, rows, ld, n, v, label);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) k_row_sub(double* __restrict__ row, const double* __restrict__ v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) row[i] -= v[i];
 }

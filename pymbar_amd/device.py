@@ -125,6 +125,16 @@ class DeviceMatrix:
             raise ValueError("v_n must have N_local entries")
         self._check(self._lib.mbar_ctx_row_sub(self._ctx, int(row), _dptr(v_n)))
 
+    def fill_masked_rows(self, row0, nrows, v_n, label_n):
+        """Rows ``row0 + i`` (``i < nrows``) become ``v_n`` on the samples with ``label_n == i`` and ``+inf`` (weight zero)
+        elsewhere: one extra "state" per histogram bin of a free energy surface, built on the device."""
+        v_n = np.ascontiguousarray(v_n, dtype=np.float64)
+        label_n = np.ascontiguousarray(label_n, dtype=np.int32)
+        if v_n.shape != (self.N_local,) or label_n.shape != (self.N_local,):
+            raise ValueError("v_n and label_n must have N_local entries")
+        self._check(self._lib.mbar_ctx_fill_masked_rows(self._ctx, int(row0), int(nrows), _dptr(v_n),
+                                                        label_n.ctypes.data_as(C.POINTER(C.c_int32))))
+
     def set_option(self, key, value):
         self._check(self._lib.mbar_ctx_set_option(self._ctx, key.encode(), int(value)))
 

@@ -55,6 +55,12 @@ class OracleMatrix:
             self._last_v = np.asarray(v_n, dtype=np.float64).copy()
         self.u[row] -= self._last_v
 
+    def fill_masked_rows(self, row0, nrows, v_n, label_n):
+        v_n = np.asarray(v_n, dtype=np.float64)
+        label_n = np.asarray(label_n)
+        for i in range(nrows):
+            self.u[row0 + i] = np.where(label_n == i, v_n, np.inf)
+
     def to_host(self):
         return self.u.copy()
 
