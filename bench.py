@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--lse-variant", type=int, default=1)
     ap.add_argument("--gram-variant", type=int, default=2)
     ap.add_argument("--device-loop", type=int, default=1, help="0 = host-driven adaptive loop (A/B)")
+    ap.add_argument("--pmode", type=int, default=1,
+                    help="1 = the device-resident loop sweeps the resident probability matrix P = exp(a0 - u - logden(a0)) "
+                         "(no exponentials after the build); 0 = every sweep recomputes its exponentials from u (A/B)")
     ap.add_argument("--allow-host-allreduce", action="store_true", help="debugging only: do not fail when RCCL is unavailable")
     args = ap.parse_args()
 
@@ -188,6 +191,7 @@ def main():
     dm.set_option("lse_variant", args.lse_variant)
     dm.set_option("gram_variant", args.gram_variant)
     dm.set_option("device_loop", args.device_loop)
+    dm.set_option("pmode", args.pmode)
     dm.set_option("graph", 0)  # eager launches: per-kernel HIP-event timers inside the timed region (the GPU queue never
     #                            runs dry at this size: an iteration is ~5 ms of kernels against ~0.1 ms of enqueueing)
     dm.set_Nk(N_k)
@@ -259,8 +263,9 @@ def main():
         achieved_tf = flops / (gram_avg * 1e-3) * 1e-12 if gram_avg > 0 else 0.0
         achieved_gbs = bytes_pass / (lse_avg * 1e-3) * 1e-9 if lse_avg > 0 else 0.0
         ms_step = 1e3 * elapsed / args.steps
+        pm = bool(args.pmode and args.device_loop and args.staging == 0)
         tr_g, src_g = pmc_traffic("k_gram<", K, n_loc)
-        tr_l, src_l = pmc_traffic("k_lse<8, 2", K, n_loc)
+        tr_l, src_l = pmc_traffic("k_psweep<8, 2" if pm else "k_lse<8, 2", K, n_loc)
         out = {
             "metric": "mbar_adaptive_iterations_per_sec",
             "value": it_per_s,
@@ -280,9 +285,10 @@ def main():
                             f"fp64, generated in HBM",
                 "K": K, "N_per_gpu": n_loc, "N_total": N_total, "parallelism": f"N-sharded x{world}",
                 "allreduce": allreduce, "device": info["name"], "adaptive_loop": "device-resident" if args.device_loop else "host-driven",
+                "sweeps": "resident probability matrix (built once per solver call, inside the timed region)" if pm else "exponentials recomputed from u in every sweep",
             },
             "roofline": {
-                "kernel": ({0: "k_gram_xchg<8>", 1: "k_gram_pair<8>"}.get(args.gram_variant, "k_gram<8,8> one wave per SIMD") + " (fp64 MFMA W^T W)") if K == 128 else "k_gram",
+                "kernel": ({0: "k_gram_xchg<8>", 1: "k_gram_pair<8>"}.get(args.gram_variant, "k_gram<8,8> one wave per SIMD" + (", operands P / s" if pm else ", operands by table exp")) + " (fp64 MFMA W^T W)") if K == 128 else "k_gram",
                 "bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": tr_g,
                 "traffic_source": f"committed PMC pass {src_g} (not collected in this run)" if src_g else None,
@@ -290,7 +296,8 @@ def main():
                 "measured_mfma_f64_peak_tflops": mfma_peak,
             },
             "roofline_lse": {
-                "kernel": "k_lse<8,2> (log-sum-exp + per-state sums, 2 candidates per sweep, one exp per element)",
+                "kernel": ("k_psweep<8,2> (normalisers + per-state sums of 2 candidates from the resident probability matrix, no exp)"
+                           if pm else "k_lse<8,2> (log-sum-exp + per-state sums, 2 candidates per sweep, one exp per element)"),
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": tr_l,
                 "traffic_source": f"committed PMC pass {src_l} (not collected in this run)" if src_l else None,

@@ -79,7 +79,11 @@ int mbar_device_synchronize(int device);
  *   "wide_k_kernel"  1 = single-buffer sweep with four waves per CU for 129 <= K <= 256 (default), 0 = off
  *   "device_loop"    1 = adaptive iterations run device-resident where possible (default), 0 = host-driven loop
  *   "adapt_batch"    adaptive iterations enqueued between two looks at the control words (default 8)
- *   "graph", "sci_batch", "timing"   hipGraph batching of the solver loops; HIP-event timers (mbar_ctx_timing) */
+ *   "pmode"          1 = the device-resident loop keeps P = exp(a0 - u - logden(a0)) resident (one more K x N array, built
+ *                    once per solve) and sweeps that: no exponentials in the loop (default); 0 = sweeps recompute them from u
+ *   "graph", "sci_batch"             hipGraph batching of the solver loops
+ *   "timing"         HIP-event timers (mbar_ctx_timing): 1 = event records around a launch (default), 2 = events bound to
+ *                    the kernel dispatch in the device-resident loop (no marker packets between kernels), 0 = off */
 int mbar_ctx_set_option(mbar_ctx* ctx, const char* key, int64_t value);
 
 /* ---- data ---------------------------------------------------------------------------------- */

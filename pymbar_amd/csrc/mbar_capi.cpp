@@ -73,6 +73,7 @@ struct mbar_ctx {
     int64_t K = 0, Kp = 0, N = 0, ld = 0;
     bool have_Nk = false;
     bool u_checked = false, u_poison = false;  // NaN / -inf entries found in the matrix
+    bool u_posinf = true;                      // +inf entries (legal) may be present: keep the exponentials clamped
     std::vector<double> Nk, lnNk;   // K
     std::vector<int> sampled;       // indices with N_k > 0
     // device
@@ -107,10 +108,14 @@ struct mbar_ctx {
     int* h_ctl = nullptr;           // pinned mirror of the control words
     hipGraphExec_t ad_graph = nullptr;
     int64_t ad_graph_batch = 0, ad_graph_sig = 0;
+    // P mode of that loop: resident probability matrix exp(a0 - u - logden(a0)), Kp x ld doubles, built once per solve
+    double* P = nullptr;
+    bool P_failed = false;          // the allocation did not fit: stay in the classic mode for the life of the context
+    double* pm_vec = nullptr;       // a0[Kp] | ccur[Kp]
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_allreduce_fn host_reduce = nullptr;
@@ -240,12 +245,13 @@ int refresh_poison(mbar_ctx* c) {
     if (c->nranks > 1) {
         // a NaN in ONE shard poisons the sums of every rank: agree on the flag, so that all ranks take the same early
         // return (a clean rank would otherwise wait in the all-reduce of a sweep the poisoned rank never launches)
-        double v = (double)h;
-        int rc = allreduce_host(c, &v, 1, 1);
+        double v[2] = {(h & 3) ? 1.0 : 0.0, (h & 4) ? 1.0 : 0.0};
+        int rc = allreduce_host(c, v, 2, 1);
         if (rc) return rc;
-        h = (int)v;
+        h = (v[0] > 0.0 ? 1 : 0) | (v[1] > 0.0 ? 4 : 0);
     }
-    c->u_poison = h != 0;
+    c->u_poison = (h & 3) != 0;
+    c->u_posinf = (h & 4) != 0;
     c->u_checked = true;
     return MBAR_OK;
 }
@@ -464,8 +470,12 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
         {
             ScopedTimer t(c, MBAR_TIMER_GRAM);
             if (it.diag)
+            {
+                LoopCtl lo;
+                lo.unclamped = c->u_checked && !c->u_posinf;
                 HIPCHK(c, launch_gram_diag(c->stream, it.nbi, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, logden,
-                                           it.ri, gp, nullptr));
+                                           it.ri, gp, nullptr, lo));
+            }
             else
                 HIPCHK(c, launch_gram_off(c->stream, it.nbj, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
                                           logden, it.ri, it.rj, gp));
@@ -925,9 +935,26 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     if (rc) return rc;
     rc = ensure_ad(c, history ? history_rows : 0);
     if (rc) return rc;
+    // P mode: the sweeps run on the resident probability matrix (one more K x N array); if it does not fit, or with
+    // register staging, the classic sweeps on u are used
+    bool pmode = c->opt_pmode && dma && !c->P_failed;
+    if (pmode && !c->P) {
+        rc = drop_graphs(c);
+        if (rc) return rc;
+        if (hipMalloc((void**)&c->P, (size_t)Kp * c->ld * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->P = nullptr;
+            c->P_failed = true;
+            pmode = false;
+        } else {
+            HIPCHK(c, hipMemsetAsync(c->P, 0, (size_t)Kp * c->ld * sizeof(double), c->stream));
+        }
+    }
+    if (pmode && !c->pm_vec) HIPCHK(c, hipMalloc((void**)&c->pm_vec, (size_t)2 * Kp * sizeof(double)));
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     const LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
-    const LaunchGeom gl = lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+    const LaunchGeom gl = pmode ? psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid)
+                                : lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
     const size_t rec_g = (size_t)nb * (nb + 1) / 2 * 256;
     const size_t rec_l = (size_t)2 * Kp;
     const size_t off_gram = rec_l + 2;
@@ -962,6 +989,15 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         HIPCHK(c, hipMemcpyAsync(c->ad, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->ad_ints, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (pmode) {  // build point a0 = aden(f), multipliers of the current f = 1, P from u with the logden of slot 0
+            std::vector<double> pv((size_t)2 * Kp, 1.0);
+            std::copy(an.begin(), an.end(), pv.begin());
+            for (int64_t k = 0; k < Kp; ++k)
+                if (!(k < K && c->Nk[k] > 0.0)) pv[(size_t)Kp + k] = 0.0;
+            HIPCHK(c, hipMemcpyAsync(c->pm_vec, pv.data(), pv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            ScopedTimer t(c, MBAR_TIMER_OTHER);
+            HIPCHK(c, launch_build_p(c->stream, c->u, c->ld, c->N, Kp, c->pm_vec, c->logden[0], c->P, c->logden[0]));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     AdaptArgs q;
@@ -984,14 +1020,24 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     q.state = c->ad + ad_off_state(c);
     q.hist = c->ad + ad_off_hist(c);
     q.hist_cap = c->ad_hist_cap;
-    const LoopCtl lc_slot{c->ad_ints, c->ld}, lc_flat{c->ad_ints, 0};
+    q.pmode = pmode ? 1 : 0;
+    q.a0 = c->pm_vec;
+    q.ccur = pmode ? c->pm_vec + Kp : nullptr;
+    LoopCtl lc_slot, lc_flat;
+    lc_slot.ctl = lc_flat.ctl = c->ad_ints;
+    lc_slot.slot_stride = c->ld;
+    lc_slot.unclamped = lc_flat.unclamped = c->u_checked && !c->u_posinf;
+    lc_slot.pmode = lc_flat.pmode = pmode;
 
     auto enqueue_iteration = [&](bool timed) -> int {
         // ---- pass A: Gram at f with the known logden (the slot of the accepted candidate) ----
-        const double* lden = c->logden[0];
+        const double* lden = c->logden[0];  // (P mode: the slots hold the reciprocals 1 / s_n instead of logden)
         LoopCtl lca = lc_slot;
-        if (c->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent
-            HIPCHK(c, launch_shift_logden(c->stream, c->logden[0], c->cw, 0.5, c->N, c->lden_eff, lc_slot));
+        if (c->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent / the reciprocal
+            if (pmode)
+                HIPCHK(c, launch_rinv_weighted(c->stream, c->logden[0], c->cw, c->N, c->lden_eff, lc_slot));
+            else
+                HIPCHK(c, launch_shift_logden(c->stream, c->logden[0], c->cw, 0.5, c->N, c->lden_eff, lc_slot));
             lden = c->lden_eff;
             lca = lc_flat;
         }
@@ -1002,7 +1048,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             const bool ext = tp.a && tp.b && c->opt_timing == 2;
             if (ext) { lca.ev_start = tp.a; lca.ev_stop = tp.b; }
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
-            HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, c->u, c->ld, c->N, d_anum(c), lden, 0, c->part, nullptr, lca));
+            HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, c->part,
+                                       nullptr, lca));
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
             if (tp.a && tp.b) c->pending.push_back(tp);
         }
@@ -1022,12 +1069,19 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             LoopCtl lcb = lc_slot;
             if (ext) { lcb.ev_start = tp.a; lcb.ev_stop = tp.b; }
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
-            HIPCHK(c, launch_lse(c->stream, nb, 2, dma, gl, c->u, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, nullptr,
-                                 psum_part, obj_part, lcb));
+            if (pmode)
+                HIPCHK(c, launch_psweep(c->stream, nb, 2, gl, c->P, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, psum_part,
+                                        lcb));
+            else
+                HIPCHK(c, launch_lse(c->stream, nb, 2, dma, gl, c->u, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr,
+                                     nullptr, psum_part, obj_part, lcb));
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
             if (tp.a && tp.b) c->pending.push_back(tp);
         }
-        HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, obj_part, 2, gl.nwaves, c->scratch, c->red, c->red + rec_l));
+        if (pmode)  // (no objective sums in P mode: the adaptive loop does not use them)
+            HIPCHK(c, launch_reduce(c->stream, psum_part, gl.nwaves, (int64_t)rec_l, c->scratch, c->red));
+        else
+            HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, obj_part, 2, gl.nwaves, c->scratch, c->red, c->red + rec_l));
         if (c->comm) {
             int r2 = allreduce_dev(c, c->red, (int64_t)(rec_l + 2), 0);
             if (r2) return r2;
@@ -1039,8 +1093,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const int64_t batch = c->opt_adapt_batch;
     const bool use_graph = c->opt_graph && !c->comm && (maxiter - res.iterations) >= batch;
     if (use_graph) {
-        const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 8) ^ (c->weighted ? 4 : 0) ^
-                            (c->opt_staging ? 2 : 0) ^ (int64_t)nb;
+        const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 8) ^ (pmode ? 128 : 0) ^
+                            (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (int64_t)nb;
         if (!c->ad_graph || c->ad_graph_batch != batch || c->ad_graph_sig != sig) {
             if (c->ad_graph) HIPCHK(c, hipGraphExecDestroy(c->ad_graph));
             c->ad_graph = nullptr;
@@ -1112,7 +1166,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     res.sci_iter = c->h_ctl[CTL_SCI];
     res.nr_iter = c->h_ctl[CTL_NR];
     if (handed_back) {
-        static const char* why[] = {"", "the Newton system is not positive definite", "the candidates are too far apart for the fused sweep",
+        static const char* why[] = {"", "the Newton system is not positive definite", "a candidate is too far from the point the sweeps are anchored at",
                                     "a candidate is not finite"};
         const int r = c->h_ctl[CTL_REASON];
         c->error = std::string("device-resident adaptive loop handed back to the host loop: ") + why[(r >= 1 && r <= 3) ? r : 0];
@@ -1225,6 +1279,8 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->u) (void)hipFree(c->u);
     if (c->logden[0]) (void)hipFree(c->logden[0]);
     if (c->ad) (void)hipFree(c->ad);
+    if (c->P) (void)hipFree(c->P);
+    if (c->pm_vec) (void)hipFree(c->pm_vec);
     if (c->ad_ints) (void)hipFree(c->ad_ints);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->ad_graph) (void)hipGraphExecDestroy(c->ad_graph);
@@ -1273,6 +1329,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "gram_variant") c->opt_gram_variant = value;
     else if (k == "sci_batch") c->opt_sci_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
     else if (k == "device_loop") c->opt_device_loop = value;
+    else if (k == "pmode") c->opt_pmode = value;
     else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;
@@ -1665,14 +1722,26 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     int rc = refresh_poison(c);
     if (rc) return rc;
     bool on_device = device_loop_eligible(c) && !c->u_poison && f_is_finite(c, f.data(), 1) && maxiter > 0;
-    if (on_device) {
+    while (on_device) {
         bool handed_back = false;
         rc = adaptive_device_loop(c, f, tol, maxiter, min_sc_iter, gamma, check_convergence, history, history_rows, res, psum,
                                   max_delta, handed_back);
         if (rc) return rc;
-        on_device = !handed_back;
+        if (!handed_back) break;
+        // The device handed the solve back.  A step too large for the sweeps' anchor point is a one-off (typically the
+        // first Newton step from a poor start): ONE host-driven iteration, then back to the device, which re-anchors at
+        // the new f.  Anything else (Newton system not positive definite, non-finite candidate) stays on the host.
+        const bool one_off = c->h_ctl[CTL_REASON] == 2 && res.iterations + 1 < maxiter;
+        if (!one_off) {
+            on_device = false;
+            break;
+        }
+        rc = adaptive_host_loop(c, f, tol, res.iterations + 1, min_sc_iter, gamma, check_convergence, history, history_rows, res,
+                                psum, max_delta);
+        if (rc) return rc;
+        if (res.success || !f_is_finite(c, f.data(), 1)) break;
     }
-    if (!on_device && !res.success) {
+    if (!on_device && !res.success && res.iterations < maxiter) {
         rc = adaptive_host_loop(c, f, tol, maxiter, min_sc_iter, gamma, check_convergence, history, history_rows, res, psum,
                                 max_delta);
         if (rc) return rc;

@@ -44,6 +44,10 @@ struct LoopCtl {
     // optional: events bound to the kernel dispatch itself (hipExtLaunchKernelGGL): start / stop time stamps of the
     // kernel with no marker packets in the stream (an event record between two kernels costs ~6 us of idle queue)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // the matrix holds no +inf entry: the full 128-state Gram panel may run its exponentials without the clamp
+    bool unclamped = false;
+    // the matrix handed to the Gram launcher is the resident probability matrix (P mode)
+    bool pmode = false;
 };
 
 struct LaunchGeom {
@@ -146,7 +150,23 @@ struct AdaptArgs {
     double* state;           // [0] max_delta of the last iteration
     double* hist;            // rows of 4 doubles {choice, |g_sci|, |g_nr|, max_delta}
     int64_t hist_cap;
+    // P mode: the sweeps work on P = exp(a0 - u - logden(a0)); aden then holds the multipliers exp(a - a0) of BOTH
+    // candidates, ccur those of the current f (the Gram kernel returns G with both factors still to be applied)
+    int pmode;
+    const double* a0;        // [Kp] aden at the build point (-inf for unsampled / padded states)
+    double* ccur;            // [Kp]
 };
+// ---- P mode: resident probability matrix P = exp(a0 - u - logden(a0)) (see k_psweep) ----------------------------------
+LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
+// cmul: [nf][16 nb] multipliers exp(a - a0); rinv0 = base of the three slot vectors when lc.ctl is set
+hipError_t launch_psweep(hipStream_t s, int nb, int nf, const LaunchGeom& g, const double* P, int64_t ld, int64_t N,
+                         const double* cmul, const double* cw, double* rinv0, double* rinv1, double* psum_part,
+                         const LoopCtl& lc = LoopCtl());
+// P from u at a0 with the known logden(a0) (read from rinv_slot's storage BEFORE it is overwritten with ones)
+hipError_t launch_build_p(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t Kp, const double* a0,
+                          const double* logden, double* P, double* rinv_slot);
+hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,
+                                const LoopCtl& lc = LoopCtl());
 // K x K Newton system (gauge-fixed, Gauss-Jordan in registers, one workgroup) + both candidates + sweep inputs
 hipError_t launch_newton(hipStream_t s, const AdaptArgs& a);
 // gradient norms of both candidates, choice (mbar_solvers.py:607), convergence test (:627-640), next Gram operand

@@ -130,7 +130,10 @@ __device__ __forceinline__ double log_pos(double s) {
 // or two waves per SIMD nothing else hides the LDS latency of the table look-up, and hipcc's own schedule leaves
 // only a handful of instructions between each ds_read and its use.  Stage 1 issues all N table reads, stage 2 (the
 // polynomials) runs while they are in flight, stage 3 combines.  x[] in: ts, out: 2^(ts/S).
-template <int N>
+// CLAMP = false: the arguments are known to be finite (callers substitute finite sentinels for their -inf cases and the
+// matrix holds no +inf): one v_max_f64 per element less.  Finite arguments of any size are safe without the clamp --
+// v_cvt_i32_f64 saturates, so a hugely negative argument ends in ldexp(..., -2^20) = 0.
+template <int N, bool CLAMP = true>
 __device__ __forceinline__ void exp2s_batch(double (&x)[N]) {
 #ifdef MBAR_EXPERIMENT_NOEXP  // timing experiment only (profiles/r1_noexp_experiment.txt): results are garbage
 #pragma unroll
@@ -141,7 +144,7 @@ __device__ __forceinline__ void exp2s_batch(double (&x)[N]) {
     int q[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double t = fmax(x[i], EXP2_CLAMP);
+        const double t = CLAMP ? fmax(x[i], EXP2_CLAMP) : x[i];
         const double s = __builtin_rint(t);
         x[i] = t - s;
         const int si = (int)s;
@@ -1183,7 +1186,11 @@ k_lse_pair(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // Output block b, register r, lane l  ->  element (row = (l >> 4) + 4 r, col = l & 15) of block b.
 // ---------------------------------------------------------------------------------------------
 constexpr int GRAM_AGPR_BLOCKS = 31;
-template <int NBI, int NBJ, bool DIAG, bool DMA, bool WIDE>
+// Finite stand-ins for the infinities of the operand exponent when the sweep runs without the exponential's clamp
+constexpr double GRAM_NEG_HUGE = -2.9e303, LOGDEN_HUGE = 1e300;
+// PMODE: `u` is the resident probability matrix and `logden` the vector of reciprocals 1 / s_n (P mode, see k_psweep):
+// the MFMA operand is P_kn / s_n, ONE multiply per element, no exponential, no table.
+template <int NBI, int NBJ, bool DIAG, bool DMA, bool WIDE, bool CLAMP = true, bool PMODE = false>
 __global__ void __launch_bounds__(256, 1)
 k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
        const double* __restrict__ anum_i, const double* __restrict__ anum_j,
@@ -1215,8 +1222,10 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
     const int ks = lane & 15, ns = lane >> 4;
-    exp_table_init(smem);
-    __syncthreads();
+    if constexpr (!PMODE) {
+        exp_table_init(smem);
+        __syncthreads();
+    }
     char* buf = smem + EXP_TABLE_BYTES + wave * (NBUF * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
@@ -1225,12 +1234,14 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 
     double a[NBT];
 #pragma unroll
-    for (int I = 0; I < NBT; ++I) a[I] = (DIAG || I < NBI) ? anum_i[16 * I + ks] : anum_j[16 * (I - NBI) + ks];
+    for (int I = 0; I < NBT; ++I) a[I] = PMODE ? 0.0 : ((DIAG || I < NBI) ? anum_i[16 * I + ks] : anum_j[16 * (I - NBI) + ks]);
+    if constexpr (!PMODE) {
 #pragma unroll
-    for (int I = 0; I < NBT; ++I) settle(a[I]);
+        for (int I = 0; I < NBT; ++I) settle(a[I]);
+    }
     double aS[NBT];  // exponent arguments are formed directly in table units: t = (a - logden - u) S log2(e)
 #pragma unroll
-    for (int I = 0; I < NBT; ++I) aS[I] = a[I] * LOG2E_S;
+    for (int I = 0; I < NBT; ++I) aS[I] = CLAMP ? a[I] * LOG2E_S : fmax(a[I] * LOG2E_S, GRAM_NEG_HUGE);  // (-inf: unsampled / padded states)
     v4d acc[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -1289,11 +1300,18 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const bool valid = (t * TS + 4 * g + ns) < N;
-            const double lde = valid ? ldc[g] : INFINITY;  // padded samples: exp(-inf) = 0
             double p[NBT];
+            if constexpr (PMODE) {
+                const double rin = valid ? ldc[g] : 0.0;  // 1 / s_n (times sqrt(c_n) when weighted); padded samples: 0
 #pragma unroll
-            for (int I = 0; I < NBT; ++I) p[I] = fma(uv[g][I], -LOG2E_S, aS[I] - lde * LOG2E_S);
-            exp2s_batch<NBT>(p);
+                for (int I = 0; I < NBT; ++I) p[I] = uv[g][I] * rin;
+            } else {
+                // padded samples (and samples of multiplicity zero, logden = +inf): exp(-inf) = 0
+                const double lde = CLAMP ? (valid ? ldc[g] : INFINITY) : (valid ? fmin(ldc[g], LOGDEN_HUGE) : LOGDEN_HUGE);
+#pragma unroll
+                for (int I = 0; I < NBT; ++I) p[I] = fma(uv[g][I], -LOG2E_S, aS[I] - lde * LOG2E_S);
+                exp2s_batch<NBT, CLAMP>(p);
+            }
             auto mfma = [&](int b, double x, double y) {
                 if constexpr (PINNED) {
                     if (b < GRAM_AGPR_BLOCKS)
@@ -1316,7 +1334,12 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 #pragma unroll
                 for (int I = 0; I < NBI; ++I)
 #pragma unroll
-                    for (int J = I; J < NBI; ++J) mfma(b++, p[I], p[J]);
+                    for (int J = I; J < NBI; ++J) {
+#ifdef MBAR_EXPERIMENT_NODIAG  // timing experiment only (profiles/r2_gram_ceiling.txt): the diagonal blocks are never computed
+                        if (I == J) { ++b; continue; }
+#endif
+                        mfma(b++, p[I], p[J]);
+                    }
             } else {
 #pragma unroll
                 for (int I = 0; I < NBI; ++I)
@@ -1774,8 +1797,8 @@ k_logw(const double* __restrict__ u, int64_t ld, int64_t N, const double* __rest
         out[k * ld_out + n] = fk - u[k * ld + n] - logden[n];
 }
 
-// Boundary check of the matrix: bit 0 = some entry is NaN, bit 1 = some entry is -inf (+inf is legal: such a
-// sample simply has zero weight in that state).  The fast exp of the sweeps launders NaN, so a poisoned matrix
+// Boundary check of the matrix: bit 0 = some entry is NaN, bit 1 = some entry is -inf, bit 2 = some entry is +inf (legal:
+// such a sample simply has zero weight in that state).  The fast exp of the sweeps launders NaN, so a poisoned matrix
 // is flagged here once and every reduced output is then reported as NaN, like the reference would compute.
 __global__ void __launch_bounds__(256)
 k_check_u(const double* __restrict__ u, int64_t ld, int64_t N, int* __restrict__ flags) {
@@ -1785,6 +1808,7 @@ k_check_u(const double* __restrict__ u, int64_t ld, int64_t N, int* __restrict__
         const double v = u[k * ld + n];
         if (v != v) f |= 1;
         if (v == -INFINITY) f |= 2;
+        if (v == INFINITY) f |= 4;  // legal (weight zero), but the unclamped Gram sweep must not see it
     }
     if (f) atomicOr(flags, f);
 }
@@ -1864,6 +1888,182 @@ __global__ void k_mfma_peak(int iters, double* sink) {
     if (v == 12345.678) sink[threadIdx.x] = v;  // never true: keeps the loop alive
 }
 
+// ---------------------------------------------------------------------------------------------
+// Resident probability matrix ("P mode") of the device-resident adaptive loop.
+//   P_kn = exp(a0_k - u_kn - logden_n(a0))   (rows of a sample sum to 1; 0 for unsampled / padded states)
+// is built ONCE per solve at the starting point a0 = f0 + ln N.  For any other f, with c_k = exp(a_k - a0_k):
+//   s_n = sum_k P_kn c_k,   logden_n(f) = logden_n(a0) + log s_n,   p_kn(f) = P_kn c_k / s_n,
+// so the two-candidate evaluation sweep needs NO exponential (one FMA dot product and one FMA accumulation per
+// element and candidate) and the Gram sweep forms its MFMA operands with ONE multiply per element,
+//   G = diag(c) [ sum_n (P_n / s_n)(P_n / s_n)^T ] diag(c),
+// instead of the 14-instruction table exponential -- on gfx950 the fp64 matrix instructions and the fp64 VALU share
+// one pipe, so every VALU instruction removed from the Gram sweep is kernel time (profiles/r2_gram_ceiling.txt).
+// Costs one extra K x N array in HBM (288 GB are there for that) and one build sweep per solve.  Entries of P below
+// 1e-308 are flushed to zero: with |a - a0| <= 250 enforced by k_newton (hand-back, then the host rebuilds at the
+// current f) the mass lost that way is below 1e-199 of a sample's normaliser.
+// ---------------------------------------------------------------------------------------------
+// P[k][n] = exp(a0_k - u[k][n] - logden[n]) for k < Kp, n < N (coalesced along n; the library exp: runs once per solve).
+__global__ void __launch_bounds__(256)
+k_build_p(const double* __restrict__ u, int64_t ld, int64_t N, const double* __restrict__ a0,
+          const double* __restrict__ logden, double* __restrict__ P) {
+    const int64_t k = blockIdx.y;
+    const double ak = a0[k];
+    double* row = P + k * ld;
+    if (ak == -INFINITY) {  // unsampled / padded state (uniform per block row)
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) row[n] = 0.0;
+        return;
+    }
+    const double* ur = u + k * ld;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+        row[n] = exp((ak - logden[n]) - ur[n]);
+}
+// v[n] = 1 for n < N (the normaliser 1 / s_n at the build point)
+__global__ void __launch_bounds__(256) k_fill_ones(double* __restrict__ v, int64_t N) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) v[n] = 1.0;
+}
+// out[n] = rinv[slot][n] * sqrt(cw[n]): per-sample multiplicities folded into both MFMA operands of the P-mode Gram sweep
+__global__ void __launch_bounds__(256)
+k_rinv_weighted(const double* __restrict__ rinv, const double* __restrict__ cw, int64_t N, double* __restrict__ out,
+                const int* __restrict__ ctl, int64_t slot_stride) {
+    if (ctl) {
+        if (ctl[CTL_DONE] != 0) return;
+        rinv += (int64_t)ctl[CTL_SLOT] * slot_stride;
+    }
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+        out[n] = rinv[n] * sqrt(cw[n]);
+}
+
+// Two 4-sample groups of a P tile for NF candidates: s = sum_k P c_k (FMA dot + 16-lane sum), r = 1 / s, acc += P w r.
+template <int NB, int NF>
+__device__ __forceinline__ void psweep_two_groups(const char* cbuf, int rd0, int rd1, const double (&c)[NF][NB],
+                                                  double (&acc)[NF][NB], double w0, double w1, double (&r0)[NF],
+                                                  double (&r1)[NF]) {
+    double x0[NB], x1[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        x0[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
+        x1[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        double s0 = dot_sum<NB>(x0, c[f]), s1 = dot_sum<NB>(x1, c[f]);
+        row16_sum2(s0, s1);
+        // (a padded sample has an all-zero column: keep its reciprocal finite, its multiplicity w is 0)
+        r0[f] = recip_fast(fmax(s0, 1e-300));
+        r1[f] = recip_fast(fmax(s1, 1e-300));
+        const double q0 = w0 * r0[f], q1 = w1 * r1[f];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[f][I] = fma(x1[I], q1, fma(x0[I], q0, acc[f][I]));
+    }
+}
+
+// Evaluation sweep over the resident probability matrix for NF candidates given by their multipliers
+// cmul[f][k] = exp(a^f_k - a0_k) (0 for unsampled / padded states):
+//   rinv^f_n = 1 / sum_k P_kn cmul[f][k]          -> slot vectors (base + slot * stride, like the logden slots)
+//   psum_part[wave][f][k] = sum_n w_n P_kn rinv^f_n   (the caller multiplies by cmul[f][k]: that is sum_n p_nk(f))
+// Same tile pipeline as k_lse (LDS-DMA, double buffer, one tile of prefetch); no exponential, no table in LDS.
+template <int NB, int NF, bool WIDE>
+__global__ void __launch_bounds__(64 * lse_waves(NB))
+k_psweep(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cmul,
+         const double* __restrict__ cw, double* __restrict__ rinv0, double* __restrict__ rinv1,
+         double* __restrict__ psum_part, const int* __restrict__ ctl, int64_t slot_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl) {
+        if (ctl[CTL_DONE] != 0) return;
+        const int s = ctl[CTL_SLOT];
+        rinv1 = rinv0 + (int64_t)((s + 2) % 3) * slot_stride;
+        rinv0 = rinv0 + (int64_t)((s + 1) % 3) * slot_stride;
+    }
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem + wave * (2 * TILE_BYTES);
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const RowIdentity rows{0};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+
+    double c[NF][NB], acc[NF][NB];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            c[f][I] = cmul[f * ROWS + 16 * I + ks];
+            acc[f][I] = 0.0;
+        }
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) settle(c[f][I]);
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+    const int gq = ks & 3;               // this lane keeps the reciprocal of sample 4 gq + ns for the store below
+    const int fq = (NF == 2 && (ks & 4)) ? 1 : 0;
+
+    int64_t t = gw;
+    int cur = 0;
+    if (t < ntiles) {
+        stage_tile<ROWS, true, 0, 1>(P, ld, t * TS, buf, lane, so, rows);
+        stage_vec16<true>(cw, t * TS, buf + U_BYTES, lane);
+    }
+    for (; t < ntiles; t += W) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        const char* wslot = cbuf + U_BYTES;
+        const int64_t tn = t + W;
+        if (tn < ntiles) {
+            char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+            stage_tile<ROWS, true, 0, 2>(P, ld, tn * TS, nbuf, lane, so, rows);
+            stage_vec16<true>(cw, tn * TS, nbuf + U_BYTES, lane);
+            constexpr int NEVEN = (ROWS / 8 + 1) / 2 + 1;  // even pieces + the weight slot
+            // vmcnt counts stores too: [even(t)][odd(t)][rinv store of tile t - W][even(tn)], and tile t is needed now
+            if (t != gw)
+                wait_vm<NEVEN + 1>();
+            else
+                wait_vm<NEVEN>();
+        } else {
+            wait_vm<0>();
+        }
+        double w[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) w[g] = *reinterpret_cast<const double*>(wslot + (4 * g + ns) * 8);
+        double ra[NF], rb[NF], keep = 0.0;
+        psweep_two_groups<NB, NF>(cbuf, pos[0], pos[1], c, acc, w[0], w[1], ra, rb);
+        if (gq == 0) keep = ra[fq];
+        if (gq == 1) keep = rb[fq];
+        __builtin_amdgcn_sched_barrier(0);
+        if (tn < ntiles) stage_tile<ROWS, true, 1, 2>(P, ld, tn * TS, buf + (cur ^ 1) * TILE_BYTES, lane, so, rows);
+        __builtin_amdgcn_sched_barrier(0);
+        psweep_two_groups<NB, NF>(cbuf, pos[2], pos[3], c, acc, w[2], w[3], ra, rb);
+        if (gq == 2) keep = ra[fq];
+        if (gq == 3) keep = rb[fq];
+        {
+            const int64_t n = t * TS + 4 * gq + ns;
+            double* out = fq ? rinv1 : rinv0;
+            // (exactly ONE store instruction per tile and wave -- sample 0 of every tile exists, so it is never skipped --
+            // which the vmcnt bookkeeping at the loop top relies on)
+            if (n < N && ks < 4 * NF) out[n] = keep;
+        }
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(gw * NF + f) * ROWS + 16 * I + lane] = v;
+        }
+    }
+}
+
 // Same reduction as k_reduce for TWO partial-record arrays with the same number of records in one launch
 // (blocks [0, gxA) work on A, the rest on B; identical summation order).
 __global__ void __launch_bounds__(256)
@@ -1924,6 +2124,7 @@ k_newton(AdaptArgs q) {
     __shared__ double colbuf[2][NC];
     __shared__ double pv[NC], rh[NC], xs[NC + 1];
     __shared__ double s_f[128], s_ps[128], s_nk[128], s_ln[128];  // per-state vectors (Kp <= 128)
+    __shared__ double s_cc[128], s_a0[128];                       // P mode: current multipliers, build point
     __shared__ int smp[NC + 1], pos[128];                          // sampled list (m <= NC) and its inverse
     if (q.ctl[CTL_DONE] != 0) return;
     const int tid = threadIdx.x, ty = tid / T, tx = tid % T;
@@ -1935,6 +2136,8 @@ k_newton(AdaptArgs q) {
         s_ps[k] = q.psum[k];
         s_nk[k] = q.Nk[k];
         s_ln[k] = q.lnNk[k];
+        s_cc[k] = q.pmode ? q.ccur[k] : 1.0;
+        s_a0[k] = q.pmode ? q.a0[k] : 0.0;
         pos[k] = 0;
     }
     for (int i = tid; i < q.m; i += NT) smp[i] = q.sampled[i];
@@ -1953,6 +2156,12 @@ k_newton(AdaptArgs q) {
     for (int r = 0; r < 4; ++r)  // 16 independent loads (always a valid address; masked below)
 #pragma unroll
         for (int c = 0; c < 4; ++c) A[r][c] = -gram_elem(q.gram_red, nb, ki[r], kj[c]);
+    if (q.pmode) {  // the P-mode Gram sweep leaves the two per-state factors exp(a - a0) to be applied here
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) A[r][c] *= s_cc[ki[r]] * s_cc[kj[c]];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -2022,10 +2231,23 @@ k_newton(AdaptArgs q) {
             fn = fk - gamma * xs[pos[k]];                        // :584
             fs = (fk - log(s_ps[k] / s_nk[k])) - shift;          // :587-588
             a0 = fs + s_ln[k];
-            const double d = (fn + s_ln[k]) - a0;
-            rt = exp(d);
-            if (!(fabs(d) < 300.0)) flags |= 2;
+            const double a1 = fn + s_ln[k];
+            if (q.pmode) {
+                // multipliers of both candidates relative to the build point of P; too far from it (250 kT: the
+                // flushed tail of P would start to matter near e^700) hands back, the host rebuilds P at the current f
+                const double d0 = a0 - s_a0[k], d1 = a1 - s_a0[k];
+                if (!(fabs(d0) < 250.0) || !(fabs(d1) < 250.0)) flags |= 2;
+                a0 = exp(d0);
+                rt = exp(d1);
+            } else {
+                const double d = a1 - a0;
+                rt = exp(d);
+                if (!(fabs(d) < 300.0)) flags |= 2;
+            }
             if (!isfinite(fs) || !isfinite(fn)) flags |= 4;
+        } else if (q.pmode) {
+            a0 = 0.0;
+            rt = 0.0;
         }
         q.cand[k] = fs;
         q.cand[q.Kp + k] = fn;
@@ -2070,8 +2292,12 @@ k_select(AdaptArgs q) {
     const bool in = tid < Kp;
     const double nk = in ? q.Nk[tid] : 0.0;
     const bool sampled = in && tid < q.K && nk > 0.0;
-    const double ps0 = in ? q.lse_red[tid] : 0.0;
-    const double ps1 = in ? q.lse_red[Kp + tid] * q.ratio[tid] : 0.0;  // the sweep accumulates e_k / s' : times c_k = its psum
+    // the sweeps accumulate UNSCALED per-state sums: times the candidate's per-state constant = its psum
+    // (classic: ratio c_k of the second candidate only; P mode: exp(a - a0) of both, kept in aden)
+    const double m0 = (in && q.pmode) ? q.aden[tid] : 1.0;
+    const double m1 = in ? (q.pmode ? q.aden[Kp + tid] : q.ratio[tid]) : 0.0;
+    const double ps0 = in ? q.lse_red[tid] * m0 : 0.0;
+    const double ps1 = in ? q.lse_red[Kp + tid] * m1 : 0.0;
     const double fo = in ? q.f[tid] : 0.0, fs = in ? q.cand[tid] : 0.0, fn = in ? q.cand[Kp + tid] : 0.0;
     const double lnk = in ? q.lnNk[tid] : 0.0;
     const double ga = sampled ? ps0 - nk : 0.0, gb = sampled ? ps1 - nk : 0.0;
@@ -2083,6 +2309,7 @@ k_select(AdaptArgs q) {
         q.f[tid] = fnew;
         q.psum[tid] = ch == 0 ? ps0 : ps1;
         q.anum[tid] = sampled ? fnew + lnk : -INFINITY;
+        if (q.pmode) q.ccur[tid] = ch == 0 ? m0 : m1;
     }
     // convergence measures over the sampled states except the gauge state (:627-633); NaN: see the host loop
     const bool counts = sampled && tid != first;
@@ -2372,7 +2599,7 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
     }
 }
 
-template <int NBI, int NBJ, bool DIAG, bool DMA>
+template <int NBI, int NBJ, bool DIAG, bool DMA, bool CLAMP = true, bool PMODE = false>
 static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                                 const double* ai, const double* aj, const double* logden, int64_t ri,
                                 int64_t rj, double* gp, double* pp, const LoopCtl& lc = LoopCtl()) {
@@ -2391,7 +2618,8 @@ static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double
                                logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride);
         return hipGetLastError();
     };
-    return stage_offsets_wide(ld) ? launch(k_gram<NBI, NBJ, DIAG, DMA, true>) : launch(k_gram<NBI, NBJ, DIAG, DMA, false>);
+    return stage_offsets_wide(ld) ? launch(k_gram<NBI, NBJ, DIAG, DMA, true, CLAMP, PMODE>)
+                                  : launch(k_gram<NBI, NBJ, DIAG, DMA, false, CLAMP, PMODE>);
 }
 
 template <int NB, bool DMA>
@@ -2427,9 +2655,21 @@ static hipError_t launch_gram_xchg_t(hipStream_t s, const LaunchGeom& g, const d
 hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
                             int64_t N, const double* anum, const double* logden, int64_t row0, double* gp,
                             double* pp, const LoopCtl& lc) {
-    if (nb == 8 && g.variant == 2)  // one wave per SIMD owns all 36 blocks (accumulator classes pinned by hand)
+    if (lc.pmode) {  // resident probability matrix: `u` = P, `logden` = the reciprocals 1 / s_n; LDS-DMA staging only
+        if (!dma || (nb == 8 && g.variant != 2)) return hipErrorInvalidValue;
+        switch (nb) {
+#define MBAR_CASE(NB_) \
+    case NB_: return launch_gram_t<NB_, NB_, true, true, true, true>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp, lc);
+            MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7) MBAR_CASE(8)
+#undef MBAR_CASE
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (nb == 8 && g.variant == 2) {  // one wave per SIMD owns all 36 blocks (accumulator classes pinned by hand)
+        if (lc.unclamped && dma) return launch_gram_t<8, 8, true, true, false>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp, lc);
         return dma ? launch_gram_t<8, 8, true, true>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp, lc)
                    : launch_gram_t<8, 8, true, false>(s, g, u, ld, N, anum, anum, logden, row0, row0, gp, pp, lc);
+    }
     if (nb == 8) {  // paired-wave variants: g.nwaves counts tile streams (4 per workgroup)
         if (lc.ctl) return hipErrorInvalidValue;  // (only k_gram honours the control words)
         if (g.variant == 0)
@@ -2651,6 +2891,77 @@ hipError_t launch_newton(hipStream_t s, const AdaptArgs& a) {
 hipError_t launch_select(hipStream_t s, const AdaptArgs& a) {
     if (a.Kp > 256) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- P mode ------------------------------------------------------------------------------------------------------
+LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override) {
+    LaunchGeom g;
+    const size_t tile = (size_t)nb * 16 * TS * 8 + TS * 8;
+    g.variant = 1;
+    g.waves = lse_waves(nb);
+    g.lds_bytes = (size_t)g.waves * 2 * tile;  // no look-up tables: the sweep has no exponential
+    int64_t want = (ntiles + g.waves - 1) / g.waves;
+    int64_t cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+    if (grid_override > 0) cap = grid_override;
+    if (want < 1) want = 1;
+    g.blocks = (int)(want < cap ? want : cap);
+    g.nwaves = g.blocks * g.waves;
+    g.psum_records = g.nwaves;
+    return g;
+}
+
+template <int NB>
+static hipError_t launch_psweep_nb(hipStream_t s, int nf, const LaunchGeom& g, const double* P, int64_t ld, int64_t N,
+                                   const double* cmul, const double* cw, double* rinv0, double* rinv1, double* pp,
+                                   const LoopCtl& lc) {
+    auto go = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        if (lc.ev_start && lc.ev_stop)
+            hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, P, ld, N,
+                                  ntiles, cmul, cw, rinv0, rinv1, pp, lc.ctl, lc.slot_stride);
+        else
+            hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, P, ld, N, ntiles, cmul, cw, rinv0,
+                               rinv1, pp, lc.ctl, lc.slot_stride);
+        return hipGetLastError();
+    };
+    const bool wide = stage_offsets_wide(ld);
+    if (nf == 1) return wide ? go(k_psweep<NB, 1, true>) : go(k_psweep<NB, 1, false>);
+    return wide ? go(k_psweep<NB, 2, true>) : go(k_psweep<NB, 2, false>);
+}
+
+hipError_t launch_psweep(hipStream_t s, int nb, int nf, const LaunchGeom& g, const double* P, int64_t ld, int64_t N,
+                         const double* cmul, const double* cw, double* rinv0, double* rinv1, double* pp, const LoopCtl& lc) {
+    switch (nb) {
+#define MBAR_CASE(NB_) \
+    case NB_: return launch_psweep_nb<NB_>(s, nf, g, P, ld, N, cmul, cw, rinv0, rinv1, pp, lc);
+        MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7) MBAR_CASE(8)
+#undef MBAR_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_build_p(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t Kp, const double* a0,
+                          const double* logden, double* P, double* rinv_slot) {
+    int64_t bx = (N + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_build_p, dim3((unsigned)bx, (unsigned)Kp), dim3(256), 0, s, u, ld, N, a0, logden, P);
+    hipLaunchKernelGGL(k_fill_ones, dim3((unsigned)bx), dim3(256), 0, s, rinv_slot, N);  // (after the build: it read logden there)
+    return hipGetLastError();
+}
+
+hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,
+                                const LoopCtl& lc) {
+    int64_t bx = (N + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_rinv_weighted, dim3((unsigned)bx), dim3(256), 0, s, rinv, cw, N, out, lc.ctl, lc.slot_stride);
     return hipGetLastError();
 }
 

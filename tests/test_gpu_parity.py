@@ -261,6 +261,43 @@ def test_nan_and_infinite_energies(DM):
             np.testing.assert_allclose(ms.mbar_gradient(dm, N_k, f), oracle.mbar_gradient(u_kn, N_k, f), rtol=1e-9, atol=1e-9)
 
 
+def test_full_panel_gram_with_and_without_the_exponential_clamp(DM):
+    """The 128-state Gram panel runs its exponentials without the clamp when the matrix holds no +inf entry (finite
+    stand-ins replace the -inf of unsampled / padded states and of padded or zero-weight samples) and with it
+    otherwise.  Both instantiations against the oracle: ragged N, unsampled states, huge finite energies, +inf
+    entries, per-sample multiplicities including zeros; the W-mode Gram (all states) as well."""
+    K, N = 128, 3001
+    u_kn, N_k, f = random_problem(K, N, seed=77, unsampled=(5, 64, 127))
+    u_big = u_kn.copy()
+    u_big[9, ::11] = 1e300          # "forbidden" configurations written as a huge finite energy
+    u_big[17, 3::13] = 7.5e5        # beyond the int32 range of the table index (saturating convert)
+    u_inf = u_big.copy()
+    u_inf[40, ::5] = np.inf
+    Nf = N_k.astype(float)
+    for tag, u in (("finite (unclamped)", u_big), ("+inf (clamped)", u_inf)):
+        with DM.from_host(u) as dm:
+            check_l1(dm, u, N_k, f, tag=tag)
+            G, wsum = dm.gram_w(f)
+            W = oracle.mbar_W_nk(u, Nf, f)
+            np.testing.assert_allclose(G, W.T @ W, rtol=1e-10, atol=1e-15, err_msg=tag + " gram_w")
+            # multiplicities (with zeros) == the explicitly resampled matrix
+            rng = np.random.default_rng(3)
+            c_n = rng.integers(0, 4, size=N).astype(float)
+            dm.set_sample_weights(c_n)
+            try:
+                ps, _, Gc = dm.eval(f, gram=True)
+            finally:
+                dm.set_sample_weights(None)
+            ue = np.repeat(u, c_n.astype(int), axis=1)
+            part = oracle.shard_partials(ue, N_k, f, want_gram=True)
+            np.testing.assert_allclose(ps[0], part["psum"], rtol=1e-11, atol=1e-9, err_msg=tag + " weighted psum")
+            np.testing.assert_allclose(Gc, part["gram"], rtol=1e-10, atol=1e-10, err_msg=tag + " weighted gram")
+            fa, ra = dm.solve_adaptive(np.zeros(K), tol=1e-12, maxiter=100, min_sc_iter=0)
+            assert ra["success"]
+            g = oracle.mbar_gradient(u, Nf, fa)
+            assert np.linalg.norm(g) < 1e-6 * N
+
+
 def test_objective_offset_matches_preconditioned_objective(DM):
     u_kn, N_k, f = random_problem(12, 1500, seed=21)
     with DM.from_host(u_kn) as dm:

@@ -15,11 +15,12 @@ from pymbar_amd.device import DeviceMatrix  # noqa: E402
 
 def run(dm, K, label, steps):
     f0 = np.zeros(K)
-    for mode, opts in (("device graph", dict(device_loop=1, graph=1, timing=1)),
-                       ("device eager", dict(device_loop=1, graph=0, timing=1)),
-                       ("device eager ev2", dict(device_loop=1, graph=0, timing=2)),
-                       ("device eager notime", dict(device_loop=1, graph=0, timing=0)),
-                       ("host loop", dict(device_loop=0, graph=1, timing=1))):
+    for mode, opts in (("device graph classic", dict(device_loop=1, graph=1, timing=1, pmode=0)),
+                       ("device graph", dict(device_loop=1, graph=1, timing=1, pmode=1)),
+                       ("device eager", dict(device_loop=1, graph=0, timing=1, pmode=1)),
+                       ("device eager classic", dict(device_loop=1, graph=0, timing=1, pmode=0)),
+                       ("device eager notime", dict(device_loop=1, graph=0, timing=0, pmode=1)),
+                       ("host loop", dict(device_loop=0, graph=1, timing=1, pmode=1))):
         for k, v in opts.items():
             dm.set_option(k, v)
         dm.solve_adaptive(f0, maxiter=steps, min_sc_iter=0, check_convergence=False)  # warm-up (captures the graph)
