@@ -929,11 +929,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const int64_t ntiles = (c->N + TS - 1) / TS;
     const bool dma = c->opt_staging == 0;
     handed_back = false;
-    // initial gradient (mbar_solvers.py:570); leaves logden(f) in slot 0
     psum.assign(K, 0.0);
-    int rc = eval_core(c, f.data(), 1, 0, c->logden[0], nullptr, psum.data(), nullptr, nullptr);
-    if (rc) return rc;
-    rc = ensure_ad(c, history ? history_rows : 0);
+    int rc = ensure_ad(c, history ? history_rows : 0);
     if (rc) return rc;
     // P mode: the sweeps run on the resident probability matrix (one more K x N array); if it does not fit, or with
     // register staging, the classic sweeps on u are used
@@ -951,6 +948,33 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         }
     }
     if (pmode && !c->pm_vec) HIPCHK(c, hipMalloc((void**)&c->pm_vec, (size_t)2 * Kp * sizeof(double)));
+    // initial gradient (mbar_solvers.py:570).  Classic: the evaluation sweep, logden(f) stays in slot 0.  P mode: the
+    // same sweep also writes P = exp(a0 - u - logden(a0)) with a0 = aden(f) and leaves 1 / s = 1 in slot 0.
+    if (!pmode) {
+        rc = eval_core(c, f.data(), 1, 0, c->logden[0], nullptr, psum.data(), nullptr, nullptr);
+        if (rc) return rc;
+    } else {
+        const LaunchGeom gb = build_sweep_geometry(nb, c->num_cu, ntiles, c->opt_grid);
+        rc = ensure(c, &c->part, &c->part_doubles, (size_t)gb.nwaves * Kp);
+        if (rc) return rc;
+        rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)gb.nwaves / 32 + 1) * Kp);
+        if (rc) return rc;
+        rc = ensure_red(c, (size_t)2 * Kp + 2);
+        if (rc) return rc;
+        build_aden(c, f.data(), c->hstage, Kp);
+        HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, (size_t)Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        {
+            ScopedTimer t(c, MBAR_TIMER_OTHER);
+            HIPCHK(c, launch_build_sweep(c->stream, nb, gb, c->u, c->ld, c->N, d_aden(c), c->cw, c->P, c->logden[0], c->part));
+        }
+        HIPCHK(c, launch_reduce(c->stream, c->part, gb.nwaves, Kp, c->scratch, c->red));
+        rc = allreduce_dev(c, c->red, Kp, 0);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->hred, c->red, (size_t)Kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        rc = sync_stream(c);
+        if (rc) return rc;
+        for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k];
+    }
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     const LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
     const LaunchGeom gl = pmode ? psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid)
@@ -989,14 +1013,12 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         HIPCHK(c, hipMemcpyAsync(c->ad, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->ad_ints, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if (pmode) {  // build point a0 = aden(f), multipliers of the current f = 1, P from u with the logden of slot 0
+        if (pmode) {  // anchor point a0 = aden(f), multipliers of the current f = 1 (P itself was written by the build sweep)
             std::vector<double> pv((size_t)2 * Kp, 1.0);
             std::copy(an.begin(), an.end(), pv.begin());
             for (int64_t k = 0; k < Kp; ++k)
                 if (!(k < K && c->Nk[k] > 0.0)) pv[(size_t)Kp + k] = 0.0;
             HIPCHK(c, hipMemcpyAsync(c->pm_vec, pv.data(), pv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            ScopedTimer t(c, MBAR_TIMER_OTHER);
-            HIPCHK(c, launch_build_p(c->stream, c->u, c->ld, c->N, Kp, c->pm_vec, c->logden[0], c->P, c->logden[0]));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }

@@ -165,6 +165,11 @@ hipError_t launch_psweep(hipStream_t s, int nb, int nf, const LaunchGeom& g, con
 // P from u at a0 with the known logden(a0) (read from rinv_slot's storage BEFORE it is overwritten with ones)
 hipError_t launch_build_p(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t Kp, const double* a0,
                           const double* logden, double* P, double* rinv_slot);
+// fused build: the single-candidate sweep at the anchor point (psum partial records [nwaves][16 nb]) that also writes P and
+// fills the reciprocal slot with ones
+LaunchGeom build_sweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
+hipError_t launch_build_sweep(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                              const double* aden, const double* cw, double* P, double* rinv_slot, double* psum_part);
 hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,
                                 const LoopCtl& lc = LoopCtl());
 // K x K Newton system (gauge-fixed, Gauss-Jordan in registers, one workgroup) + both candidates + sweep inputs

@@ -1933,6 +1933,133 @@ k_rinv_weighted(const double* __restrict__ rinv, const double* __restrict__ cw, 
         out[n] = rinv[n] * sqrt(cw[n]);
 }
 
+// Build sweep of P mode: the single-candidate evaluation sweep at the anchor point a0 (log-sum-exp over states, per-state
+// sums: the solver's initial gradient) that ALSO writes the normalised probabilities P_kn = e_kn / s_n.  They go back into
+// the LDS tile in place of the energies they came from and leave with coalesced 16-byte stores that mirror the DMA
+// pattern (8 lanes per 128-byte row), so the pass moves 8 K N bytes in and 8 K N out instead of the separate
+// sweep + build (8 + 16).  The reciprocal slot of the anchor point is all ones.
+template <int NB>
+__device__ __forceinline__ void build_two_groups(char* cbuf, int rd0, int rd1, const double (&a)[NB], double (&acc)[NB],
+                                                 double w0, double w1) {
+    double x0[NB], x1[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        x0[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd0);
+        x1[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        x0[I] = a[I] - x0[I];
+        x1[I] = a[I] - x1[I];
+    }
+    double m0 = tree_max<NB>(x0), m1 = tree_max<NB>(x1);
+    row16_max2(m0, m1);
+    const double m2_0 = m0 * LOG2E_S, m2_1 = m1 * LOG2E_S;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        x0[I] = fma(x0[I], LOG2E_S, -m2_0);
+        x1[I] = fma(x1[I], LOG2E_S, -m2_1);
+    }
+    exp2s_batch2<NB>(x0, x1);
+    double s0 = tree_sum<NB>(x0), s1 = tree_sum<NB>(x1);
+    row16_sum2(s0, s1);
+    const double ri0 = recip_fast(s0), ri1 = recip_fast(s1);
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        x0[I] *= ri0;
+        x1[I] *= ri1;
+        acc[I] = fma(x1[I], w1, fma(x0[I], w0, acc[I]));
+        *reinterpret_cast<double*>(cbuf + I * (16 * TS * 8) + rd0) = x0[I];
+        *reinterpret_cast<double*>(cbuf + I * (16 * TS * 8) + rd1) = x1[I];
+    }
+}
+template <int NB, bool WIDE>
+__global__ void __launch_bounds__(64 * lse_waves(NB))
+k_build_sweep(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ aden,
+              const double* __restrict__ cw, double* __restrict__ P, double* __restrict__ rinv_slot,
+              double* __restrict__ psum_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16;
+    constexpr int NDMA = ROWS / 8;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    exp_table_init(smem);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const RowIdentity rows{0};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+
+    double a[NB], acc[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        a[I] = aden[16 * I + ks];
+        acc[I] = 0.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) settle(a[I]);
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    int64_t t = gw;
+    int cur = 0;
+    if (t < ntiles) {
+        stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
+        stage_vec16<true>(cw, t * TS, buf + U_BYTES, lane);
+    }
+    for (; t < ntiles; t += W) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        const char* wslot = cbuf + U_BYTES;
+        const int64_t tn = t + W;
+        if (tn < ntiles) {
+            char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+            stage_tile<ROWS, true, 0, 1>(u, ld, tn * TS, nbuf, lane, so, rows);
+            stage_vec16<true>(cw, tn * TS, nbuf + U_BYTES, lane);
+            // vmcnt counts stores too, in issue order: [tile t: NDMA + 1][stores of tile t - W: NDMA + 1][tile tn: NDMA + 1]
+            if (t != gw)
+                wait_vm<2 * (NDMA + 1)>();
+            else
+                wait_vm<NDMA + 1>();
+        } else {
+            wait_vm<0>();
+        }
+        double w[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) w[g] = *reinterpret_cast<const double*>(wslot + (4 * g + ns) * 8);
+        build_two_groups<NB>(cbuf, pos[0], pos[1], a, acc, w[0], w[1]);
+        build_two_groups<NB>(cbuf, pos[2], pos[3], a, acc, w[2], w[3]);
+        // the tile now holds P: out with it, 16 bytes per lane, 8 lanes per row (the LDS-DMA pattern backwards)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            const double2 v = *reinterpret_cast<const double2*>(cbuf + j * 1024 + lane * 16);
+            char* dst = reinterpret_cast<char*>(P + (int64_t)(8 * j) * ld + t * TS) + so.off[j & 1];
+            *reinterpret_cast<double2*>(dst) = v;
+        }
+        {   // 1 / s_n = 1 at the anchor point (one store instruction per tile, like the sweeps' logden / reciprocal store)
+            const int64_t n = t * TS + lane;
+            if (lane < TS && n < N) rinv_slot[n] = 1.0;
+        }
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        double v = acc[I];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) psum_part[gw * ROWS + 16 * I + lane] = v;
+    }
+}
+
 // Two 4-sample groups of a P tile for NF candidates: s = sum_k P c_k (FMA dot + 16-lane sum), r = 1 / s, acc += P w r.
 template <int NB, int NF>
 __device__ __forceinline__ void psweep_two_groups(const char* cbuf, int rd0, int rd1, const double (&c)[NF][NB],
@@ -2963,6 +3090,36 @@ hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double*
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(k_rinv_weighted, dim3((unsigned)bx), dim3(256), 0, s, rinv, cw, N, out, lc.ctl, lc.slot_stride);
     return hipGetLastError();
+}
+
+// Fused build: single-candidate sweep at the anchor point + P + unit reciprocals.  Geometry of the classic sweep.
+template <int NB>
+static hipError_t launch_build_sweep_nb(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                        const double* aden, const double* cw, double* P, double* rinv_slot, double* pp) {
+    auto go = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, P, rinv_slot, pp);
+        return hipGetLastError();
+    };
+    return stage_offsets_wide(ld) ? go(k_build_sweep<NB, true>) : go(k_build_sweep<NB, false>);
+}
+LaunchGeom build_sweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override) {
+    return lse_geometry(nb, 1, num_cu, ntiles, grid_override, 1);  // default double-buffered sweep, tables in LDS
+}
+hipError_t launch_build_sweep(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                              const double* aden, const double* cw, double* P, double* rinv_slot, double* pp) {
+    switch (nb) {
+#define MBAR_CASE(NB_) \
+    case NB_: return launch_build_sweep_nb<NB_>(s, g, u, ld, N, aden, cw, P, rinv_slot, pp);
+        MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7) MBAR_CASE(8)
+#undef MBAR_CASE
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace mbar
