@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--pmode", type=int, default=1,
                     help="1 = the device-resident loop sweeps the resident probability matrix P = exp(a0 - u - logden(a0)) "
                          "(no exponentials after the build); 0 = every sweep recomputes its exponentials from u (A/B)")
+    ap.add_argument("--fused", type=int, default=1,
+                    help="1 = ONE sweep per iteration in P mode: the candidate sweep also accumulates the Gram matrix of the "
+                         "Newton-Raphson candidate (the separate Gram sweep runs only when that candidate is rejected); 0 = two sweeps (A/B)")
     ap.add_argument("--allow-host-allreduce", action="store_true", help="debugging only: do not fail when RCCL is unavailable")
     args = ap.parse_args()
 
@@ -192,6 +195,7 @@ def main():
     dm.set_option("gram_variant", args.gram_variant)
     dm.set_option("device_loop", args.device_loop)
     dm.set_option("pmode", args.pmode)
+    dm.set_option("fused", args.fused)
     dm.set_option("graph", 0)  # eager launches: per-kernel HIP-event timers inside the timed region (the GPU queue never
     #                            runs dry at this size: an iteration is ~5 ms of kernels against ~0.1 ms of enqueueing)
     dm.set_Nk(N_k)
@@ -253,19 +257,75 @@ def main():
 
     if rank == 0:
         it_per_s = args.steps / elapsed
+        ms_step = 1e3 * elapsed / args.steps
         gram_ms, gram_n = timing["gram"]
         lse_ms, lse_n = timing["lse"]
-        gram_avg = gram_ms / max(1, gram_n)
-        lse_avg = lse_ms / max(1, lse_n)
+        fus_ms, fus_n = timing.get("fused", (0.0, 0))
+        pm = bool(args.pmode and args.device_loop and args.staging == 0)
+        fused = bool(pm and args.fused and fus_n > 0)
         flops = float(n_loc) * K * (K + 1)           # symmetric Gram: K(K+1)/2 entries x 2 flop x N (this rank's shard)
         bytes_pass = 8.0 * K * n_loc                 # one read of the shard per sweep
-        # the adaptive loop issues 1 single-f sweep (initial gradient) + `steps` two-candidate sweeps
-        achieved_tf = flops / (gram_avg * 1e-3) * 1e-12 if gram_avg > 0 else 0.0
-        achieved_gbs = bytes_pass / (lse_avg * 1e-3) * 1e-9 if lse_avg > 0 else 0.0
-        ms_step = 1e3 * elapsed / args.steps
-        pm = bool(args.pmode and args.device_loop and args.staging == 0)
-        tr_g, src_g = pmc_traffic("k_gram<", K, n_loc)
-        tr_l, src_l = pmc_traffic("k_psweep<8, 2" if pm else "k_lse<8, 2", K, n_loc)
+        sweep_flops = 8.0 * K * n_loc                # candidate sweep in P mode: 2 candidates x (dot + accumulation) x 2 flop
+        if fused:
+            # ONE kernel per iteration: candidates' normalisers / per-state sums + the Gram matrix of the Newton-Raphson
+            # candidate.  The separate Gram sweep runs only for rejected speculations (and once at the start); its launches
+            # are no-ops otherwise, so its timer average is not a sweep time -- the count of real sweeps comes from the solver.
+            dom_avg = fus_ms / fus_n
+            dom_flops = flops + sweep_flops
+            tr_g, src_g = pmc_traffic("k_fused<8", K, n_loc)
+            roof = {
+                "kernel": "k_fused<8> (one pass over the resident probability matrix: 2 candidates' normalisers and per-state "
+                          "sums + fp64 MFMA Gram matrix of the Newton-Raphson candidate)",
+                "bound": "mfma", "achieved": dom_flops / (dom_avg * 1e-3) * 1e-12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "traffic": tr_g, "traffic_source": f"committed PMC pass {src_g} (not collected in this run)" if src_g else None,
+                "avg_launch_ms": dom_avg, "launches": fus_n, "algorithmic_flop_per_launch": dom_flops,
+                "of_which_matrix_flop": flops, "of_which_vector_flop": sweep_flops,
+                "matrix_only_tflops": flops / (dom_avg * 1e-3) * 1e-12,
+            }
+            roof["frac"] = roof["achieved"] / FP64_MFMA_PEAK_TFLOPS
+            hbm_gbs = bytes_pass / (dom_avg * 1e-3) * 1e-9
+            roof2 = {
+                "kernel": "k_fused<8> seen from HBM (it is not bound by it)",
+                "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                "traffic": tr_g, "avg_launch_ms": dom_avg, "launches": fus_n, "algorithmic_bytes_per_launch": bytes_pass,
+            }
+            outside = ms_step - dom_avg - gram_ms / args.steps
+            extra = {"separate_gram_sweeps_in_timed_region": int(res.get("gram_sweeps", -1)),
+                     "separate_gram_sweep_ms_total": gram_ms, "separate_gram_launches_incl_noops": gram_n}
+        else:
+            gram_avg = gram_ms / max(1, gram_n)
+            lse_avg = lse_ms / max(1, lse_n)
+            achieved_tf = flops / (gram_avg * 1e-3) * 1e-12 if gram_avg > 0 else 0.0
+            achieved_gbs = bytes_pass / (lse_avg * 1e-3) * 1e-9 if lse_avg > 0 else 0.0
+            tr_g, src_g = pmc_traffic("k_gram<", K, n_loc)
+            tr_l, src_l = pmc_traffic("k_psweep<8, 2" if pm else "k_lse<8, 2", K, n_loc)
+            roof = {
+                "kernel": ({0: "k_gram_xchg<8>", 1: "k_gram_pair<8>"}.get(args.gram_variant, "k_gram<8,8> one wave per SIMD" + (", operands P / s" if pm else ", operands by table exp")) + " (fp64 MFMA W^T W)") if K == 128 else "k_gram",
+                "bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": tr_g,
+                "traffic_source": f"committed PMC pass {src_g} (not collected in this run)" if src_g else None,
+                "avg_launch_ms": gram_avg, "launches": gram_n, "algorithmic_flop_per_launch": flops,
+            }
+            roof2 = {
+                "kernel": ("k_psweep<8,2> (normalisers + per-state sums of 2 candidates from the resident probability matrix, no exp)"
+                           if pm else "k_lse<8,2> (log-sum-exp + per-state sums, 2 candidates per sweep, one exp per element)"),
+                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": tr_l,
+                "traffic_source": f"committed PMC pass {src_l} (not collected in this run)" if src_l else None,
+                "avg_launch_ms": lse_avg, "launches": lse_n, "algorithmic_bytes_per_launch": bytes_pass,
+            }
+            outside = ms_step - gram_avg - lse_avg
+            extra = {}
+        roof["measured_mfma_f64_peak_tflops"] = mfma_peak
+        if fused:
+            sweeps = "ONE fused sweep per iteration over the resident probability matrix (built once per solver call, inside the timed region)"
+            what = "fused sweep (2-candidate gradients + MFMA Gram of the Newton-Raphson candidate) + K x K Newton solve"
+        elif pm:
+            sweeps = "resident probability matrix (built once per solver call, inside the timed region), two sweeps per iteration"
+            what = "MFMA Gram sweep + K x K Newton solve + 2-candidate gradient sweep"
+        else:
+            sweeps = "exponentials recomputed from u in every sweep, two sweeps per iteration"
+            what = "MFMA Gram sweep + K x K Newton solve + 2-candidate gradient sweep"
         out = {
             "metric": "mbar_adaptive_iterations_per_sec",
             "value": it_per_s,
@@ -281,38 +341,25 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{config_name}: harmonic ladder K={K}, N_total={N_total} ({n_loc} per GPU), adaptive NR/SCI "
-                            f"iteration = MFMA Gram sweep + K x K Newton solve + 2-candidate gradient sweep, device-resident, "
-                            f"fp64, generated in HBM",
+                            f"iteration = {what}, device-resident, fp64, generated in HBM",
                 "K": K, "N_per_gpu": n_loc, "N_total": N_total, "parallelism": f"N-sharded x{world}",
                 "allreduce": allreduce, "device": info["name"], "adaptive_loop": "device-resident" if args.device_loop else "host-driven",
-                "sweeps": "resident probability matrix (built once per solver call, inside the timed region)" if pm else "exponentials recomputed from u in every sweep",
+                "sweeps": sweeps,
             },
-            "roofline": {
-                "kernel": ({0: "k_gram_xchg<8>", 1: "k_gram_pair<8>"}.get(args.gram_variant, "k_gram<8,8> one wave per SIMD" + (", operands P / s" if pm else ", operands by table exp")) + " (fp64 MFMA W^T W)") if K == 128 else "k_gram",
-                "bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": tr_g,
-                "traffic_source": f"committed PMC pass {src_g} (not collected in this run)" if src_g else None,
-                "avg_launch_ms": gram_avg, "launches": gram_n, "algorithmic_flop_per_launch": flops,
-                "measured_mfma_f64_peak_tflops": mfma_peak,
-            },
-            "roofline_lse": {
-                "kernel": ("k_psweep<8,2> (normalisers + per-state sums of 2 candidates from the resident probability matrix, no exp)"
-                           if pm else "k_lse<8,2> (log-sum-exp + per-state sums, 2 candidates per sweep, one exp per element)"),
-                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": tr_l,
-                "traffic_source": f"committed PMC pass {src_l} (not collected in this run)" if src_l else None,
-                "avg_launch_ms": lse_avg, "launches": lse_n, "algorithmic_bytes_per_launch": bytes_pass,
-            },
-            "ms_per_step_outside_the_two_sweeps": ms_step - gram_avg - lse_avg,
+            "roofline": roof,
+            "roofline_lse": roof2,
+            "ms_per_step_outside_the_sweeps": outside,
             "cpu_baseline": cpu,
             "wallclock_to_converge_s": t_conv,
             "iterations_to_converge": int(conv["iterations"]),
             "converged": bool(conv["success"]),
             "nr_iterations": int(conv["nr_iter"]), "sci_iterations": int(conv["sci_iter"]),
+            "separate_gram_sweeps_to_converge": int(conv.get("gram_sweeps", -1)),
             "max_abs_error_vs_analytic_f": err_analytic,
             "gnorm_at_solution": float(conv["gnorm"]),
             "api_end_to_end": e2e,
         }
+        out.update(extra)
         if cpu is not None:
             out["speedup_vs_cpu_baseline"] = it_per_s / cpu["value"]
         print(json.dumps(out))

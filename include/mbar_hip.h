@@ -48,8 +48,9 @@ typedef struct mbar_ctx mbar_ctx;
 #define MBAR_TIMER_LSE 0    /* per-sample log-sum-exp + per-state sums (evaluation pass)   */
 #define MBAR_TIMER_GRAM 1   /* fp64 MFMA Gram / Hessian pass                              */
 #define MBAR_TIMER_REDUCE 2 /* partial-sum reductions                                      */
-#define MBAR_TIMER_OTHER 3  /* logW writer, robust per-state LSE, generator                */
-#define MBAR_TIMER_COUNT 4
+#define MBAR_TIMER_OTHER 3  /* logW writer, robust per-state LSE, generator, P-mode build  */
+#define MBAR_TIMER_FUSED 4  /* fused sweep of the adaptive loop (candidates + MFMA Gram)   */
+#define MBAR_TIMER_COUNT 5
 
 /* ---- library / device -------------------------------------------------------------------- */
 int mbar_version(void);
@@ -79,6 +80,8 @@ int mbar_device_synchronize(int device);
  *   "wide_k_kernel"  1 = single-buffer sweep with four waves per CU for 129 <= K <= 256 (default), 0 = off
  *   "device_loop"    1 = adaptive iterations run device-resident where possible (default), 0 = host-driven loop
  *   "adapt_batch"    adaptive iterations enqueued between two looks at the control words (default 8)
+ *   "fused"          1 = in P mode ONE sweep per iteration: the candidate sweep also accumulates the Gram matrix of the
+ *                    Newton-Raphson candidate, the separate Gram sweep runs only when that candidate is rejected (default)
  *   "pmode"          1 = the device-resident loop keeps P = exp(a0 - u - logden(a0)) resident (one more K x N array, built
  *                    once per solve) and sweeps that: no exponentials in the loop (default); 0 = sweeps recompute them from u
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
@@ -164,7 +167,7 @@ typedef struct mbar_solve_result {
     int64_t nr_iter;    /* ... of which Newton-Raphson steps were accepted       */
     int64_t sci_iter;   /* ... of which self-consistent steps were accepted      */
     int32_t success;    /* convergence test of mbar_solvers.py:636 met           */
-    int32_t reserved;
+    int32_t gram_sweeps; /* separate Gram sweeps executed (fused loop: 1 + rejected speculations)     */
     double max_delta;   /* last relative change                                  */
     double gnorm;       /* |g| at the returned f                                 */
     double wall_ms;     /* host wall time of the loop                            */

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MBAR_HIP_LIBRARY") or os.path.join(HERE, "csrc", "lib
 MBAR_OK = 0
 EVAL_GRAM = 1
 EVAL_USE_OFFSET = 2
-TIMER_LSE, TIMER_GRAM, TIMER_REDUCE, TIMER_OTHER = 0, 1, 2, 3
+TIMER_LSE, TIMER_GRAM, TIMER_REDUCE, TIMER_OTHER, TIMER_FUSED = 0, 1, 2, 3, 4
 
 
 class BackendUnavailable(RuntimeError):
@@ -34,7 +34,7 @@ class SolveResult(C.Structure):
         ("nr_iter", C.c_int64),
         ("sci_iter", C.c_int64),
         ("success", C.c_int32),
-        ("reserved", C.c_int32),
+        ("gram_sweeps", C.c_int32),
         ("max_delta", C.c_double),
         ("gnorm", C.c_double),
         ("wall_ms", C.c_double),

@@ -111,11 +111,14 @@ struct mbar_ctx {
     // P mode of that loop: resident probability matrix exp(a0 - u - logden(a0)), Kp x ld doubles, built once per solve
     double* P = nullptr;
     bool P_failed = false;          // the allocation did not fit: stay in the classic mode for the life of the context
-    double* pm_vec = nullptr;       // a0[Kp] | ccur[Kp]
+    double* pm_vec = nullptr;       // a0[Kp] | ccur[Kp] | cgram[Kp]
+    double* part_g = nullptr;       // Gram partial records of the fused-sweep loop (the psum records use `part`)
+    size_t part_g_doubles = 0;
+    double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_allreduce_fn host_reduce = nullptr;
@@ -124,8 +127,8 @@ struct mbar_ctx {
     // timing
     std::vector<TimerPair> pending;
     std::vector<hipEvent_t> pool;
-    double t_ms[MBAR_TIMER_COUNT] = {0, 0, 0, 0};
-    int64_t t_n[MBAR_TIMER_COUNT] = {0, 0, 0, 0};
+    double t_ms[MBAR_TIMER_COUNT] = {0, 0, 0, 0, 0};
+    int64_t t_n[MBAR_TIMER_COUNT] = {0, 0, 0, 0, 0};
     std::string error;
 };
 
@@ -860,6 +863,7 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
         }
         if (nan_seen) max_delta = std::numeric_limits<double>::quiet_NaN();
         res.iterations = it + 1;
+        res.gram_sweeps += 1;
         if (history && it < history_rows) {
             history[4 * it + 0] = choice;
             history[4 * it + 1] = std::sqrt(gn_sci);
@@ -947,7 +951,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             HIPCHK(c, hipMemsetAsync(c->P, 0, (size_t)Kp * c->ld * sizeof(double), c->stream));
         }
     }
-    if (pmode && !c->pm_vec) HIPCHK(c, hipMalloc((void**)&c->pm_vec, (size_t)2 * Kp * sizeof(double)));
+    if (pmode && !c->pm_vec) HIPCHK(c, hipMalloc((void**)&c->pm_vec, (size_t)3 * Kp * sizeof(double)));
+    const bool fused = pmode && c->opt_fused;
     // initial gradient (mbar_solvers.py:570).  Classic: the evaluation sweep, logden(f) stays in slot 0.  P mode: the
     // same sweep also writes P = exp(a0 - u - logden(a0)) with a0 = aden(f) and leaves 1 / s = 1 in slot 0.
     if (!pmode) {
@@ -976,9 +981,14 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k];
     }
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
-    const LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
-    const LaunchGeom gl = pmode ? psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid)
-                                : lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+    LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
+    const LaunchGeom gl = fused ? fused_geometry(nb, c->num_cu, ntiles, c->opt_grid)
+                          : pmode ? psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid)
+                                  : lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+    if (fused) {  // the separate Gram sweep (when it runs) leaves its partial records where the fused sweep leaves them
+        gg.blocks = gl.blocks;
+        gg.nwaves = gl.nwaves;
+    }
     const size_t rec_g = (size_t)nb * (nb + 1) / 2 * 256;
     const size_t rec_l = (size_t)2 * Kp;
     const size_t off_gram = rec_l + 2;
@@ -990,6 +1000,11 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
                 std::max(((size_t)gg.nwaves / 32 + 1) * rec_g, ((size_t)gl.nwaves / 32 + 1) * (rec_l + 2)));
     if (rc) return rc;
     if (c->weighted && !c->lden_eff) return fail(c, MBAR_ERR_STATE, "weighted context without its logden buffer");
+    if (fused) {
+        rc = ensure(c, &c->part_g, &c->part_g_doubles, (size_t)gl.nwaves * rec_g);
+        if (rc) return rc;
+    }
+    double* gram_part = fused ? c->part_g : c->part;
 
     // ---- solver state to the device ----
     {
@@ -1004,6 +1019,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         h[ad_off_prm(c) + 3] = check_convergence ? 1.0 : 0.0;
         h[ad_off_state(c)] = std::numeric_limits<double>::quiet_NaN();
         std::vector<int> hi((size_t)CTL_WORDS + Kp, 0);
+        hi[CTL_NEEDGRAM] = 1;  // (nothing has been speculated yet: the first iteration runs the Gram sweep)
+        hi[CTL_GRAMSWEEPS] = 1;
         hi[CTL_ITER] = (int)res.iterations;
         hi[CTL_SCI] = (int)res.sci_iter;
         hi[CTL_NR] = (int)res.nr_iter;
@@ -1014,10 +1031,10 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         HIPCHK(c, hipMemcpyAsync(c->ad_ints, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         if (pmode) {  // anchor point a0 = aden(f), multipliers of the current f = 1 (P itself was written by the build sweep)
-            std::vector<double> pv((size_t)2 * Kp, 1.0);
+            std::vector<double> pv((size_t)3 * Kp, 1.0);
             std::copy(an.begin(), an.end(), pv.begin());
             for (int64_t k = 0; k < Kp; ++k)
-                if (!(k < K && c->Nk[k] > 0.0)) pv[(size_t)Kp + k] = 0.0;
+                if (!(k < K && c->Nk[k] > 0.0)) pv[(size_t)Kp + k] = pv[(size_t)2 * Kp + k] = 0.0;
             HIPCHK(c, hipMemcpyAsync(c->pm_vec, pv.data(), pv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1045,6 +1062,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     q.pmode = pmode ? 1 : 0;
     q.a0 = c->pm_vec;
     q.ccur = pmode ? c->pm_vec + Kp : nullptr;
+    q.fused = fused ? 1 : 0;
+    q.cgram = fused ? c->pm_vec + 2 * Kp : nullptr;
     LoopCtl lc_slot, lc_flat;
     lc_slot.ctl = lc_flat.ctl = c->ad_ints;
     lc_slot.slot_stride = c->ld;
@@ -1069,13 +1088,14 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             if (timed) { tp.a = get_event(c); tp.b = get_event(c); }
             const bool ext = tp.a && tp.b && c->opt_timing == 2;
             if (ext) { lca.ev_start = tp.a; lca.ev_stop = tp.b; }
+            lca.cond_needgram = fused;  // fused-sweep loop: this sweep runs only when the speculated Gram matrix is not the one needed
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
-            HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, c->part,
+            HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, gram_part,
                                        nullptr, lca));
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
             if (tp.a && tp.b) c->pending.push_back(tp);
         }
-        HIPCHK(c, launch_reduce(c->stream, c->part, gg.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
+        HIPCHK(c, launch_reduce(c->stream, gram_part, gg.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
         if (c->comm) {
             int r2 = allreduce_dev(c, c->red + off_gram, (int64_t)rec_g, 0);
             if (r2) return r2;
@@ -1085,13 +1105,16 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         double* psum_part = c->part;
         double* obj_part = c->part + (size_t)gl.nwaves * rec_l;
         {
-            TimerPair tp{nullptr, nullptr, MBAR_TIMER_LSE};
+            TimerPair tp{nullptr, nullptr, fused ? MBAR_TIMER_FUSED : MBAR_TIMER_LSE};
             if (timed) { tp.a = get_event(c); tp.b = get_event(c); }
             const bool ext = tp.a && tp.b && c->opt_timing == 2;
             LoopCtl lcb = lc_slot;
             if (ext) { lcb.ev_start = tp.a; lcb.ev_stop = tp.b; }
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
-            if (pmode)
+            if (fused)
+                HIPCHK(c, launch_fused(c->stream, nb, gl, c->P, c->ld, c->N, d_aden(c), c->cw, c->weighted ? c->cwsq : c->cw,
+                                       c->logden[0], gram_part, psum_part, lcb));
+            else if (pmode)
                 HIPCHK(c, launch_psweep(c->stream, nb, 2, gl, c->P, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, psum_part,
                                         lcb));
             else
@@ -1115,7 +1138,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const int64_t batch = c->opt_adapt_batch;
     const bool use_graph = c->opt_graph && !c->comm && (maxiter - res.iterations) >= batch;
     if (use_graph) {
-        const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 8) ^ (pmode ? 128 : 0) ^
+        const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 12) ^ (pmode ? 128 : 0) ^ (fused ? 256 : 0) ^
                             (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (int64_t)nb;
         if (!c->ad_graph || c->ad_graph_batch != batch || c->ad_graph_sig != sig) {
             if (c->ad_graph) HIPCHK(c, hipGraphExecDestroy(c->ad_graph));
@@ -1144,6 +1167,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         }
     }
     int64_t it = res.iterations;
+    const int64_t it_start = it;
     bool done = false;
     while (it < maxiter && !done) {
         const int64_t nbat = std::min(batch, maxiter - it);
@@ -1187,6 +1211,9 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     res.iterations = it;
     res.sci_iter = c->h_ctl[CTL_SCI];
     res.nr_iter = c->h_ctl[CTL_NR];
+    // (a sweep requested by the very last iteration was never run)
+    res.gram_sweeps += fused ? c->h_ctl[CTL_GRAMSWEEPS] - (c->h_ctl[CTL_NEEDGRAM] && c->h_ctl[CTL_DONE] != 2 ? 1 : 0)
+                             : (int32_t)(it - it_start);
     if (handed_back) {
         static const char* why[] = {"", "the Newton system is not positive definite", "a candidate is too far from the point the sweeps are anchored at",
                                     "a candidate is not finite"};
@@ -1303,6 +1330,8 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->ad) (void)hipFree(c->ad);
     if (c->P) (void)hipFree(c->P);
     if (c->pm_vec) (void)hipFree(c->pm_vec);
+    if (c->part_g) (void)hipFree(c->part_g);
+    if (c->cwsq) (void)hipFree(c->cwsq);
     if (c->ad_ints) (void)hipFree(c->ad_ints);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->ad_graph) (void)hipGraphExecDestroy(c->ad_graph);
@@ -1352,6 +1381,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "sci_batch") c->opt_sci_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
     else if (k == "device_loop") c->opt_device_loop = value;
     else if (k == "pmode") c->opt_pmode = value;
+    else if (k == "fused") c->opt_fused = value;
     else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;
@@ -1503,6 +1533,14 @@ int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
         HIPCHK(c, hipMemsetAsync(c->lden_eff, 0, (size_t)c->ld * sizeof(double), c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->cw, w.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (weighted) {  // sqrt(c_n) for the MFMA operands of the fused sweep (plain 0 / 1 weights are their own square roots)
+        if (!c->cwsq) {
+            HIPCHK(c, hipMalloc((void**)&c->cwsq, (size_t)c->ld * sizeof(double)));
+            HIPCHK(c, hipMemsetAsync(c->cwsq, 0, (size_t)c->ld * sizeof(double), c->stream));
+        }
+        for (int64_t n = 0; n < c->N; ++n) w[n] = std::sqrt(w[n]);
+        HIPCHK(c, hipMemcpyAsync(c->cwsq, w.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->weighted = weighted;
     return MBAR_OK;

@@ -36,6 +36,8 @@ enum : int {
     CTL_NR = 4,      // ... of which Newton-Raphson steps were accepted
     CTL_REASON = 5,  // 1 = Newton system not positive definite, 2 = candidates too far apart for the fused sweep,
                      // 3 = non-finite candidate
+    CTL_NEEDGRAM = 6,  // fused sweep: 1 = the accepted candidate's Gram matrix is NOT the speculated one: run the Gram sweep
+    CTL_GRAMSWEEPS = 7,  // separate Gram sweeps requested so far
     CTL_WORDS = 8
 };
 struct LoopCtl {
@@ -48,6 +50,8 @@ struct LoopCtl {
     bool unclamped = false;
     // the matrix handed to the Gram launcher is the resident probability matrix (P mode)
     bool pmode = false;
+    // the Gram launch is conditional: the kernel exits at once unless CTL_NEEDGRAM is set (fused-sweep loop)
+    bool cond_needgram = false;
 };
 
 struct LaunchGeom {
@@ -155,6 +159,10 @@ struct AdaptArgs {
     int pmode;
     const double* a0;        // [Kp] aden at the build point (-inf for unsampled / padded states)
     double* ccur;            // [Kp]
+    // fused sweep: the Gram matrix in gram_red was accumulated with the multipliers cgram (the speculated Newton-Raphson
+    // candidate's, or the current f's after a separate Gram sweep)
+    int fused;
+    double* cgram;           // [Kp]
 };
 // ---- P mode: resident probability matrix P = exp(a0 - u - logden(a0)) (see k_psweep) ----------------------------------
 LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
@@ -165,6 +173,11 @@ hipError_t launch_psweep(hipStream_t s, int nb, int nf, const LaunchGeom& g, con
 // P from u at a0 with the known logden(a0) (read from rinv_slot's storage BEFORE it is overwritten with ones)
 hipError_t launch_build_p(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t Kp, const double* a0,
                           const double* logden, double* P, double* rinv_slot);
+// fused sweep: both candidates' normalisers / per-state sums + the Gram matrix of the second (Newton-Raphson) candidate
+LaunchGeom fused_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
+hipError_t launch_fused(hipStream_t s, int nb, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, const double* cmul,
+                        const double* cw, const double* wsq, double* rinv_base, double* gram_part, double* psum_part,
+                        const LoopCtl& lc);
 // fused build: the single-candidate sweep at the anchor point (psum partial records [nwaves][16 nb]) that also writes P and
 // fills the reciprocal slot with ones
 LaunchGeom build_sweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);

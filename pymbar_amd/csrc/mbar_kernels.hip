@@ -1196,10 +1196,11 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
        const double* __restrict__ anum_i, const double* __restrict__ anum_j,
        const double* __restrict__ logden, int64_t row_i0, int64_t row_j0,
        double* __restrict__ gram_part, double* __restrict__ psum_part, const int* __restrict__ ctl,
-       int64_t slot_stride) {
+       int64_t slot_stride, int cond_needgram) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (ctl) {  // device-resident solver loop: stop flag + the logden slot of the current f
         if (ctl[CTL_DONE] != 0) return;
+        if (cond_needgram && ctl[CTL_NEEDGRAM] == 0) return;  // the fused sweep already produced this Gram matrix
         logden += (int64_t)ctl[CTL_SLOT] * slot_stride;
     }
     constexpr int NBT = DIAG ? NBI : NBI + NBJ;  // blocks of 16 states staged per tile
@@ -2191,6 +2192,166 @@ k_psweep(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused sweep of the device-resident loop in P mode: ONE pass over the resident probability matrix per iteration.
+// For the two candidates (multipliers cmul[0] = f_sci, cmul[1] = f_nr relative to the anchor) it does what k_psweep does --
+// normalisers 1 / s_n into the slot vectors, per-state sums -- and, from the SAME tile in registers, accumulates the Gram
+// matrix of the Newton-Raphson candidate on the matrix cores, G'_nr = sum_n (P_n / s_n^nr)(P_n / s_n^nr)^T.  If the loop
+// then accepts f_nr (it nearly always does: mbar_solvers.py:607) the next iteration's Hessian is already there and the
+// separate Gram sweep is skipped; otherwise that sweep runs (k_select decides, CTL_NEEDGRAM).  Without exponentials the
+// sweep's VALU work is small next to the 9216 MFMA cycles per tile, so the fusion costs ~15 % over the bare Gram
+// sweep and saves the second pass over HBM.  (Round 1 tried the same with per-sweep exponentials: no gain, the pipe
+// was full.)  wsq: sqrt of the per-sample multiplicities (= cw itself for plain 0 / 1 weights).
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool WIDE>
+__global__ void __launch_bounds__(256, 1)
+k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cmul,
+        const double* __restrict__ cw, const double* __restrict__ wsq, double* __restrict__ rinv0,
+        double* __restrict__ rinv1, double* __restrict__ gram_part, double* __restrict__ psum_part,
+        const int* __restrict__ ctl, int64_t slot_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl) {
+        if (ctl[CTL_DONE] != 0) return;
+        const int s = ctl[CTL_SLOT];
+        rinv1 = rinv0 + (int64_t)((s + 2) % 3) * slot_stride;
+        rinv0 = rinv0 + (int64_t)((s + 1) % 3) * slot_stride;
+    }
+    constexpr int ROWS = NB * 16;
+    constexpr int NDMA = ROWS / 8 + 2;            // tile rows + the two weight vectors
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + 2 * TS * 8;
+    constexpr int NBLK = NB * (NB + 1) / 2;
+    constexpr bool PINNED = NBLK > GRAM_AGPR_BLOCKS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem + wave * (2 * TILE_BYTES);
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const RowIdentity rows{0};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+
+    double c[2][NB], acc[2][NB];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            c[f][I] = cmul[f * ROWS + 16 * I + ks];
+            acc[f][I] = 0.0;
+        }
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) settle(c[f][I]);
+    v4d G[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) G[b] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+    const int gq = ks & 3;            // this lane keeps the reciprocal of sample 4 gq + ns for the store
+    const int fq = (ks & 4) ? 1 : 0;  // ... of candidate fq (lanes ks < 8 store)
+
+    auto stage = [&](int64_t tile, char* dst) {
+        stage_tile<ROWS, true, 0, 1>(P, ld, tile * TS, dst, lane, so, rows);
+        stage_vec16<true>(cw, tile * TS, dst + U_BYTES, lane);
+        stage_vec16<true>(wsq, tile * TS, dst + U_BYTES + TS * 8, lane);
+    };
+    int64_t t = gw;
+    int cur = 0;
+    if (t < ntiles) stage(t, buf);
+    for (; t < ntiles; t += W) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        const int64_t tn = t + W;
+        if (tn < ntiles) {
+            stage(tn, buf + (cur ^ 1) * TILE_BYTES);
+            // vmcnt counts the reciprocal store too: [tile t][store of tile t - W][tile tn]
+            if (t != gw)
+                wait_vm<NDMA + 1>();
+            else
+                wait_vm<NDMA>();
+        } else {
+            wait_vm<0>();
+        }
+        // every LDS operand of the tile is requested up front (one exposed LDS round trip per tile)
+        double w[GROUPS], sw[GROUPS], uv[GROUPS][NB];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            w[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+            sw[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + TS * 8 + (4 * g + ns) * 8);
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+                uv[g][I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double keep = 0.0;
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            double s0 = dot_sum<NB>(uv[g], c[0]), s1 = dot_sum<NB>(uv[g], c[1]);
+            row16_sum2(s0, s1);
+            // (a padded sample has an all-zero column: keep its reciprocal finite, its multiplicity is 0)
+            const double r0 = recip_fast(fmax(s0, 1e-300)), r1 = recip_fast(fmax(s1, 1e-300));
+            const double q0 = w[g] * r0, q1 = w[g] * r1;
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+                acc[0][I] = fma(uv[g][I], q0, acc[0][I]);
+                acc[1][I] = fma(uv[g][I], q1, acc[1][I]);
+            }
+            if (gq == g) keep = fq ? r1 : r0;
+            const bool valid = (t * TS + 4 * g + ns) < N;
+            const double rin = valid ? r1 * sw[g] : 0.0;  // operand of the Newton-Raphson candidate's Gram matrix
+            double p[NB];
+#pragma unroll
+            for (int I = 0; I < NB; ++I) p[I] = uv[g][I] * rin;
+            auto mfma = [&](int b, double x, double y) {
+                if constexpr (PINNED) {
+                    if (b < GRAM_AGPR_BLOCKS)
+                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(G[b]) : "v"(x), "v"(y));
+                    else
+                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(G[b]) : "v"(x), "v"(y));
+                } else {
+                    G[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, G[b], 0, 0, 0);
+                }
+            };
+            if constexpr (PINNED) {  // (asm MFMAs are opaque to the scheduler and the hazard recogniser: see k_gram)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7");
+            }
+            int b = 0;
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int J = I; J < NB; ++J) mfma(b++, p[I], p[J]);
+            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            // exactly ONE store instruction per tile and wave (sample 0 of every tile exists): the vmcnt bookkeeping needs it
+            const int64_t n = t * TS + 4 * gq + ns;
+            double* out = fq ? rinv1 : rinv0;
+            if (n < N && ks < 8) out[n] = keep;
+        }
+        cur ^= 1;
+    }
+    if constexpr (PINNED) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(gw * 2 + f) * ROWS + 16 * I + lane] = v;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = G[b][r];
+}
+
 // Same reduction as k_reduce for TWO partial-record arrays with the same number of records in one launch
 // (blocks [0, gxA) work on A, the rest on B; identical summation order).
 __global__ void __launch_bounds__(256)
@@ -2263,7 +2424,7 @@ k_newton(AdaptArgs q) {
         s_ps[k] = q.psum[k];
         s_nk[k] = q.Nk[k];
         s_ln[k] = q.lnNk[k];
-        s_cc[k] = q.pmode ? q.ccur[k] : 1.0;
+        s_cc[k] = q.pmode ? (q.fused ? q.cgram[k] : q.ccur[k]) : 1.0;  // the multipliers the Gram sweep left out
         s_a0[k] = q.pmode ? q.a0[k] : 0.0;
         pos[k] = 0;
     }
@@ -2448,6 +2609,11 @@ k_select(AdaptArgs q) {
     double max_delta = block256_max(d1 != d1 ? 0.0 : d1, red);
     const double max_diff = block256_max(d2 != d2 ? 0.0 : d2, red);
     if (nan_seen > 0.0) max_delta = NAN;
+    // Fused sweep: the Gram matrix of the Newton-Raphson candidate is already there.  It serves the next iteration when
+    // that candidate was accepted -- or when the two candidates coincide to 1e-10 (at the fixed point the choice is
+    // round-off noise; the Hessian of one is the Hessian of the other far below any tolerance it is used at).
+    const bool reuse = q.fused && (ch == 1 || max_diff <= 1e-10);
+    if (q.fused && in) q.cgram[tid] = reuse ? m1 : (ch == 0 ? m0 : m1);
     if (tid == 0) {
         const int it = ctl[CTL_ITER];
         if (it < q.hist_cap) {
@@ -2461,6 +2627,10 @@ k_select(AdaptArgs q) {
         ctl[CTL_ITER] = it + 1;
         if (ch == 0) ctl[CTL_SCI] += 1; else ctl[CTL_NR] += 1;
         ctl[CTL_SLOT] = (ctl[CTL_SLOT] + (ch == 0 ? 1 : 2)) % 3;
+        if (q.fused) {
+            ctl[CTL_NEEDGRAM] = reuse ? 0 : 1;
+            if (!reuse) ctl[CTL_GRAMSWEEPS] += 1;
+        }
         if (stop) ctl[CTL_DONE] = 1;
     }
 }
@@ -2739,10 +2909,10 @@ static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double
         const int64_t ntiles = (N + TS - 1) / TS;
         if (lc.ev_start && lc.ev_stop)
             hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, u, ld,
-                                  N, ntiles, ai, aj, logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride);
+                                  N, ntiles, ai, aj, logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride, lc.cond_needgram ? 1 : 0);
         else
             hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, ai, aj,
-                               logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride);
+                               logden, ri, rj, gp, pp, lc.ctl, lc.slot_stride, lc.cond_needgram ? 1 : 0);
         return hipGetLastError();
     };
     return stage_offsets_wide(ld) ? launch(k_gram<NBI, NBJ, DIAG, DMA, true, CLAMP, PMODE>)
@@ -3116,6 +3286,61 @@ hipError_t launch_build_sweep(hipStream_t s, int nb, const LaunchGeom& g, const 
     switch (nb) {
 #define MBAR_CASE(NB_) \
     case NB_: return launch_build_sweep_nb<NB_>(s, g, u, ld, N, aden, cw, P, rinv_slot, pp);
+        MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7) MBAR_CASE(8)
+#undef MBAR_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Fused sweep (P mode): geometry of the full Gram panel -- one workgroup of four waves per CU, two tile buffers per wave.
+LaunchGeom fused_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override) {
+    LaunchGeom g;
+    g.waves = 4;
+    g.variant = 1;
+    const size_t tile = (size_t)nb * 16 * TS * 8 + 2 * TS * 8;
+    g.lds_bytes = (size_t)4 * 2 * tile;
+    int64_t want = (ntiles + 3) / 4;
+    int64_t cap = num_cu;
+    if (nb <= 5) {  // narrow panels: few accumulators, several workgroups per CU (cf. gram_geometry)
+        static const int occ[6] = {1, 4, 4, 3, 2, 2};
+        const int by_lds = blocks_per_cu_for(g.lds_bytes);
+        cap = (int64_t)num_cu * (by_lds < occ[nb] ? by_lds : occ[nb]);
+    }
+    if (grid_override > 0) cap = grid_override;
+    if (want < 1) want = 1;
+    g.blocks = (int)(want < cap ? want : cap);
+    g.nwaves = g.blocks * 4;
+    g.psum_records = g.nwaves;
+    return g;
+}
+template <int NB>
+static hipError_t launch_fused_nb(hipStream_t s, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, const double* cmul,
+                                  const double* cw, const double* wsq, double* rinv0, double* gp, double* pp, const LoopCtl& lc) {
+    auto go = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        double* r1 = nullptr;
+        if (lc.ev_start && lc.ev_stop)
+            hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, P, ld, N, ntiles, cmul,
+                                  cw, wsq, rinv0, r1, gp, pp, lc.ctl, lc.slot_stride);
+        else
+            hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, P, ld, N, ntiles, cmul, cw, wsq, rinv0, r1, gp, pp,
+                               lc.ctl, lc.slot_stride);
+        return hipGetLastError();
+    };
+    return stage_offsets_wide(ld) ? go(k_fused<NB, true>) : go(k_fused<NB, false>);
+}
+hipError_t launch_fused(hipStream_t s, int nb, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, const double* cmul,
+                        const double* cw, const double* wsq, double* rinv_base, double* gram_part, double* psum_part,
+                        const LoopCtl& lc) {
+    if (!lc.ctl) return hipErrorInvalidValue;  // (the slot vectors are addressed through the control words)
+    switch (nb) {
+#define MBAR_CASE(NB_) \
+    case NB_: return launch_fused_nb<NB_>(s, g, P, ld, N, cmul, cw, wsq, rinv_base, gram_part, psum_part, lc);
         MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7) MBAR_CASE(8)
 #undef MBAR_CASE
         default: return hipErrorInvalidValue;

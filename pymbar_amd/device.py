@@ -260,7 +260,7 @@ class DeviceMatrix:
         self._check(self._lib.mbar_solve_adaptive(self._ctx, _dptr(f), tol, int(maxiter), int(min_sc_iter),
                                                   float(gamma), 1 if check_convergence else 0, _dptr(hist),
                                                   int(history_rows), C.byref(res)))
-        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_ if k != "reserved"}
+        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_}
         out["success"] = bool(res.success)
         out["history"] = hist[: min(history_rows, res.iterations)]
         return f, out
@@ -270,7 +270,7 @@ class DeviceMatrix:
         res = _lib.SolveResult()
         self._check(self._lib.mbar_solve_sci(self._ctx, _dptr(f), tol, int(maxiter),
                                              1 if check_convergence else 0, C.byref(res)))
-        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_ if k != "reserved"}
+        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_}
         out["success"] = bool(res.success)
         return f, out
 
@@ -279,7 +279,7 @@ class DeviceMatrix:
         """{class: (total_ms, launches)} of HIP-event timed kernels since the last reset."""
         out = {}
         for name, which in (("lse", _lib.TIMER_LSE), ("gram", _lib.TIMER_GRAM), ("reduce", _lib.TIMER_REDUCE),
-                            ("other", _lib.TIMER_OTHER)):
+                            ("other", _lib.TIMER_OTHER), ("fused", _lib.TIMER_FUSED)):
             ms = C.c_double(0.0)
             n = C.c_int64(0)
             self._check(self._lib.mbar_ctx_timing(self._ctx, which, C.byref(ms), C.byref(n)))

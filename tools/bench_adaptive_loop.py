@@ -15,12 +15,13 @@ from pymbar_amd.device import DeviceMatrix  # noqa: E402
 
 def run(dm, K, label, steps):
     f0 = np.zeros(K)
-    for mode, opts in (("device graph classic", dict(device_loop=1, graph=1, timing=1, pmode=0)),
-                       ("device graph", dict(device_loop=1, graph=1, timing=1, pmode=1)),
-                       ("device eager", dict(device_loop=1, graph=0, timing=1, pmode=1)),
-                       ("device eager classic", dict(device_loop=1, graph=0, timing=1, pmode=0)),
-                       ("device eager notime", dict(device_loop=1, graph=0, timing=0, pmode=1)),
-                       ("host loop", dict(device_loop=0, graph=1, timing=1, pmode=1))):
+    for mode, opts in (("device graph classic", dict(device_loop=1, graph=1, timing=1, pmode=0, fused=0)),
+                       ("device graph 2sweep", dict(device_loop=1, graph=1, timing=1, pmode=1, fused=0)),
+                       ("device graph", dict(device_loop=1, graph=1, timing=1, pmode=1, fused=1)),
+                       ("device eager", dict(device_loop=1, graph=0, timing=1, pmode=1, fused=1)),
+                       ("device eager 2sweep", dict(device_loop=1, graph=0, timing=1, pmode=1, fused=0)),
+                       ("device eager notime", dict(device_loop=1, graph=0, timing=0, pmode=1, fused=1)),
+                       ("host loop", dict(device_loop=0, graph=1, timing=1, pmode=1, fused=1))):
         for k, v in opts.items():
             dm.set_option(k, v)
         dm.solve_adaptive(f0, maxiter=steps, min_sc_iter=0, check_convergence=False)  # warm-up (captures the graph)
@@ -30,13 +31,14 @@ def run(dm, K, label, steps):
         f, r = dm.solve_adaptive(f0, maxiter=steps, min_sc_iter=0, check_convergence=False)
         dt = time.perf_counter() - t0
         tm = dm.timing()
-        kern = sum(tm[k][0] for k in ("gram", "lse")) / steps if tm["gram"][1] else float("nan")
-        detail = f"gram {tm['gram'][0] / max(1, tm['gram'][1]):.4f} x{tm['gram'][1]} lse {tm['lse'][0] / max(1, tm['lse'][1]):.4f} x{tm['lse'][1]}"
+        kern = sum(tm[k][0] for k in ("gram", "lse", "fused")) / steps if tm["gram"][1] else float("nan")
+        detail = (f"gram {tm['gram'][0] / max(1, tm['gram'][1]):.4f} x{tm['gram'][1]} lse {tm['lse'][0] / max(1, tm['lse'][1]):.4f} "
+                  f"x{tm['lse'][1]} fused {tm['fused'][0] / max(1, tm['fused'][1]):.4f} x{tm['fused'][1]} gram_sweeps {r.get('gram_sweeps')}")
         t1 = time.perf_counter()
         fc, rc = dm.solve_adaptive(f0, tol=1e-12, maxiter=10000, min_sc_iter=0)
         dtc = time.perf_counter() - t1
         print(f"{label:22s} {mode:19s}: {1e3 * dt / steps:8.4f} ms/iteration over {steps} (timed sweeps {kern:7.4f} ms/it; {detail}), "
-              f"solve from f=0: {rc['iterations']} iterations {1e3 * dtc:8.3f} ms, success={rc['success']}", flush=True)
+              f"solve from f=0: {rc['iterations']} iterations ({rc.get('gram_sweeps')} Gram sweeps) {1e3 * dtc:8.3f} ms, success={rc['success']}", flush=True)
     return fc
 
 
