@@ -953,33 +953,6 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     }
     if (pmode && !c->pm_vec) HIPCHK(c, hipMalloc((void**)&c->pm_vec, (size_t)3 * Kp * sizeof(double)));
     const bool fused = pmode && c->opt_fused;
-    // initial gradient (mbar_solvers.py:570).  Classic: the evaluation sweep, logden(f) stays in slot 0.  P mode: the
-    // same sweep also writes P = exp(a0 - u - logden(a0)) with a0 = aden(f) and leaves 1 / s = 1 in slot 0.
-    if (!pmode) {
-        rc = eval_core(c, f.data(), 1, 0, c->logden[0], nullptr, psum.data(), nullptr, nullptr);
-        if (rc) return rc;
-    } else {
-        const LaunchGeom gb = build_sweep_geometry(nb, c->num_cu, ntiles, c->opt_grid);
-        rc = ensure(c, &c->part, &c->part_doubles, (size_t)gb.nwaves * Kp);
-        if (rc) return rc;
-        rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)gb.nwaves / 32 + 1) * Kp);
-        if (rc) return rc;
-        rc = ensure_red(c, (size_t)2 * Kp + 2);
-        if (rc) return rc;
-        build_aden(c, f.data(), c->hstage, Kp);
-        HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, (size_t)Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        {
-            ScopedTimer t(c, MBAR_TIMER_OTHER);
-            HIPCHK(c, launch_build_sweep(c->stream, nb, gb, c->u, c->ld, c->N, d_aden(c), c->cw, c->P, c->logden[0], c->part));
-        }
-        HIPCHK(c, launch_reduce(c->stream, c->part, gb.nwaves, Kp, c->scratch, c->red));
-        rc = allreduce_dev(c, c->red, Kp, 0);
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->hred, c->red, (size_t)Kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        rc = sync_stream(c);
-        if (rc) return rc;
-        for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k];
-    }
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
     const LaunchGeom gl = fused ? fused_geometry(nb, c->num_cu, ntiles, c->opt_grid)
@@ -989,20 +962,57 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         gg.blocks = gl.blocks;
         gg.nwaves = gl.nwaves;
     }
+    // build sweep of P mode: with the fused loop it also accumulates the Gram matrix at the anchor (grid of the fused sweep)
+    const LaunchGeom gb = fused ? build_gram_geometry(nb, c->num_cu, ntiles, c->opt_grid)
+                                : build_sweep_geometry(nb, c->num_cu, ntiles, c->opt_grid);
     const size_t rec_g = (size_t)nb * (nb + 1) / 2 * 256;
     const size_t rec_l = (size_t)2 * Kp;
     const size_t off_gram = rec_l + 2;
     rc = ensure_red(c, off_gram + rec_g);
     if (rc) return rc;
-    rc = ensure(c, &c->part, &c->part_doubles, std::max((size_t)gg.nwaves * rec_g, (size_t)gl.nwaves * (rec_l + 2)));
+    rc = ensure(c, &c->part, &c->part_doubles,
+                std::max(std::max((size_t)gg.nwaves * rec_g, (size_t)gl.nwaves * (rec_l + 2)), (size_t)gb.nwaves * Kp));
     if (rc) return rc;
     rc = ensure(c, &c->scratch, &c->scratch_doubles,
-                std::max(((size_t)gg.nwaves / 32 + 1) * rec_g, ((size_t)gl.nwaves / 32 + 1) * (rec_l + 2)));
+                std::max(std::max(((size_t)gg.nwaves / 32 + 1) * rec_g, ((size_t)gl.nwaves / 32 + 1) * (rec_l + 2)),
+                         ((size_t)gb.nwaves / 32 + 1) * Kp));
     if (rc) return rc;
     if (c->weighted && !c->lden_eff) return fail(c, MBAR_ERR_STATE, "weighted context without its logden buffer");
     if (fused) {
         rc = ensure(c, &c->part_g, &c->part_g_doubles, (size_t)gl.nwaves * rec_g);
         if (rc) return rc;
+    }
+    // initial gradient (mbar_solvers.py:570).  Classic: the evaluation sweep, logden(f) stays in slot 0.  P mode: the
+    // same sweep also writes P = exp(a0 - u - logden(a0)) with a0 = aden(f) and leaves 1 / s = 1 in slot 0; in the fused
+    // loop it accumulates the first Hessian's Gram matrix as well (its reduced blocks wait in `red` for k_newton).
+    if (!pmode) {
+        rc = eval_core(c, f.data(), 1, 0, c->logden[0], nullptr, psum.data(), nullptr, nullptr);
+        if (rc) return rc;
+        rc = ensure_red(c, off_gram + rec_g);  // (eval_core may have re-sized nothing; kept for symmetry)
+        if (rc) return rc;
+    } else {
+        build_aden(c, f.data(), c->hstage, Kp);
+        HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, (size_t)Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        {
+            ScopedTimer t(c, MBAR_TIMER_OTHER);
+            if (fused)
+                HIPCHK(c, launch_build_gram(c->stream, nb, gb, c->u, c->ld, c->N, d_aden(c), c->cw, c->weighted ? c->cwsq : c->cw,
+                                            c->P, c->logden[0], c->part, c->part_g));
+            else
+                HIPCHK(c, launch_build_sweep(c->stream, nb, gb, c->u, c->ld, c->N, d_aden(c), c->cw, c->P, c->logden[0], c->part));
+        }
+        HIPCHK(c, launch_reduce(c->stream, c->part, gb.nwaves, Kp, c->scratch, c->red));
+        rc = allreduce_dev(c, c->red, Kp, 0);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->hred, c->red, (size_t)Kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (fused) {  // Gram matrix at the anchor: reduced (and all-reduced) into the slot k_newton reads
+            HIPCHK(c, launch_reduce(c->stream, c->part_g, gb.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
+            rc = allreduce_dev(c, c->red + off_gram, (int64_t)rec_g, 0);
+            if (rc) return rc;
+        }
+        rc = sync_stream(c);
+        if (rc) return rc;
+        for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k];
     }
     double* gram_part = fused ? c->part_g : c->part;
 
@@ -1019,8 +1029,10 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         h[ad_off_prm(c) + 3] = check_convergence ? 1.0 : 0.0;
         h[ad_off_state(c)] = std::numeric_limits<double>::quiet_NaN();
         std::vector<int> hi((size_t)CTL_WORDS + Kp, 0);
-        hi[CTL_NEEDGRAM] = 1;  // (nothing has been speculated yet: the first iteration runs the Gram sweep)
-        hi[CTL_GRAMSWEEPS] = 1;
+        // two-sweep loops and the classic mode run a Gram sweep per iteration; the fused loop starts with the Gram matrix
+        // its build sweep accumulated (multipliers cgram = 1 at the anchor)
+        hi[CTL_NEEDGRAM] = fused ? 0 : 1;
+        hi[CTL_GRAMSWEEPS] = 0;
         hi[CTL_ITER] = (int)res.iterations;
         hi[CTL_SCI] = (int)res.sci_iter;
         hi[CTL_NR] = (int)res.nr_iter;

@@ -183,6 +183,11 @@ hipError_t launch_fused(hipStream_t s, int nb, const LaunchGeom& g, const double
 LaunchGeom build_sweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
 hipError_t launch_build_sweep(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                               const double* aden, const double* cw, double* P, double* rinv_slot, double* psum_part);
+// ... and the Gram matrix at the anchor point as well (gram partial records in the fused sweep's layout and count)
+LaunchGeom build_gram_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
+hipError_t launch_build_gram(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                             const double* aden, const double* cw, const double* wsq, double* P, double* rinv_slot,
+                             double* psum_part, double* gram_part);
 hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,
                                 const LoopCtl& lc = LoopCtl());
 // K x K Newton system (gauge-fixed, Gauss-Jordan in registers, one workgroup) + both candidates + sweep inputs

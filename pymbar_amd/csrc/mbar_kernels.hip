@@ -2061,6 +2061,146 @@ k_build_sweep(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntile
     }
 }
 
+// Build sweep that ALSO accumulates the Gram matrix at the anchor point (the first Hessian of the solve) on the matrix
+// cores: the normalised probabilities it writes to P are exactly the MFMA operands, so the separate first Gram sweep of
+// the fused loop (one more pass over HBM) is not needed.  One group of 4 samples at a time (the 36 accumulator blocks
+// of a 128-state panel leave no room for two groups of exponential temporaries).  wsq: sqrt of the sample multiplicities.
+template <int NB, bool WIDE>
+__global__ void __launch_bounds__(256, 1)
+k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ aden,
+             const double* __restrict__ cw, const double* __restrict__ wsq, double* __restrict__ P,
+             double* __restrict__ rinv_slot, double* __restrict__ psum_part, double* __restrict__ gram_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16;
+    constexpr int NDMA = ROWS / 8;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + 2 * TS * 8;  // + the tile's 16 sample weights and their square roots
+    constexpr int NBLK = NB * (NB + 1) / 2;
+    constexpr bool PINNED = NBLK > GRAM_AGPR_BLOCKS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    exp_table_init(smem);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const RowIdentity rows{0};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+
+    double a[NB], acc[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        a[I] = aden[16 * I + ks];
+        acc[I] = 0.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) settle(a[I]);
+    v4d G[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) G[b] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    auto stage = [&](int64_t tile, char* dst) {
+        stage_tile<ROWS, true, 0, 1>(u, ld, tile * TS, dst, lane, so, rows);
+        stage_vec16<true>(cw, tile * TS, dst + U_BYTES, lane);
+        stage_vec16<true>(wsq, tile * TS, dst + U_BYTES + TS * 8, lane);
+    };
+    int64_t t = gw;
+    int cur = 0;
+    if (t < ntiles) stage(t, buf);
+    for (; t < ntiles; t += W) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        const int64_t tn = t + W;
+        if (tn < ntiles) {
+            stage(tn, buf + (cur ^ 1) * TILE_BYTES);
+            // vmcnt counts stores too, in issue order: [tile t: NDMA + 2][stores of tile t - W: NDMA + 1][tile tn: NDMA + 2]
+            if (t != gw)
+                wait_vm<(NDMA + 1) + (NDMA + 2)>();
+            else
+                wait_vm<NDMA + 2>();
+        } else {
+            wait_vm<0>();
+        }
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const double w = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+            const double sw = *reinterpret_cast<const double*>(cbuf + U_BYTES + TS * 8 + (4 * g + ns) * 8);
+            double x[NB];
+#pragma unroll
+            for (int I = 0; I < NB; ++I) x[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int I = 0; I < NB; ++I) x[I] = a[I] - x[I];
+            const double m2 = row16_max(tree_max<NB>(x)) * LOG2E_S;
+#pragma unroll
+            for (int I = 0; I < NB; ++I) x[I] = fma(x[I], LOG2E_S, -m2);
+            exp2s_batch<NB>(x);
+            const double ri = recip_fast(row16_sum(tree_sum<NB>(x)));
+            const bool valid = (t * TS + 4 * g + ns) < N;
+            const double opw = valid ? sw : 0.0;
+            double p[NB];
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+                x[I] *= ri;                                   // P_kn
+                acc[I] = fma(x[I], w, acc[I]);                // per-state sums (gradient at the anchor)
+                *reinterpret_cast<double*>(cbuf + I * (16 * TS * 8) + pos[g]) = x[I];
+                p[I] = x[I] * opw;                            // MFMA operand (sqrt of the multiplicity; 0 on the padding)
+            }
+            auto mfma = [&](int b, double xx, double yy) {
+                if constexpr (PINNED) {
+                    if (b < GRAM_AGPR_BLOCKS)
+                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(G[b]) : "v"(xx), "v"(yy));
+                    else
+                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(G[b]) : "v"(xx), "v"(yy));
+                } else {
+                    G[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xx, yy, G[b], 0, 0, 0);
+                }
+            };
+            if constexpr (PINNED) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7");
+            }
+            int b = 0;
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int J = I; J < NB; ++J) mfma(b++, p[I], p[J]);
+            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+        }
+        // the tile now holds P: out with it, 16 bytes per lane, 8 lanes per row (the LDS-DMA pattern backwards)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            const double2 v = *reinterpret_cast<const double2*>(cbuf + j * 1024 + lane * 16);
+            char* dst = reinterpret_cast<char*>(P + (int64_t)(8 * j) * ld + t * TS) + so.off[j & 1];
+            *reinterpret_cast<double2*>(dst) = v;
+        }
+        {
+            const int64_t n = t * TS + lane;
+            if (lane < TS && n < N) rinv_slot[n] = 1.0;
+        }
+        cur ^= 1;
+    }
+    if constexpr (PINNED) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        double v = acc[I];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) psum_part[gw * ROWS + 16 * I + lane] = v;
+    }
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = G[b][r];
+}
+
 // Two 4-sample groups of a P tile for NF candidates: s = sum_k P c_k (FMA dot + 16-lane sum), r = 1 / s, acc += P w r.
 template <int NB, int NF>
 __device__ __forceinline__ void psweep_two_groups(const char* cbuf, int rd0, int rd1, const double (&c)[NF][NB],
@@ -3341,6 +3481,42 @@ hipError_t launch_fused(hipStream_t s, int nb, const LaunchGeom& g, const double
     switch (nb) {
 #define MBAR_CASE(NB_) \
     case NB_: return launch_fused_nb<NB_>(s, g, P, ld, N, cmul, cw, wsq, rinv_base, gram_part, psum_part, lc);
+        MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7) MBAR_CASE(8)
+#undef MBAR_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Build sweep + Gram matrix at the anchor: geometry of the fused sweep (same partial-record counts), tables in LDS.
+LaunchGeom build_gram_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override) {
+    // (same grid as the fused sweep, so that the partial-record counts agree; the kernel strides over tiles, so it does
+    // not matter if the look-up tables leave room for one workgroup per CU less)
+    LaunchGeom g = fused_geometry(nb, num_cu, ntiles, grid_override);
+    g.lds_bytes += EXP_TABLE_BYTES;
+    return g;
+}
+template <int NB>
+static hipError_t launch_build_gram_nb(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                       const double* aden, const double* cw, const double* wsq, double* P, double* rinv_slot,
+                                       double* pp, double* gp) {
+    auto go = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, wsq, P, rinv_slot, pp, gp);
+        return hipGetLastError();
+    };
+    return stage_offsets_wide(ld) ? go(k_build_gram<NB, true>) : go(k_build_gram<NB, false>);
+}
+hipError_t launch_build_gram(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                             const double* aden, const double* cw, const double* wsq, double* P, double* rinv_slot,
+                             double* psum_part, double* gram_part) {
+    switch (nb) {
+#define MBAR_CASE(NB_) \
+    case NB_: return launch_build_gram_nb<NB_>(s, g, u, ld, N, aden, cw, wsq, P, rinv_slot, psum_part, gram_part);
         MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7) MBAR_CASE(8)
 #undef MBAR_CASE
         default: return hipErrorInvalidValue;

@@ -298,6 +298,64 @@ def test_full_panel_gram_with_and_without_the_exponential_clamp(DM):
             assert np.linalg.norm(g) < 1e-6 * N
 
 
+@pytest.mark.parametrize("K,N,unsampled", [(5, 3000, ()), (40, 20000, (7, 23)), (64, 9000, ()), (128, 30011, (5,))])
+def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
+    """The adaptive iteration in its four forms -- host-driven loop, device-resident loop with per-sweep exponentials,
+    with the resident probability matrix (two sweeps), and with the fused sweep (speculated Gram matrix of the Newton
+    candidate) -- gives the same free energies, iteration counts and per-iteration gradient norms, also when the
+    self-consistent candidate is forced for the first iterations (every speculation of those iterations is rejected),
+    with per-sample multiplicities, with a damped Newton step, and for a fixed number of iterations past convergence."""
+    u_kn, N_k, f = random_problem(K, N, seed=K + 1, unsampled=unsampled)
+    sws = np.where(N_k > 0)[0]
+    modes = {"host": dict(device_loop=0), "classic": dict(device_loop=1, pmode=0, fused=0),
+             "pmode": dict(device_loop=1, pmode=1, fused=0), "fused": dict(device_loop=1, pmode=1, fused=1),
+             "fused eager": dict(device_loop=1, pmode=1, fused=1, graph=0)}
+    rng = np.random.default_rng(K)
+    # a bootstrap replicate: draw counts of a resampling WITHIN each state (sum_n c_n over a state's samples = N_k, or the
+    # weighted equations have no solution)
+    c_n = np.zeros(u_kn.shape[1])
+    start = 0
+    for n_k in N_k:
+        if n_k > 0:
+            c_n[start:start + n_k] = np.bincount(rng.integers(0, n_k, size=n_k), minlength=n_k)
+        start += n_k
+    with DM.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        for case in (dict(min_sc_iter=0), dict(min_sc_iter=3), dict(min_sc_iter=0, gamma=0.5), dict(min_sc_iter=0, weights=True),
+                     dict(min_sc_iter=0, fixed=12)):
+            out = {}
+            for name, opts in modes.items():
+                for k, v in {"graph": 1, **opts}.items():
+                    dm.set_option(k, v)
+                dm.set_sample_weights(c_n if case.get("weights") else None)
+                try:
+                    fa, ra = dm.solve_adaptive(np.zeros(K), tol=1e-12, maxiter=case.get("fixed", 200), min_sc_iter=case["min_sc_iter"],
+                                               gamma=case.get("gamma", 1.0), check_convergence="fixed" not in case, history_rows=200)
+                finally:
+                    dm.set_sample_weights(None)
+                out[name] = (fa, ra)
+            f_ref, r_ref = out["host"]
+            assert r_ref["success"] or "fixed" in case
+            for name, (fa, ra) in out.items():
+                np.testing.assert_allclose(fa[sws], f_ref[sws], rtol=1e-11, atol=1e-11, err_msg=f"{case} {name}")
+                assert ra["iterations"] == r_ref["iterations"], (case, name, ra["iterations"], r_ref["iterations"])
+                assert ra["success"] == r_ref["success"]
+                big = r_ref["history"][:, 1:3] > 1e-6
+                np.testing.assert_allclose(ra["history"][:, 1:3][big], r_ref["history"][:, 1:3][big], rtol=1e-6, err_msg=f"{case} {name}")
+                if name.startswith("fused"):
+                    if case["min_sc_iter"] == 3:
+                        assert ra["gram_sweeps"] >= 3  # the forced self-consistent steps reject the speculation
+                    assert ra["gram_sweeps"] <= ra["iterations"]
+                elif name != "host" or True:
+                    pass
+            if not case.get("weights") and "fixed" not in case:
+                f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=1e-12, min_sc_iter=case["min_sc_iter"])
+                if case.get("gamma", 1.0) == 1.0:
+                    np.testing.assert_allclose(out["fused"][0][sws], (f_or - f_or[sws[0]])[sws], rtol=1e-9, atol=1e-10)
+        for k, v in dict(device_loop=1, pmode=1, fused=1, graph=1).items():
+            dm.set_option(k, v)
+
+
 def test_objective_offset_matches_preconditioned_objective(DM):
     u_kn, N_k, f = random_problem(12, 1500, seed=21)
     with DM.from_host(u_kn) as dm:
