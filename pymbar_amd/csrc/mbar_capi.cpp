@@ -649,10 +649,16 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
 // ---- dense K x K helpers (host) ---------------------------------------------------------------
 // Cholesky solve of A x = b (A m x m SPD, row-major, destroyed).  Returns false on breakdown.
 bool chol_solve(std::vector<double>& A, std::vector<double>& b, int m) {
+    // pivots below eps * m * (largest diagonal entry) count as zero, like the singular values numpy.linalg.lstsq drops
+    // (mbar_solvers.py:582, rcond = machine precision): a state whose weights underflow leaves a row of H at ~1e-300, and
+    // dividing by it would throw the Newton candidate to +-inf where lstsq returns a zero component
+    double dmax = 0.0;
+    for (int j = 0; j < m; ++j) dmax = std::max(dmax, A[(size_t)j * m + j]);
+    const double thr = dmax * std::numeric_limits<double>::epsilon() * m;
     for (int j = 0; j < m; ++j) {
         double d = A[(size_t)j * m + j];
         for (int k = 0; k < j; ++k) d -= A[(size_t)j * m + k] * A[(size_t)j * m + k];
-        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        if (!(d > thr) || !std::isfinite(d)) return false;
         d = std::sqrt(d);
         A[(size_t)j * m + j] = d;
         for (int i = j + 1; i < m; ++i) {
@@ -809,10 +815,22 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
         double* f_nr = cand.data() + K;
         std::copy(f.begin(), f.end(), f_sci);
         std::copy(f.begin(), f.end(), f_nr);
+        bool underflow = false;
         for (int i = 0; i < m; ++i) {
             const int k = c->sampled[i];
             f_nr[k] = f[k] - gamma * x[i];                         // :584
             f_sci[k] = f[k] - std::log(psum[k] / c->Nk[k]);        // :587 via s_k
+            if (!(psum[k] > 1e-290)) underflow = true;
+        }
+        if (underflow) {
+            // A state whose weights at the current f are below the fp64 range (a start more than ~700 kT from the answer):
+            // its sum p underflowed, the reference's log-space update (:240-241) does not.  Take that path for this
+            // iteration: the all-state log-space reduction (two more sweeps; slot 0 holds logden(f) again or is about
+            // to be overwritten by pass B anyway).
+            std::vector<double> ln((size_t)K);
+            rc = mbar_lognum(c, f.data(), ln.data());
+            if (rc) return rc;
+            for (int i = 0; i < m; ++i) f_sci[c->sampled[i]] = -ln[(size_t)c->sampled[i]];
         }
         const double shift = f_sci[first];
         for (int i = 0; i < m; ++i) f_sci[c->sampled[i]] -= shift;  // :588
@@ -834,7 +852,10 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
         int choice;
         // (every rank holds bit-identical reduced sums, so this choice needs no collective; only the loop exit below
         // is agreed on explicitly, because a desynchronised exit would strand the other ranks in an all-reduce)
-        const bool take_sci = gn_sci < gn_nr || res.sci_iter < min_sc_iter;
+        // (:607.  A Newton candidate whose gradient is not a number -- a start so poor that H is numerically zero and the
+        // step is of order 1e24 -- loses against a finite self-consistent candidate; the reference's comparison would pick
+        // it, but the reference's log-space gradient never produces that NaN in the first place)
+        const bool take_sci = gn_sci < gn_nr || (std::isnan(gn_nr) && !std::isnan(gn_sci)) || res.sci_iter < min_sc_iter;
         if (take_sci) {  // :607
             std::copy(f_sci, f_sci + K, f.begin());
             std::copy(psum2.begin(), psum2.begin() + K, psum.begin());
@@ -1794,6 +1815,7 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     int rc = refresh_poison(c);
     if (rc) return rc;
     bool on_device = device_loop_eligible(c) && !c->u_poison && f_is_finite(c, f.data(), 1) && maxiter > 0;
+    int handbacks = 0;
     while (on_device) {
         bool handed_back = false;
         rc = adaptive_device_loop(c, f, tol, maxiter, min_sc_iter, gamma, check_convergence, history, history_rows, res, psum,
@@ -1803,7 +1825,11 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
         // The device handed the solve back.  A step too large for the sweeps' anchor point is a one-off (typically the
         // first Newton step from a poor start): ONE host-driven iteration, then back to the device, which re-anchors at
         // the new f.  Anything else (Newton system not positive definite, non-finite candidate) stays on the host.
-        const bool one_off = c->h_ctl[CTL_REASON] == 2 && res.iterations + 1 < maxiter;
+        // (a non-finite candidate is usually the same situation seen from the other side -- a state whose weights
+        // underflow at the current f -- and the host iteration handles it in log space; a Newton system that is not
+        // positive definite, or repeated hand-backs, stay on the host)
+        const int reason = c->h_ctl[CTL_REASON];
+        const bool one_off = (reason == 2 || reason == 3) && ++handbacks <= 6 && res.iterations + 1 < maxiter;
         if (!one_off) {
             on_device = false;
             break;

@@ -170,9 +170,6 @@ LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_over
 hipError_t launch_psweep(hipStream_t s, int nb, int nf, const LaunchGeom& g, const double* P, int64_t ld, int64_t N,
                          const double* cmul, const double* cw, double* rinv0, double* rinv1, double* psum_part,
                          const LoopCtl& lc = LoopCtl());
-// P from u at a0 with the known logden(a0) (read from rinv_slot's storage BEFORE it is overwritten with ones)
-hipError_t launch_build_p(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t Kp, const double* a0,
-                          const double* logden, double* P, double* rinv_slot);
 // fused sweep: both candidates' normalisers / per-state sums + the Gram matrix of the second (Newton-Raphson) candidate
 LaunchGeom fused_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
 hipError_t launch_fused(hipStream_t s, int nb, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, const double* cmul,

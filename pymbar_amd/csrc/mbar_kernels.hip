@@ -1903,25 +1903,6 @@ __global__ void k_mfma_peak(int iters, double* sink) {
 // 1e-308 are flushed to zero: with |a - a0| <= 250 enforced by k_newton (hand-back, then the host rebuilds at the
 // current f) the mass lost that way is below 1e-199 of a sample's normaliser.
 // ---------------------------------------------------------------------------------------------
-// P[k][n] = exp(a0_k - u[k][n] - logden[n]) for k < Kp, n < N (coalesced along n; the library exp: runs once per solve).
-__global__ void __launch_bounds__(256)
-k_build_p(const double* __restrict__ u, int64_t ld, int64_t N, const double* __restrict__ a0,
-          const double* __restrict__ logden, double* __restrict__ P) {
-    const int64_t k = blockIdx.y;
-    const double ak = a0[k];
-    double* row = P + k * ld;
-    if (ak == -INFINITY) {  // unsampled / padded state (uniform per block row)
-        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) row[n] = 0.0;
-        return;
-    }
-    const double* ur = u + k * ld;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
-        row[n] = exp((ak - logden[n]) - ur[n]);
-}
-// v[n] = 1 for n < N (the normaliser 1 / s_n at the build point)
-__global__ void __launch_bounds__(256) k_fill_ones(double* __restrict__ v, int64_t N) {
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) v[n] = 1.0;
-}
 // out[n] = rinv[slot][n] * sqrt(cw[n]): per-sample multiplicities folded into both MFMA operands of the P-mode Gram sweep
 __global__ void __launch_bounds__(256)
 k_rinv_weighted(const double* __restrict__ rinv, const double* __restrict__ cw, int64_t N, double* __restrict__ out,
@@ -2618,6 +2599,11 @@ k_newton(AdaptArgs q) {
             A[r][c] = v;
         }
     }
+    // pivots below eps * M * (largest per-state sum, which bounds the diagonal of H) count as zero like the singular values
+    // numpy.linalg.lstsq drops (:582): the host path then takes the pseudo-inverse
+    double pmax = 0.0;
+    for (int i = 0; i < q.m; ++i) pmax = fmax(pmax, s_ps[smp[i]]);
+    const double piv_thr = pmax * 2.220446049250313e-16 * (double)(M > 0 ? M : 1);
     bool bad = false;
 #pragma unroll
     for (int jc = 0; jc < 4; ++jc) {
@@ -2634,7 +2620,7 @@ k_newton(AdaptArgs q) {
             __syncthreads();
             const double piv = cb[j];
             if (tid == 0) pv[j] = piv;
-            if (!(piv > 0.0) || !isfinite(piv)) bad = true;  // the same value in every thread
+            if (!(piv > piv_thr) || !isfinite(piv)) bad = true;  // the same value in every thread
             const double inv = recip_fast(piv);
             double mr[4];
 #pragma unroll
@@ -2741,7 +2727,8 @@ k_select(AdaptArgs q) {
     const double ga = sampled ? ps0 - nk : 0.0, gb = sampled ? ps1 - nk : 0.0;
     const double gs = block256_sum(ga * ga, red);
     const double gn = block256_sum(gb * gb, red);
-    const int ch = (gs < gn || ctl[CTL_SCI] < min_sc) ? 0 : 1;  // :607 (every thread holds the same sums)
+    // :607 (every thread holds the same sums); a NaN Newton gradient loses against a finite self-consistent one (host loop)
+    const int ch = (gs < gn || (gn != gn && gs == gs) || ctl[CTL_SCI] < min_sc) ? 0 : 1;
     const double fnew = ch == 0 ? fs : fn;
     if (in) {
         q.f[tid] = fnew;
@@ -3391,16 +3378,6 @@ hipError_t launch_psweep(hipStream_t s, int nb, int nf, const LaunchGeom& g, con
 #undef MBAR_CASE
         default: return hipErrorInvalidValue;
     }
-}
-
-hipError_t launch_build_p(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t Kp, const double* a0,
-                          const double* logden, double* P, double* rinv_slot) {
-    int64_t bx = (N + 255) / 256;
-    if (bx > 2048) bx = 2048;
-    if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(k_build_p, dim3((unsigned)bx, (unsigned)Kp), dim3(256), 0, s, u, ld, N, a0, logden, P);
-    hipLaunchKernelGGL(k_fill_ones, dim3((unsigned)bx), dim3(256), 0, s, rinv_slot, N);  // (after the build: it read logden there)
-    return hipGetLastError();
 }
 
 hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,

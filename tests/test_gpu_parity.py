@@ -356,6 +356,35 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
             dm.set_option(k, v)
 
 
+@pytest.mark.parametrize("K,step", [(40, 30.0), (128, 9.0)])
+def test_device_loop_reanchors_when_a_step_leaves_its_window(DM, K, step):
+    """Free energies spread over ~1200 kT with a start at f = 0: the first candidates lie far outside the 250 kT window
+    around the anchor of the resident probability matrix, so k_newton hands the solve back, the host runs one classic
+    iteration and the device loop re-anchors -- possibly several times.  Same answer and iteration count as the
+    host-driven loop and as the oracle."""
+    u_kn, N_k, f = random_problem(K, 6000, seed=5)
+    u_kn = u_kn + step * np.arange(K)[:, None]          # f_k shifts by step * k
+    sws = np.arange(K)
+    with DM.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        out = {}
+        for name, opts in (("host", dict(device_loop=0)), ("fused", dict(device_loop=1, pmode=1, fused=1)),
+                           ("pmode", dict(device_loop=1, pmode=1, fused=0)), ("classic", dict(device_loop=1, pmode=0, fused=0))):
+            for k, v in opts.items():
+                dm.set_option(k, v)
+            out[name] = dm.solve_adaptive(np.zeros(K), tol=1e-12, maxiter=300, min_sc_iter=0)
+        f_ref, r_ref = out["host"]
+        assert r_ref["success"]
+        assert abs(f_ref[-1] - step * (K - 1)) < 10.0
+        for name, (fa, ra) in out.items():
+            assert ra["success"] and ra["iterations"] == r_ref["iterations"], (name, ra["iterations"], r_ref["iterations"])
+            np.testing.assert_allclose(fa, f_ref, rtol=1e-12, atol=1e-9, err_msg=name)
+        f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=1e-12, min_sc_iter=0)
+        np.testing.assert_allclose(out["fused"][0], f_or - f_or[0], rtol=1e-10, atol=1e-8)
+        for k, v in dict(device_loop=1, pmode=1, fused=1).items():
+            dm.set_option(k, v)
+
+
 def test_objective_offset_matches_preconditioned_objective(DM):
     u_kn, N_k, f = random_problem(12, 1500, seed=21)
     with DM.from_host(u_kn) as dm:
