@@ -261,7 +261,9 @@ def main():
         gram_ms, gram_n = timing["gram"]
         lse_ms, lse_n = timing["lse"]
         fus_ms, fus_n = timing.get("fused", (0.0, 0))
-        pm = bool(args.pmode and args.device_loop and args.staging == 0)
+        # (the device-resident loop, hence P mode and the fused sweep, needs RCCL or a single rank; with the host transport the
+        # host-driven loop and its classic sweeps run)
+        pm = bool(args.pmode and args.device_loop and args.staging == 0 and allreduce in ("none", "rccl"))
         fused = bool(pm and args.fused and fus_n > 0)
         flops = float(n_loc) * K * (K + 1)           # symmetric Gram: K(K+1)/2 entries x 2 flop x N (this rank's shard)
         bytes_pass = 8.0 * K * n_loc                 # one read of the shard per sweep
@@ -343,7 +345,8 @@ def main():
                 "workload": f"{config_name}: harmonic ladder K={K}, N_total={N_total} ({n_loc} per GPU), adaptive NR/SCI "
                             f"iteration = {what}, device-resident, fp64, generated in HBM",
                 "K": K, "N_per_gpu": n_loc, "N_total": N_total, "parallelism": f"N-sharded x{world}",
-                "allreduce": allreduce, "device": info["name"], "adaptive_loop": "device-resident" if args.device_loop else "host-driven",
+                "allreduce": allreduce, "device": info["name"],
+                "adaptive_loop": "device-resident" if (args.device_loop and allreduce in ("none", "rccl")) else "host-driven",
                 "sweeps": sweeps,
             },
             "roofline": roof,

@@ -39,6 +39,11 @@ def main():
                     pass
                 per = ms / reps
                 out.append(f"{name} {per:7.3f} ms {gb / per:6.2f} TB/s")
+            if N * K <= 2.5e8:  # log W (16 K N bytes of HBM traffic + a K N download): only where the host copy is small
+                dm.timing_reset()
+                dm.logw_kn(f)
+                ms, n = dm.timing()["other"]
+                out.append(f"logw kernel {ms:7.3f} ms {2 * gb / ms:6.2f} TB/s")
             print(f"K={K:4d} N={N:9d}: " + " | ".join(out), flush=True)
 
 
