@@ -2518,28 +2518,32 @@ __device__ __forceinline__ double gram_elem(const double* __restrict__ g, int nb
     return g[(int64_t)b * 256 + (ki & 15) * 16 + (kj & 15)];
 }
 
-// Newton direction + both candidates, ONE workgroup of T x T threads (T = 8, 16, 32: up to 31 / 63 / 127 unknowns).
+// Newton direction + both candidates, ONE workgroup of T x T threads with an R x R tile each (up to R T - 1 unknowns:
+// 8 x 8 threads x 4 x 4 -> 31, 16 x 16 x 4 x 4 -> 63, 16 x 16 x 8 x 8 -> 127).
 //   H = diag(psum) - G on the sampled states, g = psum - N_k (:581, :284-292); gauge x[first] = 0, so the system is the
 //   (m-1) x (m-1) SPD block of H -- the same vector as lstsq(H, g) minus its first component (:582-583).
-// The augmented matrix [A | b] lives in REGISTERS, a 4 x 4 tile per thread in a CYCLIC layout (thread (ty, tx): rows
-// ty + T r, columns tx + T c; column 4T-1 holds b).  Gauss-Jordan without pivoting (A is SPD; the pivots are the
+// The augmented matrix [A | b] lives in REGISTERS, an R x R tile per thread in a CYCLIC layout (thread (ty, tx): rows
+// ty + T r, columns tx + T c; column R T - 1 holds b).  A step is a latency chain LDS write -> barrier -> LDS read -> rcp ->
+// FMA; few waves matter more than few FMAs per thread (127 unknowns: 4 waves with 8 x 8 tiles 80 us, 16 waves with 4 x 4
+// tiles 95 us).  Replacing the barrier by per-wave flag words in LDS, so that the next pivot column is published before the
+// rest of the tile is updated, was slower still (112 us: the polling loop costs more than the barrier).  Gauss-Jordan without pivoting (A is SPD; the pivots are the
 // squares of the Cholesky diagonal, so "pivot <= 0" is exactly the Cholesky breakdown test of the host path): step j
 // needs only column j, which its owners publish through a double-buffered LDS vector -- row j of the live block is the
-// same vector by symmetry -- so a step is one barrier, ~10 LDS reads and at most 16 FMAs per thread, and there are no
+// same vector by symmetry -- so a step is one barrier, 2 R + 1 LDS reads and at most R R FMAs per thread, and there are no
 // triangular solves: x_i = b_i / pivot_i at the end.  The whole kernel is bound by the fp64 issue rate of ONE compute
 // unit, so it is written for instruction count:
 //   * columns left of the pivot are never read again; they are left stale (whole tile columns c < j / T: skipped
 //     statically, the step loop is unrolled over j / T) or take garbage, and the pivots are kept in their own vector;
-//   * b_j travels in slot 4T-1 of the column vector (row 4T-1 is always padding: its multiplier is then garbage, which
+//   * b_j travels in slot R T - 1 of the column vector (row R T - 1 is always padding: its multiplier is then garbage, which
 //     only ever touches that row), so the b column needs no special case;
 //   * the pivot row is excluded by zeroing ONE multiplier under a compare, not by a select per row.
 // A non-positive pivot, candidates more than 300 kT apart (the fused two-candidate sweep shares one shift) or a
 // non-finite candidate hand the solve back to the host loop (CTL_DONE = 2).
 // Outputs: cand = (f_sci, f_nr), ratio = exp(aden_nr - aden_sci), aden = (aden_sci, ratio) for the sweep.
-template <int T>
+template <int T, int R>
 __global__ void __launch_bounds__(T * T)
 k_newton(AdaptArgs q) {
-    constexpr int NC = 4 * T, NT = T * T;
+    constexpr int NC = R * T, NT = T * T;
     __shared__ double colbuf[2][NC];
     __shared__ double pv[NC], rh[NC], xs[NC + 1];
     __shared__ double s_f[128], s_ps[128], s_nk[128], s_ln[128];  // per-state vectors (Kp <= 128)
@@ -2563,28 +2567,28 @@ k_newton(AdaptArgs q) {
     __syncthreads();
     for (int i = tid; i < q.m; i += NT) pos[smp[i]] = i;
 
-    int ki[4], kj[4];
+    int ki[R], kj[R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int i = ty + T * r, k = tx + T * r;
         ki[r] = i < M ? smp[i + 1] : 0;
         kj[r] = k < M ? smp[k + 1] : 0;
     }
-    double A[4][4];
+    double A[R][R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)  // 16 independent loads (always a valid address; masked below)
+    for (int r = 0; r < R; ++r)  // R x R independent loads (always a valid address; masked below)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) A[r][c] = -gram_elem(q.gram_red, nb, ki[r], kj[c]);
+        for (int c = 0; c < R; ++c) A[r][c] = -gram_elem(q.gram_red, nb, ki[r], kj[c]);
     if (q.pmode) {  // the P-mode Gram sweep leaves the two per-state factors exp(a - a0) to be applied here
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) A[r][c] *= s_cc[ki[r]] * s_cc[kj[c]];
+            for (int c = 0; c < R; ++c) A[r][c] *= s_cc[ki[r]] * s_cc[kj[c]];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < R; ++c) {
             const int i = ty + T * r, k = tx + T * c;
             double v = A[r][c];
             if (i < M) {
@@ -2606,37 +2610,37 @@ k_newton(AdaptArgs q) {
     const double piv_thr = pmax * 2.220446049250313e-16 * (double)(M > 0 ? M : 1);
     bool bad = false;
 #pragma unroll
-    for (int jc = 0; jc < 4; ++jc) {
+    for (int jc = 0; jc < R; ++jc) {
         const int jend = M < T * (jc + 1) ? M : T * (jc + 1);
         for (int j = T * jc; j < jend; ++j) {
             const int jt = j - T * jc;
             double* cb = colbuf[j & 1];
             if (tx == jt) {  // owners of column j
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < 3 || ty != T - 1) cb[ty + T * r] = A[r][jc];  // (slot NC-1 belongs to b_j)
+                for (int r = 0; r < R; ++r)
+                    if (r < R - 1 || ty != T - 1) cb[ty + T * r] = A[r][jc];  // (slot NC-1 belongs to b_j)
             }
-            if (ty == jt && tx == T - 1) cb[NC - 1] = A[jc][3];  // b_j
+            if (ty == jt && tx == T - 1) cb[NC - 1] = A[jc][R - 1];  // b_j
             __syncthreads();
             const double piv = cb[j];
             if (tid == 0) pv[j] = piv;
             if (!(piv > piv_thr) || !isfinite(piv)) bad = true;  // the same value in every thread
             const double inv = recip_fast(piv);
-            double mr[4];
+            double mr[R];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mr[r] = cb[ty + T * r] * inv;
+            for (int r = 0; r < R; ++r) mr[r] = cb[ty + T * r] * inv;
             if (ty == jt) mr[jc] = 0.0;  // the pivot row itself
 #pragma unroll
-            for (int c = jc; c < 4; ++c) {
+            for (int c = jc; c < R; ++c) {
                 const double rv = cb[tx + T * c];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) A[r][c] = fma(-mr[r], rv, A[r][c]);
+                for (int r = 0; r < R; ++r) A[r][c] = fma(-mr[r], rv, A[r][c]);
             }
         }
     }
     if (tx == T - 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rh[ty + T * r] = A[r][3];
+        for (int r = 0; r < R; ++r) rh[ty + T * r] = A[r][R - 1];
     }
     __syncthreads();
     if (tid == 0) xs[0] = 0.0;
@@ -3314,11 +3318,11 @@ hipError_t launch_newton(hipStream_t s, const AdaptArgs& a) {
     const int M = a.m - 1;
     if (M > 127 || a.Kp > 128) return hipErrorInvalidValue;
     if (M <= 31)
-        hipLaunchKernelGGL(k_newton<8>, dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_newton<8, 4>), dim3(1), dim3(64), 0, s, a);
     else if (M <= 63)
-        hipLaunchKernelGGL(k_newton<16>, dim3(1), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_newton<16, 4>), dim3(1), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(k_newton<32>, dim3(1), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL((k_newton<16, 8>), dim3(1), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
