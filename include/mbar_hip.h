@@ -65,6 +65,10 @@ int mbar_device_info(int device, char* name, int name_len, int* compute_units, i
 int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local);
 void mbar_ctx_destroy(mbar_ctx* ctx);
 int mbar_ctx_synchronize(mbar_ctx* ctx);
+/* Device and pinned-host blocks freed by contexts are kept for re-use (hipMalloc / hipFree cost more than a sweep at the
+ * sizes pymbar is typically run at); bounded by MBAR_CACHE_MB (environment, default 2048; 0 = off).  This returns every
+ * parked block to the driver. */
+int mbar_cache_trim(void);
 /* hipDeviceSynchronize on `device` (every stream of every context): the bracket of a timed region. */
 int mbar_device_synchronize(int device);
 /* Tuning / test knobs (defaults are the measured best; every variant is parity-tested):

@@ -58,6 +58,7 @@ SIGNATURES = {
     "mbar_ctx_destroy": (None, [_ctx]),
     "mbar_ctx_synchronize": (C.c_int, [_ctx]),
     "mbar_device_synchronize": (C.c_int, [C.c_int]),
+    "mbar_cache_trim": (C.c_int, []),
     "mbar_ctx_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int64]),
     "mbar_ctx_upload_u": (C.c_int, [_ctx, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "mbar_ctx_download_u": (C.c_int, [_ctx, _dp, C.c_int64]),

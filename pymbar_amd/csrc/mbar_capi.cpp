@@ -18,7 +18,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace mbar;
@@ -58,6 +61,123 @@ struct RcclApi {
     }
 };
 RcclApi g_rccl;
+
+// ---- caching allocator ----------------------------------------------------------------------------------------------
+// hipMalloc / hipFree / hipHostMalloc cost 0.1 - 1 ms each (hipFree also synchronises the device): a context makes ~15
+// allocations, and pymbar's real workloads (K ~ 40, N ~ 1e5: sweeps of ~10 us) build and drop contexts all the time -- the
+// MBAR object, one augmented matrix per expectation call, one temporary per module-level function call.  Freed blocks are
+// therefore kept (per device, bounded: MBAR_CACHE_MB, default 2048 MB of device memory and 64 MB of pinned host memory;
+// bigger blocks go straight back to the driver) and handed out again to requests of about the same size.  Every API
+// call of this library leaves its stream idle before it frees anything, so a cached block has no work in flight.
+struct MemCache {
+    struct Pool {
+        std::multimap<size_t, void*> free_blocks;
+        size_t cached = 0, limit = 0;
+    };
+    std::mutex mu;
+    std::map<int, Pool> dev;                       // device ordinal -> pool
+    Pool pinned;
+    std::unordered_map<void*, std::pair<size_t, int>> live;  // every block handed out: size, device (-1 = pinned host)
+    bool configured = false;
+    void configure() {
+        if (configured) return;
+        configured = true;
+        size_t mb = 2048;
+        if (const char* e = std::getenv("MBAR_CACHE_MB")) mb = (size_t)std::strtoull(e, nullptr, 10);
+        dev_limit = mb << 20;
+        pinned.limit = std::min<size_t>(dev_limit, (size_t)64 << 20);
+    }
+    size_t dev_limit = 0;
+    static size_t round_up(size_t b) { return (b + 4095) / 4096 * 4096; }
+    static void* take(Pool& p, size_t want) {
+        auto it = p.free_blocks.lower_bound(want);
+        if (it == p.free_blocks.end() || it->first > want + want / 4 + 65536) return nullptr;  // (no big block for a small request)
+        void* q = it->second;
+        p.cached -= it->first;
+        p.free_blocks.erase(it);
+        return q;
+    }
+    hipError_t alloc(void** out, size_t bytes, bool host) {
+        std::lock_guard<std::mutex> lock(mu);
+        configure();
+        const size_t want = round_up(bytes ? bytes : 1);
+        int d = -1;
+        if (!host) {
+            hipError_t e = hipGetDevice(&d);
+            if (e != hipSuccess) return e;
+        }
+        Pool& p = host ? pinned : dev[d];
+        if (!host) p.limit = dev_limit;
+        size_t got = want;
+        void* q = take(p, want);
+        if (q) {
+            got = live[q].first;
+        } else {
+            hipError_t e = host ? hipHostMalloc(&q, want, hipHostMallocDefault) : hipMalloc(&q, want);
+            if (e != hipSuccess && !p.free_blocks.empty()) {  // out of memory with blocks parked here: give them back, retry
+                (void)hipGetLastError();
+                for (auto& kv : p.free_blocks) {
+                    live.erase(kv.second);
+                    if (host) (void)hipHostFree(kv.second); else (void)hipFree(kv.second);
+                }
+                p.free_blocks.clear();
+                p.cached = 0;
+                e = host ? hipHostMalloc(&q, want, hipHostMallocDefault) : hipMalloc(&q, want);
+            }
+            if (e != hipSuccess) return e;
+            live[q] = {want, d};
+        }
+        (void)got;
+        *out = q;
+        return hipSuccess;
+    }
+    hipError_t release(void* q) {
+        if (!q) return hipSuccess;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = live.find(q);
+        if (it == live.end()) return hipErrorInvalidValue;
+        const size_t sz = it->second.first;
+        const int d = it->second.second;
+        Pool& p = d < 0 ? pinned : dev[d];
+        if (p.cached + sz <= p.limit && sz <= p.limit / 2) {
+            p.free_blocks.emplace(sz, q);
+            p.cached += sz;
+            return hipSuccess;
+        }
+        live.erase(it);
+        return d < 0 ? hipHostFree(q) : hipFree(q);
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& dp : dev) {
+            for (auto& kv : dp.second.free_blocks) {
+                live.erase(kv.second);
+                (void)hipSetDevice(dp.first);
+                (void)hipFree(kv.second);
+            }
+            dp.second.free_blocks.clear();
+            dp.second.cached = 0;
+        }
+        for (auto& kv : pinned.free_blocks) {
+            live.erase(kv.second);
+            (void)hipHostFree(kv.second);
+        }
+        pinned.free_blocks.clear();
+        pinned.cached = 0;
+    }
+};
+MemCache g_mem;
+struct DevInfo {
+    int num_cu = 256;
+    std::string arch;
+};
+std::mutex g_dev_mu;
+std::map<int, DevInfo> g_dev_info;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;
+inline hipError_t cache_malloc(void** p, size_t bytes) { return g_mem.alloc(p, bytes, false); }
+inline hipError_t cache_free(void* p) { return g_mem.release(p); }
+inline hipError_t cache_host_malloc(void** p, size_t bytes) { return g_mem.alloc(p, bytes, true); }
+inline hipError_t cache_host_free(void* p) { return g_mem.release(p); }
 
 struct TimerPair {
     hipEvent_t a, b;
@@ -219,10 +339,10 @@ int ensure(mbar_ctx* c, double** p, size_t* have, size_t want) {
         int rc = drop_graphs(c);
         if (rc) return rc;
     }
-    if (*p) HIPCHK(c, hipFree(*p));
+    if (*p) HIPCHK(c, cache_free(*p));
     *p = nullptr;
     *have = 0;
-    HIPCHK(c, hipMalloc((void**)p, want * sizeof(double)));
+    HIPCHK(c, cache_malloc((void**)p, want * sizeof(double)));
     *have = want;
     return MBAR_OK;
 }
@@ -533,13 +653,13 @@ int ensure_red(mbar_ctx* c, size_t want) {
         int rc = drop_graphs(c);
         if (rc) return rc;
     }
-    if (c->red) HIPCHK(c, hipFree(c->red));
-    if (c->hred) HIPCHK(c, hipHostFree(c->hred));
+    if (c->red) HIPCHK(c, cache_free(c->red));
+    if (c->hred) HIPCHK(c, cache_host_free(c->hred));
     c->red = nullptr;
     c->hred = nullptr;
     c->red_doubles = 0;
-    HIPCHK(c, hipMalloc((void**)&c->red, want * sizeof(double)));
-    HIPCHK(c, hipHostMalloc((void**)&c->hred, want * sizeof(double), hipHostMallocDefault));
+    HIPCHK(c, cache_malloc((void**)&c->red, want * sizeof(double)));
+    HIPCHK(c, cache_host_malloc((void**)&c->hred, want * sizeof(double)));
     c->red_doubles = want;
     return MBAR_OK;
 }
@@ -934,13 +1054,13 @@ int ensure_ad(mbar_ctx* c, int64_t hist_rows) {
     if (!c->ad || c->ad_hist_cap < cap) {
         int rc = drop_graphs(c);
         if (rc) return rc;
-        if (c->ad) HIPCHK(c, hipFree(c->ad));
+        if (c->ad) HIPCHK(c, cache_free(c->ad));
         c->ad = nullptr;
-        HIPCHK(c, hipMalloc((void**)&c->ad, (ad_off_hist(c) + (size_t)4 * cap) * sizeof(double)));
+        HIPCHK(c, cache_malloc((void**)&c->ad, (ad_off_hist(c) + (size_t)4 * cap) * sizeof(double)));
         c->ad_hist_cap = cap;
     }
-    if (!c->ad_ints) HIPCHK(c, hipMalloc((void**)&c->ad_ints, (size_t)(CTL_WORDS + c->Kp) * sizeof(int)));
-    if (!c->h_ctl) HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, (size_t)CTL_WORDS * sizeof(int), hipHostMallocDefault));
+    if (!c->ad_ints) HIPCHK(c, cache_malloc((void**)&c->ad_ints, (size_t)(CTL_WORDS + c->Kp) * sizeof(int)));
+    if (!c->h_ctl) HIPCHK(c, cache_host_malloc((void**)&c->h_ctl, (size_t)CTL_WORDS * sizeof(int)));
     return MBAR_OK;
 }
 
@@ -963,7 +1083,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     if (pmode && !c->P) {
         rc = drop_graphs(c);
         if (rc) return rc;
-        if (hipMalloc((void**)&c->P, (size_t)Kp * c->ld * sizeof(double)) != hipSuccess) {
+        if (cache_malloc((void**)&c->P, (size_t)Kp * c->ld * sizeof(double)) != hipSuccess) {
             (void)hipGetLastError();
             c->P = nullptr;
             c->P_failed = true;
@@ -972,7 +1092,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             HIPCHK(c, hipMemsetAsync(c->P, 0, (size_t)Kp * c->ld * sizeof(double), c->stream));
         }
     }
-    if (pmode && !c->pm_vec) HIPCHK(c, hipMalloc((void**)&c->pm_vec, (size_t)3 * Kp * sizeof(double)));
+    if (pmode && !c->pm_vec) HIPCHK(c, cache_malloc((void**)&c->pm_vec, (size_t)3 * Kp * sizeof(double)));
     const bool fused = pmode && c->opt_fused;
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
@@ -1316,32 +1436,51 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
         }                                                                                           \
     } while (0)
     CRT(hipSetDevice(device));
-    hipDeviceProp_t p;
-    CRT(hipGetDeviceProperties(&p, device));
-    c->num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
-        int rc = fail(nullptr, MBAR_ERR_NODEVICE, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+    // (hipGetDeviceProperties and stream creation cost milliseconds: properties are looked up once per device, streams of
+    // destroyed contexts are kept for the next one)
+    DevInfo di;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        auto it = g_dev_info.find(device);
+        if (it == g_dev_info.end()) {
+            hipDeviceProp_t p;
+            CRT(hipGetDeviceProperties(&p, device));
+            di.num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+            di.arch = p.gcnArchName;
+            g_dev_info[device] = di;
+        } else {
+            di = it->second;
+        }
+        auto& pool = g_stream_pool[device];
+        if (!pool.empty()) {
+            c->stream = pool.back();
+            pool.pop_back();
+        }
+    }
+    c->num_cu = di.num_cu;
+    if (std::strncmp(di.arch.c_str(), "gfx950", 6) != 0) {
+        int rc = fail(nullptr, MBAR_ERR_NODEVICE, std::string("device is ") + di.arch + ", this library is built for gfx950 only");
         mbar_ctx_destroy(c);
         return rc;
     }
-    CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (!c->stream) CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t ubytes = (size_t)c->Kp * c->ld * sizeof(double);
-    CRT(hipMalloc((void**)&c->u, ubytes));
+    CRT(cache_malloc((void**)&c->u, ubytes));
     CRT(hipMemsetAsync(c->u, 0, ubytes, c->stream));
     // three logden vectors in ONE allocation: the device-resident loop addresses them as base + slot * ld
-    CRT(hipMalloc((void**)&c->logden[0], (size_t)3 * c->ld * sizeof(double)));
+    CRT(cache_malloc((void**)&c->logden[0], (size_t)3 * c->ld * sizeof(double)));
     CRT(hipMemsetAsync(c->logden[0], 0, (size_t)3 * c->ld * sizeof(double), c->stream));
     c->logden[1] = c->logden[0] + c->ld;
     c->logden[2] = c->logden[0] + 2 * c->ld;
-    CRT(hipMalloc((void**)&c->cw, (size_t)c->ld * sizeof(double)));
+    CRT(cache_malloc((void**)&c->cw, (size_t)c->ld * sizeof(double)));
     CRT(hipMemsetAsync(c->cw, 0, (size_t)c->ld * sizeof(double), c->stream));
     {
         std::vector<double> ones((size_t)c->N, 1.0);
         CRT(hipMemcpyAsync(c->cw, ones.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
         CRT(hipStreamSynchronize(c->stream));
     }
-    CRT(hipMalloc((void**)&c->small, small_doubles(c->Kp) * sizeof(double)));
-    CRT(hipHostMalloc((void**)&c->hstage, (size_t)4 * c->Kp * sizeof(double), hipHostMallocDefault));
+    CRT(cache_malloc((void**)&c->small, small_doubles(c->Kp) * sizeof(double)));
+    CRT(cache_host_malloc((void**)&c->hstage, (size_t)4 * c->Kp * sizeof(double)));
     CRT(hipMemsetAsync(c->small, 0, small_doubles(c->Kp) * sizeof(double), c->stream));
     CRT(hipStreamSynchronize(c->stream));
 #undef CRT
@@ -1358,30 +1497,37 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     flush_timers(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->u) (void)hipFree(c->u);
-    if (c->logden[0]) (void)hipFree(c->logden[0]);
-    if (c->ad) (void)hipFree(c->ad);
-    if (c->P) (void)hipFree(c->P);
-    if (c->pm_vec) (void)hipFree(c->pm_vec);
-    if (c->part_g) (void)hipFree(c->part_g);
-    if (c->cwsq) (void)hipFree(c->cwsq);
-    if (c->ad_ints) (void)hipFree(c->ad_ints);
-    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->u) (void)cache_free(c->u);
+    if (c->logden[0]) (void)cache_free(c->logden[0]);
+    if (c->ad) (void)cache_free(c->ad);
+    if (c->P) (void)cache_free(c->P);
+    if (c->pm_vec) (void)cache_free(c->pm_vec);
+    if (c->part_g) (void)cache_free(c->part_g);
+    if (c->cwsq) (void)cache_free(c->cwsq);
+    if (c->ad_ints) (void)cache_free(c->ad_ints);
+    if (c->h_ctl) (void)cache_host_free(c->h_ctl);
     if (c->ad_graph) (void)hipGraphExecDestroy(c->ad_graph);
-    if (c->dn) (void)hipFree(c->dn);
-    if (c->cw) (void)hipFree(c->cw);
-    if (c->lden_eff) (void)hipFree(c->lden_eff);
-    if (c->small) (void)hipFree(c->small);
-    if (c->part) (void)hipFree(c->part);
-    if (c->scratch) (void)hipFree(c->scratch);
-    if (c->red) (void)hipFree(c->red);
-    if (c->hred) (void)hipHostFree(c->hred);
-    if (c->lognum_part) (void)hipFree(c->lognum_part);
-    if (c->f_hist) (void)hipFree(c->f_hist);
-    if (c->hstage) (void)hipHostFree(c->hstage);
-    if (c->vec_tmp) (void)hipFree(c->vec_tmp);
+    if (c->dn) (void)cache_free(c->dn);
+    if (c->cw) (void)cache_free(c->cw);
+    if (c->lden_eff) (void)cache_free(c->lden_eff);
+    if (c->small) (void)cache_free(c->small);
+    if (c->part) (void)cache_free(c->part);
+    if (c->scratch) (void)cache_free(c->scratch);
+    if (c->red) (void)cache_free(c->red);
+    if (c->hred) (void)cache_host_free(c->hred);
+    if (c->lognum_part) (void)cache_free(c->lognum_part);
+    if (c->f_hist) (void)cache_free(c->f_hist);
+    if (c->hstage) (void)cache_host_free(c->hstage);
+    if (c->vec_tmp) (void)cache_free(c->vec_tmp);
     if (c->sci_graph) (void)hipGraphExecDestroy(c->sci_graph);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) {  // (idle: synchronised above) kept for the next context on this device
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        auto& pool = g_stream_pool[c->device];
+        if (pool.size() < 8)
+            pool.push_back(c->stream);
+        else
+            (void)hipStreamDestroy(c->stream);
+    }
     delete c;
 }
 
@@ -1389,6 +1535,11 @@ int mbar_ctx_synchronize(mbar_ctx* c) {
     if (!c) return fail(nullptr, MBAR_ERR_ARG, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return sync_stream(c);
+}
+
+int mbar_cache_trim(void) {
+    g_mem.trim();
+    return MBAR_OK;
 }
 
 int mbar_device_synchronize(int device) {
@@ -1466,7 +1617,7 @@ int mbar_ctx_row_sub(mbar_ctx* c, int64_t row, const double* v_host) {
     if (row < 0 || row >= c->K) return fail(c, MBAR_ERR_ARG, "row out of range");
     if (!v_host && !c->vec_tmp) return fail(c, MBAR_ERR_STATE, "mbar_ctx_row_sub: no vector has been uploaded yet");
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->vec_tmp) HIPCHK(c, hipMalloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
+    if (!c->vec_tmp) HIPCHK(c, cache_malloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
     double* tmp = c->vec_tmp;
     if (v_host)  // NULL: subtract the vector of the previous call again (one observable at many states)
         HIPCHK(c, hipMemcpyAsync(tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1480,14 +1631,14 @@ int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const do
     if (row0 < 0 || nrows < 0 || row0 + nrows > c->K) return fail(c, MBAR_ERR_ARG, "row range out of bounds");
     if (nrows == 0) return MBAR_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->vec_tmp) HIPCHK(c, hipMalloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
+    if (!c->vec_tmp) HIPCHK(c, cache_malloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
     int* dlabel = nullptr;
-    HIPCHK(c, hipMalloc((void**)&dlabel, (size_t)c->N * sizeof(int)));
+    HIPCHK(c, cache_malloc((void**)&dlabel, (size_t)c->N * sizeof(int)));
     hipError_t e = hipMemcpyAsync(c->vec_tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dlabel, label_host, (size_t)c->N * sizeof(int), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = launch_fill_masked_rows(c->stream, c->u + row0 * c->ld, c->ld, c->N, nrows, c->vec_tmp, dlabel);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(dlabel);
+    (void)cache_free(dlabel);
     if (e != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("mbar_ctx_fill_masked_rows: ") + hipGetErrorString(e));
     c->u_checked = false;
     flush_timers(c);
@@ -1562,13 +1713,13 @@ int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
         }
     }
     if (weighted && !c->lden_eff) {
-        HIPCHK(c, hipMalloc((void**)&c->lden_eff, (size_t)c->ld * sizeof(double)));
+        HIPCHK(c, cache_malloc((void**)&c->lden_eff, (size_t)c->ld * sizeof(double)));
         HIPCHK(c, hipMemsetAsync(c->lden_eff, 0, (size_t)c->ld * sizeof(double), c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->cw, w.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (weighted) {  // sqrt(c_n) for the MFMA operands of the fused sweep (plain 0 / 1 weights are their own square roots)
         if (!c->cwsq) {
-            HIPCHK(c, hipMalloc((void**)&c->cwsq, (size_t)c->ld * sizeof(double)));
+            HIPCHK(c, cache_malloc((void**)&c->cwsq, (size_t)c->ld * sizeof(double)));
             HIPCHK(c, hipMemsetAsync(c->cwsq, 0, (size_t)c->ld * sizeof(double), c->stream));
         }
         for (int64_t n = 0; n < c->N; ++n) w[n] = std::sqrt(w[n]);
@@ -1651,13 +1802,13 @@ int mbar_ctx_set_objective_offset(mbar_ctx* c, const double* f0) {
     if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
     if (!f0) {
-        if (c->dn) HIPCHK(c, hipFree(c->dn));
+        if (c->dn) HIPCHK(c, cache_free(c->dn));
         c->dn = nullptr;
         return MBAR_OK;
     }
     double* tmp = nullptr;
     if (!c->dn) {
-        HIPCHK(c, hipMalloc((void**)&tmp, (size_t)c->ld * sizeof(double)));
+        HIPCHK(c, cache_malloc((void**)&tmp, (size_t)c->ld * sizeof(double)));
         HIPCHK(c, hipMemsetAsync(tmp, 0, (size_t)c->ld * sizeof(double), c->stream));
     } else {
         tmp = c->dn;
@@ -1744,23 +1895,23 @@ int mbar_logw(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out) {
     // stream the result through a device staging buffer in row blocks to bound extra memory
     const int64_t rows_per = std::max<int64_t>(1, std::min<int64_t>(c->K, (int64_t)((256ull << 20) / ((size_t)c->ld * 8))));
     double* stage = nullptr;
-    HIPCHK(c, hipMalloc((void**)&stage, (size_t)rows_per * c->ld * sizeof(double)));
+    HIPCHK(c, cache_malloc((void**)&stage, (size_t)rows_per * c->ld * sizeof(double)));
     HIPCHK(c, hipMemcpyAsync(d_f(c), f, c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
     for (int64_t k0 = 0; k0 < c->K; k0 += rows_per) {
         const int64_t nr = std::min(rows_per, c->K - k0);
         {
             ScopedTimer t(c, MBAR_TIMER_OTHER);
             hipError_t e = launch_logw(c->stream, c->u + k0 * c->ld, c->ld, c->N, nr, d_f(c) + k0, c->logden[0], stage, c->ld);
-            if (e != hipSuccess) { (void)hipFree(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
+            if (e != hipSuccess) { (void)cache_free(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
         }
         hipError_t e = hipMemcpy2DAsync(out_kn + k0 * ld_out, (size_t)ld_out * sizeof(double), stage,
                                         (size_t)c->ld * sizeof(double), (size_t)c->N * sizeof(double), (size_t)nr,
                                         hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { (void)hipFree(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)cache_free(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
     }
     flush_timers(c);
-    HIPCHK(c, hipFree(stage));
+    HIPCHK(c, cache_free(stage));
     return MBAR_OK;
 }
 
@@ -1885,7 +2036,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     }
     const int64_t rows = lse_rows(c);
     const int64_t batch = c->opt_sci_batch;
-    if (!c->f_hist) HIPCHK(c, hipMalloc((void**)&c->f_hist, (size_t)256 * Kp * sizeof(double)));
+    if (!c->f_hist) HIPCHK(c, cache_malloc((void**)&c->f_hist, (size_t)256 * Kp * sizeof(double)));
     int rc = ensure_red(c, (size_t)rows + 8);
     if (rc) return rc;
     // initial f and aden on the device
