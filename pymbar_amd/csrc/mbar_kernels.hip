@@ -45,6 +45,13 @@ __device__ __forceinline__ double row16_max(double x) {
     x = fmax(x, dpp_move<0x140>(x));
     return x;
 }
+// Lane N of every 16-lane row to all lanes of that row (gfx90a+: the one DPP control 64-bit moves accept).
+template <int N>
+__device__ __forceinline__ double row16_bcast(double x) {
+    double r;
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(N));
+    return r;
+}
 __device__ __forceinline__ double row16_sum(double x) {
     x += dpp_move<0xB1>(x);
     x += dpp_move<0x4E>(x);
@@ -2316,14 +2323,36 @@ k_psweep(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, co
 // ---------------------------------------------------------------------------------------------
 // Fused sweep of the device-resident loop in P mode: ONE pass over the resident probability matrix per iteration.
 // For the two candidates (multipliers cmul[0] = f_sci, cmul[1] = f_nr relative to the anchor) it does what k_psweep does --
-// normalisers 1 / s_n into the slot vectors, per-state sums -- and, from the SAME tile in registers, accumulates the Gram
+// normalisers 1 / s_n into the slot vectors, per-state sums -- and, from the SAME tile in LDS, accumulates the Gram
 // matrix of the Newton-Raphson candidate on the matrix cores, G'_nr = sum_n (P_n / s_n^nr)(P_n / s_n^nr)^T.  If the loop
 // then accepts f_nr (it nearly always does: mbar_solvers.py:607) the next iteration's Hessian is already there and the
-// separate Gram sweep is skipped; otherwise that sweep runs (k_select decides, CTL_NEEDGRAM).  Without exponentials the
-// sweep's VALU work is small next to the 9216 MFMA cycles per tile, so the fusion costs ~15 % over the bare Gram
-// sweep and saves the second pass over HBM.  (Round 1 tried the same with per-sweep exponentials: no gain, the pipe
-// was full.)  wsq: sqrt of the per-sample multiplicities (= cw itself for plain 0 / 1 weights).
+// separate Gram sweep is skipped; otherwise that sweep runs (k_select decides, CTL_NEEDGRAM).
+// One wave per SIMD owns the register file (288 accumulator registers), so nothing hides behind another wave: every
+// instruction that is not under an executing matrix instruction costs its issue slot, fp64 VALU work shares the matrix pipe,
+// and an LDS-DMA instruction stalls the wave for tens of cycles.  The tile loop is therefore laid out by hand
+// (profiles/r2_fused_sweep_anatomy.txt):
+//   * the normalisers are 4x4x4 matrix instructions on a second read of the tile (32 x 16 cycles instead of 64 FMAs,
+//     128 DPP moves, 32 adds and eight reciprocals), computed one tile AHEAD between the Gram blocks of groups 2 and 3;
+//   * Gram operands are fetched one group ahead, the multiplier operands in two batches, all behind issued matrix work;
+//   * the tile after next is requested piece by piece between the Gram blocks of group 3 (the buffer is free then);
+//   * the 8 NB per-state accumulations stay where they are written (the compiler would sink them to the loop end and keep
+//     all four groups' operands alive), and the loop body is ONE basic block (the register allocator handles the pinned
+//     accumulators only then).
+// wsq: sqrt of the per-sample multiplicities (= cw itself for plain 0 / 1 weights).
 // ---------------------------------------------------------------------------------------------
+// Schedule of the 2 NB 4x4x4 steps a group carries (k_fused): how many have been issued once row I of the group's Gram blocks
+// is out.  Narrow panels: two per row, the rest after the last-but-one row.  NB >= 4: the first NB (one operand batch) two per
+// row, the second batch spread over the rows that remain before the last.
+template <int NB>
+__host__ __device__ constexpr int fused_steps_done(int I) {
+    if (I < 0) return 0;
+    if (I >= NB - 2) return 2 * NB;
+    if (NB < 4) return 2 * (I + 1) < 2 * NB ? 2 * (I + 1) : 2 * NB;
+    const int r1 = (NB + 1) / 2 - 1;  // row that completes the first batch
+    if (I <= r1) return 2 * (I + 1) < NB ? 2 * (I + 1) : NB;
+    const int rows = NB - 2 - r1;     // rows r1 + 1 .. NB - 2 share the second batch
+    return NB + (NB * (I - r1) + rows - 1) / rows;
+}
 template <int NB, bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cmul,
@@ -2353,18 +2382,26 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
     const RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
-    double c[2][NB], acc[2][NB];
+    double acc[2][NB];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int I = 0; I < NB; ++I) {
-            c[f][I] = cmul[f * ROWS + 16 * I + ks];
-            acc[f][I] = 0.0;
-        }
+        for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
+    // The normalisers s_n = sum_k P_kn c_k of both candidates come from the matrix pipe as well: v_mfma_f64_4x4x4_4b
+    // contracts over lane bits 4-5 (measured lane map, profiles/r2_mfma4x4_probe.txt: A lane = i + 4 b + 16 k, B lane =
+    // j + 4 b + 16 k, D lane = j + 4 b + 16 i), so with the tile read a SECOND time as A(sample = lane & 15, state = 4 step +
+    // (lane >> 4)) and the multipliers as B(candidate = lane & 3, same state) 32 instructions of 16 cycles leave
+    // s[sample (lane >> 4) + 4 ((lane >> 2) & 3)][candidate lane & 3] in one register -- in place of 64 FMAs, 128 DPP moves,
+    // 32 adds and eight reciprocals.  The multiplier operand is a 4 KB table behind the wave buffers.
+    constexpr int NSTEP = ROWS / 4;
+    {
+        double* ctab = reinterpret_cast<double*>(smem + nwv * (2 * TILE_BYTES));
+        for (int e = threadIdx.x; e < NSTEP * 16; e += blockDim.x) ctab[e] = (e & 3) < 2 ? cmul[(e & 3) * ROWS + (e >> 2)] : 0.0;
+        __syncthreads();
+    }
+    int apos[4];  // second-layout read: row 4 step + k holds sample n at position (n + (row & 14)) & 15
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int I = 0; I < NB; ++I) settle(c[f][I]);
+    for (int q = 0; q < 4; ++q) apos[q] = ns * (TS * 8) + (((lane & 15) + (ns & 2) + 4 * q) & 15) * 8;
     v4d G[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) G[b] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -2373,76 +2410,149 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
     int pos[GROUPS];
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
-    const int gq = ks & 3;            // this lane keeps the reciprocal of sample 4 gq + ns for the store
-    const int fq = (ks & 4) ? 1 : 0;  // ... of candidate fq (lanes ks < 8 store)
+    const int sq = ns + 4 * ((lane >> 2) & 3);  // the lane's sample and candidate in the layout the 4x4x4 blocks leave
+    const int fq = lane & 3;
 
     auto stage = [&](int64_t tile, char* dst) {
         stage_tile<ROWS, true, 0, 1>(P, ld, tile * TS, dst, lane, so, rows);
         stage_vec16<true>(cw, tile * TS, dst + U_BYTES, lane);
         stage_vec16<true>(wsq, tile * TS, dst + U_BYTES + TS * 8, lane);
     };
+    // operands of group g in the Gram layout (state 16 I + ks, sample 4 g + ns) + the sample's multiplicity and its root
+    auto read_group = [&](const char* tb, int g, double (&x)[NB], double& wg, double& swg) {
+        wg = *reinterpret_cast<const double*>(tb + U_BYTES + (4 * g + ns) * 8);
+        swg = *reinterpret_cast<const double*>(tb + U_BYTES + TS * 8 + (4 * g + ns) * 8);
+#pragma unroll
+        for (int I = 0; I < NB; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
+    };
+    uint32_t cop_off = (uint32_t)(nwv * (2 * TILE_BYTES) + (lane >> 4) * 32 + (lane & 3) * 8);
+    auto read_step = [&](const char* tb, int st, double& a, double& b) {
+        a = *reinterpret_cast<const double*>(tb + st * (4 * TS * 8) + apos[st & 3]);
+        b = *reinterpret_cast<const double*>(smem + cop_off + st * 128);
+    };
+    auto mfma4 = [&](double& d, double a, double b) {
+        if constexpr (PINNED)
+            asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+        else
+            d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, d, 0, 0, 0);
+    };
+    auto store_rinv = [&](int64_t tile, double r) {
+        // exactly ONE store instruction per tile and wave (sample 0 of every tile exists): the vmcnt bookkeeping needs it
+        const int64_t n = tile * TS + sq;
+        double* out = fq ? rinv1 : rinv0;
+        if (n < N && fq < 2) out[n] = r;
+    };
+    // Software pipeline over the wave's tiles t_0, t_1, ... (two LDS buffers): while the Gram blocks of tile t_i issue, the
+    // 4x4x4 blocks of tile t_{i+1}'s normalisers are slipped in between them (their LDS operands requested a row of blocks
+    // earlier), the Gram operands are fetched one group ahead, and tile t_{i+2} is requested into t_i's buffer as soon as
+    // its last group has been read -- no LDS round trip and no HBM latency is left exposed in the loop.
+    //   vmcnt, in issue order, at the top of iteration i: [tile t_{i+1}: NDMA] [store of tile t_i's reciprocals: 1]
     int64_t t = gw;
     int cur = 0;
-    if (t < ntiles) stage(t, buf);
-    for (; t < ntiles; t += W) {
-        char* cbuf = buf + cur * TILE_BYTES;
-        const int64_t tn = t + W;
-        if (tn < ntiles) {
-            stage(tn, buf + (cur ^ 1) * TILE_BYTES);
-            // vmcnt counts the reciprocal store too: [tile t][store of tile t - W][tile tn]
-            if (t != gw)
-                wait_vm<NDMA + 1>();
-            else
-                wait_vm<NDMA>();
+    double rcur = 0.0;
+    double uv[2][NB], w[2], sw[2];
+    if (t < ntiles) {
+        stage(t, buf);
+        if (t + W < ntiles) {
+            stage(t + W, buf + TILE_BYTES);
+            wait_vm<NDMA>();
         } else {
             wait_vm<0>();
         }
-        // every LDS operand of the tile is requested up front (one exposed LDS round trip per tile)
-        double w[GROUPS], sw[GROUPS], uv[GROUPS][NB];
+        double sa = 0.0, sb = 0.0;
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g) {
-            w[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
-            sw[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + TS * 8 + (4 * g + ns) * 8);
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-                uv[g][I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rd_base + pos[g]);
+        for (int st = 0; st < NSTEP; st += 2) {
+            double a0, b0, a1, b1;
+            read_step(buf, st, a0, b0);
+            read_step(buf, st + 1, a1, b1);
+            sa = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, sb, 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        double keep = 0.0;
-        // normalisers of all four groups and both candidates: in-lane FMA dot products, then the 16-lane reductions
-        double sv[2 * GROUPS];
+        // (a padded sample has an all-zero column: keep its reciprocal finite, its multiplicity is 0)
+        rcur = recip_fast(fmax(sa + sb, 1e-300));
+        store_rinv(t, rcur);
+        read_group(buf, 0, uv[0], w[0], sw[0]);
+    }
+#if defined(MBAR_EXPERIMENT_FUSED_WAITS)  // instrumented build (profiles/r2_fused_sweep_anatomy.txt): cycles per tile and in the waits
+    long long dbg_vm = 0, dbg_n = 0, dbg_b2 = 0;
+    const long long dbg_t0 = clock64();
+#endif
+    for (; t < ntiles; t += W) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+        const int64_t tn = t + W, tnn = t + 2 * W;
+        const int64_t tstage = tnn < ntiles ? tnn : t;
+        // (the multiplier table never changes: without this the compiler keeps all of it in 8 NB registers)
+        asm volatile("" : "+v"(cop_off));
+        // (four accumulators in rotation: the asm 4x4x4 blocks are invisible to the hazard recogniser, and a dependent one
+        // needs four wait states after its predecessor)
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            sv[2 * g] = dot_sum<NB>(uv[g], c[0]);
-            sv[2 * g + 1] = dot_sum<NB>(uv[g], c[1]);
-        }
-        // (the 16-lane sums stay on DPP: the same reduction batched through ds_swizzle -- off the VALU pipe, but four exposed
-        // LDS round trips per tile -- measured 2.5 % slower on the same box)
-#pragma unroll
-        for (int g = 0; g < GROUPS; ++g) row16_sum2(sv[2 * g], sv[2 * g + 1]);
-#pragma unroll
-        for (int g = 0; g < GROUPS; ++g) {
-            const double s0 = sv[2 * g], s1 = sv[2 * g + 1];
-            // (a padded sample has an all-zero column: keep its reciprocal finite, its multiplicity is 0)
-            const double r0 = recip_fast(fmax(s0, 1e-300)), r1 = recip_fast(fmax(s1, 1e-300));
-            const double q0 = w[g] * r0, q1 = w[g] * r1;
+            const int gc = g & 1, gn = gc ^ 1;
+#if defined(MBAR_EXPERIMENT_FUSED_WAITS)
+            if (g == 2) {
+                const long long c0 = clock64();
+                wait_vm<1>();
+                const long long c1 = clock64();
+                const long long c2 = clock64();
+                dbg_vm += (c1 - c0) - (c2 - c1);
+                dbg_n += 1;
+            }
+#else
+            if (g == 2) wait_vm<1>();  // tile t_{i+1}, requested three quarters of an iteration ago
+#endif
+            double r0, r1;
+            switch (g) {
+                case 0: r0 = row16_bcast<0>(rcur); r1 = row16_bcast<1>(rcur); break;
+                case 1: r0 = row16_bcast<4>(rcur); r1 = row16_bcast<5>(rcur); break;
+                case 2: r0 = row16_bcast<8>(rcur); r1 = row16_bcast<9>(rcur); break;
+                default: r0 = row16_bcast<12>(rcur); r1 = row16_bcast<13>(rcur); break;
+            }
+            const double q0 = w[gc] * r0, q1 = w[gc] * r1;
 #pragma unroll
             for (int I = 0; I < NB; ++I) {
-                acc[0][I] = fma(uv[g][I], q0, acc[0][I]);
-                acc[1][I] = fma(uv[g][I], q1, acc[1][I]);
+                acc[0][I] = fma(uv[gc][I], q0, acc[0][I]);
+                acc[1][I] = fma(uv[gc][I], q1, acc[1][I]);
+                // (pinned here: left alone, the compiler sinks all 8 NB updates to the end of the iteration and keeps
+                // the operands of all four groups alive for them)
+                settle(acc[0][I]);
+                settle(acc[1][I]);
             }
-            if (gq == g) keep = fq ? r1 : r0;
             const bool valid = (t * TS + 4 * g + ns) < N;
-            const double rin = valid ? r1 * sw[g] : 0.0;  // operand of the Newton-Raphson candidate's Gram matrix
+            const double rin = valid ? r1 * sw[gc] : 0.0;  // operand of the Newton-Raphson candidate's Gram matrix
             double p[NB];
 #pragma unroll
-            for (int I = 0; I < NB; ++I) p[I] = uv[g][I] * rin;
+            for (int I = 0; I < NB; ++I) p[I] = uv[gc][I] * rin;
+            // operands of the next group, and of the 4x4x4 steps this group carries (requested here, after the group's own
+            // VALU work, so that nothing waits for them before the first rows of blocks have issued)
+            if (g < GROUPS - 1) {
+                read_group(cbuf, g + 1, uv[gn], w[gn], sw[gn]);
+            } else {
+                // every read of this tile has been issued a group ago: its buffer can take the tile after next
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (no branch in the loop body -- the register allocator handles the 288 pinned accumulator registers
+                // only in a single block: past the end this tile is simply requested again and never looked at)
+                // The two weight vectors are requested here, the ROWS / 8 pieces of the tile between this group's Gram blocks:
+                // issuing an LDS-DMA instruction stalls the wave for tens of cycles, which the matrix pipe hides there.
+                stage_vec16<true>(cw, tstage * TS, cbuf + U_BYTES, lane);
+                stage_vec16<true>(wsq, tstage * TS, cbuf + U_BYTES + TS * 8, lane);
+                read_group(nbuf, 0, uv[gn], w[gn], sw[gn]);
+            }
+            // the next tile's normalisers ride on this tile's groups 2 and 3: 2 NB steps each, their operands fetched in
+            // two batches of NB (wide panels: registers) or at once
+            constexpr int B1 = NB >= 4 ? NB : 2 * NB;
+            double opa[B1], opb[B1];
+            if (g >= 2) {
+#pragma unroll
+                for (int q = 0; q < B1; ++q) read_step(nbuf, (g - 2) * 2 * NB + q, opa[q], opb[q]);
+            }
             auto mfma = [&](int b, double x, double y) {
                 if constexpr (PINNED) {
                     if (b < GRAM_AGPR_BLOCKS)
-                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(G[b]) : "v"(x), "v"(y));
+                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(G[b]) : "v"(x), "v"(y));
                     else
-                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(G[b]) : "v"(x), "v"(y));
+                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(G[b]) : "v"(x), "v"(y));
                 } else {
                     G[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, G[b], 0, 0, 0);
                 }
@@ -2453,19 +2563,60 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
             }
             int b = 0;
 #pragma unroll
-            for (int I = 0; I < NB; ++I)
+            for (int I = 0; I < NB; ++I) {
+                if (NB == 1 && g >= 2) {
+                    mfma4(sacc[2 * (g & 1)], opa[0], opb[0]);
+                    mfma4(sacc[2 * (g & 1) + 1], opa[1], opb[1]);
+                }
 #pragma unroll
-                for (int J = I; J < NB; ++J) mfma(b++, p[I], p[J]);
+                for (int J = I; J < NB; ++J) {
+                    mfma(b, p[I], p[J]);
+                    if (g == GROUPS - 1) {  // tile pieces [b PIECES / NBLK, (b + 1) PIECES / NBLK) of the tile after next
+                        constexpr int PIECES = ROWS / 8;
+#pragma unroll
+                        for (int j = b * PIECES / NBLK; j < (b + 1) * PIECES / NBLK; ++j) {
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                            stage_piece<true>(P + rows(8 * j) * ld + tstage * TS, so.off[j & 1], cbuf + j * 1024, lane);
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    ++b;
+                }
+                // 4x4x4 steps of the next tile after every row of blocks but the last (so that the accumulators are long
+                // complete when the VALU reads them): fused_steps_done(I) of the group's 2 NB steps are issued by row I
+                if (g >= 2 && NB > 1 && I < NB - 1) {
+#pragma unroll
+                    for (int q = fused_steps_done<NB>(I - 1); q < fused_steps_done<NB>(I); ++q)
+                        mfma4(sacc[q & 3], opa[q % B1], opb[q % B1]);
+                    if (B1 < 2 * NB && fused_steps_done<NB>(I - 1) < B1 && fused_steps_done<NB>(I) >= B1) {
+#pragma unroll
+                        for (int q = 0; q < B1; ++q) read_step(nbuf, (g - 2) * 2 * NB + B1 + q, opa[q], opb[q]);
+                    }
+#if defined(MBAR_EXPERIMENT_FUSED_WAITS)
+                    if (B1 < 2 * NB && fused_steps_done<NB>(I - 2) < B1 && fused_steps_done<NB>(I - 1) >= B1) {
+                        // (the point where the second batch is first used: time the wait for it)
+                        const long long c0 = clock64();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const long long c1 = clock64();
+                        const long long c2 = clock64();
+                        dbg_b2 += (c1 - c0) - (c2 - c1);
+                    }
+#endif
+                }
+            }
             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
         }
-        {
-            // exactly ONE store instruction per tile and wave (sample 0 of every tile exists): the vmcnt bookkeeping needs it
-            const int64_t n = t * TS + 4 * gq + ns;
-            double* out = fq ? rinv1 : rinv0;
-            if (n < N && ks < 8) out[n] = keep;
-        }
+        if constexpr (PINNED) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        rcur = recip_fast(fmax((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]), 1e-300));
+        store_rinv(tn, rcur);  // (past the last tile every lane is beyond N)
         cur ^= 1;
     }
+#if defined(MBAR_EXPERIMENT_FUSED_WAITS)
+    if (lane == 0 && (gw % 341) == 0)
+        printf("DBG wave %ld: tiles %lld total %lld cycles (%lld per tile), vm wait %lld per tile, batch-2 lgkm wait %lld per tile (2 per tile)\n",
+               (long)gw, dbg_n, clock64() - dbg_t0, (clock64() - dbg_t0) / (dbg_n ? dbg_n : 1), dbg_vm / (dbg_n ? dbg_n : 1),
+               dbg_b2 / (dbg_n ? dbg_n : 1));
+#endif
     if constexpr (PINNED) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -3429,7 +3580,7 @@ LaunchGeom fused_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_overr
     g.waves = 4;
     g.variant = 1;
     const size_t tile = (size_t)nb * 16 * TS * 8 + 2 * TS * 8;
-    g.lds_bytes = (size_t)4 * 2 * tile;
+    g.lds_bytes = (size_t)4 * 2 * tile + (size_t)nb * 512;  // + the candidates' multipliers as a 4x4x4 MFMA operand
     int64_t want = (ntiles + 3) / 4;
     int64_t cap = num_cu;
     if (nb <= 5) {  // narrow panels: few accumulators, several workgroups per CU (cf. gram_geometry)
