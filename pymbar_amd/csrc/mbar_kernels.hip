@@ -2367,9 +2367,9 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
         rinv0 = rinv0 + (int64_t)((s + 1) % 3) * slot_stride;
     }
     constexpr int ROWS = NB * 16;
-    constexpr int NDMA = ROWS / 8 + 2;            // tile rows + the two weight vectors
+    constexpr int NDMA = ROWS / 8 + 1;            // tile rows + one piece for the two weight vectors
     constexpr int U_BYTES = ROWS * TS * 8;
-    constexpr int TILE_BYTES = U_BYTES + 2 * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + 1024;    // (the weights' piece is a full-wave LDS-DMA too: no exec-masked branch)
     constexpr int NBLK = NB * (NB + 1) / 2;
     constexpr bool PINNED = NBLK > GRAM_AGPR_BLOCKS;
     const int lane = threadIdx.x & 63;
@@ -2413,10 +2413,15 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
     const int sq = ns + 4 * ((lane >> 2) & 3);  // the lane's sample and candidate in the layout the 4x4x4 blocks leave
     const int fq = lane & 3;
 
+    // multiplicities and their roots behind the tile: even 128-byte rows of the piece take cw, odd rows wsq (rows 2-7 repeat them)
+    const char* wsrc = reinterpret_cast<const char*>(((lane >> 3) & 1) ? wsq : cw) + (lane & 7) * 16;
+    auto stage_w = [&](int64_t tile, char* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + tile * (TS * 8)),
+                                         (__attribute__((address_space(3))) void*)(dst + U_BYTES), 16, 0, 0);
+    };
     auto stage = [&](int64_t tile, char* dst) {
         stage_tile<ROWS, true, 0, 1>(P, ld, tile * TS, dst, lane, so, rows);
-        stage_vec16<true>(cw, tile * TS, dst + U_BYTES, lane);
-        stage_vec16<true>(wsq, tile * TS, dst + U_BYTES + TS * 8, lane);
+        stage_w(tile, dst);
     };
     // operands of group g in the Gram layout (state 16 I + ks, sample 4 g + ns) + the sample's multiplicity and its root
     auto read_group = [&](const char* tb, int g, double (&x)[NB], double& wg, double& swg) {
@@ -2430,11 +2435,17 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
         a = *reinterpret_cast<const double*>(tb + st * (4 * TS * 8) + apos[st & 3]);
         b = *reinterpret_cast<const double*>(smem + cop_off + st * 128);
     };
-    auto mfma4 = [&](double& d, double a, double b) {
-        if constexpr (PINNED)
-            asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
-        else
-            d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, d, 0, 0, 0);
+    // (first: the accumulator starts from the inline constant 0 -- a register zeroed by a VALU move right in front of an asm
+    // matrix instruction, where the hazard recogniser cannot see it, gave wrong sums)
+    auto mfma4 = [&](double& d, double a, double b, bool first) {
+        if constexpr (PINNED) {
+            if (first)
+                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+            else
+                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+        } else {
+            d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, first ? 0.0 : d, 0, 0, 0);
+        }
     };
     auto store_rinv = [&](int64_t tile, double r) {
         // exactly ONE store instruction per tile and wave (sample 0 of every tile exists): the vmcnt bookkeeping needs it
@@ -2486,7 +2497,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
         asm volatile("" : "+v"(cop_off));
         // (four accumulators in rotation: the asm 4x4x4 blocks are invisible to the hazard recogniser, and a dependent one
         // needs four wait states after its predecessor)
-        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+        double sacc[4];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const int gc = g & 1, gn = gc ^ 1;
@@ -2519,33 +2530,36 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                 settle(acc[0][I]);
                 settle(acc[1][I]);
             }
-            const bool valid = (t * TS + 4 * g + ns) < N;
-            const double rin = valid ? r1 * sw[gc] : 0.0;  // operand of the Newton-Raphson candidate's Gram matrix
+            // (a padded sample needs no mask: its multiplicity and the root of it are stored as zeros)
+            const double rin = r1 * sw[gc];  // operand of the Newton-Raphson candidate's Gram matrix
             double p[NB];
 #pragma unroll
             for (int I = 0; I < NB; ++I) p[I] = uv[gc][I] * rin;
-            // operands of the next group, and of the 4x4x4 steps this group carries (requested here, after the group's own
-            // VALU work, so that nothing waits for them before the first rows of blocks have issued)
-            if (g < GROUPS - 1) {
-                read_group(cbuf, g + 1, uv[gn], w[gn], sw[gn]);
-            } else {
-                // every read of this tile has been issued a group ago: its buffer can take the tile after next
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // (no branch in the loop body -- the register allocator handles the 288 pinned accumulator registers
-                // only in a single block: past the end this tile is simply requested again and never looked at)
-                // The two weight vectors are requested here, the ROWS / 8 pieces of the tile between this group's Gram blocks:
-                // issuing an LDS-DMA instruction stalls the wave for tens of cycles, which the matrix pipe hides there.
-                stage_vec16<true>(cw, tstage * TS, cbuf + U_BYTES, lane);
-                stage_vec16<true>(wsq, tstage * TS, cbuf + U_BYTES + TS * 8, lane);
-                read_group(nbuf, 0, uv[gn], w[gn], sw[gn]);
-            }
-            // the next tile's normalisers ride on this tile's groups 2 and 3: 2 NB steps each, their operands fetched in
-            // two batches of NB (wide panels: registers) or at once
+            // Operands of the next group and of the 4x4x4 steps this group carries (the next tile's normalisers ride on this
+            // tile's groups 2 and 3: 2 NB steps each, their operands fetched in two batches of NB for wide panels), the weights'
+            // piece of the tile after next: with pinned accumulators these are issued BEHIND the group's first Gram blocks
+            // (request_next / request_steps below), otherwise here and the compiler places them.
             constexpr int B1 = NB >= 4 ? NB : 2 * NB;
             double opa[B1], opb[B1];
-            if (g >= 2) {
+            auto request_next = [&]() {
+                if (g < GROUPS - 1) {
+                    read_group(cbuf, g + 1, uv[gn], w[gn], sw[gn]);
+                } else {
+                    // (every read of this tile was issued a group ago and has been consumed: its buffer can take the tile
+                    // after next -- past the end this tile is simply requested again and never looked at, so that the loop
+                    // body stays ONE basic block: the register allocator handles the 288 pinned accumulator registers only then)
+                    read_group(nbuf, 0, uv[gn], w[gn], sw[gn]);
+                }
+            };
+            auto request_steps = [&]() {
+                if (g >= 2) {
 #pragma unroll
-                for (int q = 0; q < B1; ++q) read_step(nbuf, (g - 2) * 2 * NB + q, opa[q], opb[q]);
+                    for (int q = 0; q < B1; ++q) read_step(nbuf, (g - 2) * 2 * NB + q, opa[q], opb[q]);
+                }
+            };
+            if constexpr (!PINNED) {
+                request_next();
+                request_steps();
             }
             auto mfma = [&](int b, double x, double y) {
                 if constexpr (PINNED) {
@@ -2565,18 +2579,27 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
 #pragma unroll
             for (int I = 0; I < NB; ++I) {
                 if (NB == 1 && g >= 2) {
-                    mfma4(sacc[2 * (g & 1)], opa[0], opb[0]);
-                    mfma4(sacc[2 * (g & 1) + 1], opa[1], opb[1]);
+                    mfma4(sacc[2 * (g & 1)], opa[0], opb[0], true);
+                    mfma4(sacc[2 * (g & 1) + 1], opa[1], opb[1], true);
                 }
 #pragma unroll
                 for (int J = I; J < NB; ++J) {
                     mfma(b, p[I], p[J]);
-                    if (g == GROUPS - 1) {  // tile pieces [b PIECES / NBLK, (b + 1) PIECES / NBLK) of the tile after next
-                        constexpr int PIECES = ROWS / 8;
+                    if constexpr (PINNED) {
+                        if (b == 0 || b == 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (b == 0) request_next(); else request_steps();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (g == GROUPS - 1) {  // pieces [b NDMA / NBLK, (b + 1) NDMA / NBLK) of the tile after next; the last = weights
 #pragma unroll
-                        for (int j = b * PIECES / NBLK; j < (b + 1) * PIECES / NBLK; ++j) {
+                        for (int j = b * NDMA / NBLK; j < (b + 1) * NDMA / NBLK; ++j) {
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
-                            stage_piece<true>(P + rows(8 * j) * ld + tstage * TS, so.off[j & 1], cbuf + j * 1024, lane);
+                            if (j < ROWS / 8)
+                                stage_piece<true>(P + rows(8 * j) * ld + tstage * TS, so.off[j & 1], cbuf + j * 1024, lane);
+                            else
+                                stage_w(tstage, cbuf);
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -2587,7 +2610,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                 if (g >= 2 && NB > 1 && I < NB - 1) {
 #pragma unroll
                     for (int q = fused_steps_done<NB>(I - 1); q < fused_steps_done<NB>(I); ++q)
-                        mfma4(sacc[q & 3], opa[q % B1], opb[q % B1]);
+                        mfma4(sacc[q & 3], opa[q % B1], opb[q % B1], g == 2 && q < 4);
                     if (B1 < 2 * NB && fused_steps_done<NB>(I - 1) < B1 && fused_steps_done<NB>(I) >= B1) {
 #pragma unroll
                         for (int q = 0; q < B1; ++q) read_step(nbuf, (g - 2) * 2 * NB + B1 + q, opa[q], opb[q]);
@@ -2606,7 +2629,10 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
             }
             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (PINNED) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        // (the wait states between the last 4x4x4 block and the VALU reading its result; tied to the accumulators so that the
+        // scheduler cannot move the additions in front of it)
+        if constexpr (PINNED)
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]));
         rcur = recip_fast(fmax((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]), 1e-300));
         store_rinv(tn, rcur);  // (past the last tile every lane is beyond N)
         cur ^= 1;
@@ -3579,7 +3605,7 @@ LaunchGeom fused_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_overr
     LaunchGeom g;
     g.waves = 4;
     g.variant = 1;
-    const size_t tile = (size_t)nb * 16 * TS * 8 + 2 * TS * 8;
+    const size_t tile = (size_t)nb * 16 * TS * 8 + 1024;    // + one LDS-DMA piece for the two weight vectors
     g.lds_bytes = (size_t)4 * 2 * tile + (size_t)nb * 512;  // + the candidates' multipliers as a 4x4x4 MFMA operand
     int64_t want = (ntiles + 3) / 4;
     int64_t cap = num_cu;
@@ -3634,7 +3660,7 @@ LaunchGeom build_gram_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_
     // (same grid as the fused sweep, so that the partial-record counts agree; the kernel strides over tiles, so it does
     // not matter if the look-up tables leave room for one workgroup per CU less)
     LaunchGeom g = fused_geometry(nb, num_cu, ntiles, grid_override);
-    g.lds_bytes += EXP_TABLE_BYTES;
+    g.lds_bytes = (size_t)4 * 2 * ((size_t)nb * 16 * TS * 8 + 2 * TS * 8) + EXP_TABLE_BYTES;  // (its own tile layout + the tables)
     return g;
 }
 template <int NB>
