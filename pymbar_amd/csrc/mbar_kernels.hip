@@ -2340,6 +2340,12 @@ k_psweep(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, co
 //     accumulators only then).
 // wsq: sqrt of the per-sample multiplicities (= cw itself for plain 0 / 1 weights).
 // ---------------------------------------------------------------------------------------------
+// Experiment, off: the diagonal 16 x 16 blocks of the full panel as three v_mfma_f64_4x4x4_4b_f64 each (48 matrix-pipe cycles
+// instead of 64; parity-green) measured 1 % SLOWER than the 16x16x4 blocks on the same box
+// (profiles/r2_fused_sweep_anatomy.txt, section 5).
+#ifndef MBAR_FUSED_DIAG4
+#define MBAR_FUSED_DIAG4 0
+#endif
 // Schedule of the 2 NB 4x4x4 steps a group carries (k_fused): how many have been issued once row I of the group's Gram blocks
 // is out.  Narrow panels: two per row, the rest after the last-but-one row.  NB >= 4: the first NB (one operand batch) two per
 // row, the second batch spread over the rows that remain before the last.
@@ -2405,6 +2411,14 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
     v4d G[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) G[b] = v4d{0.0, 0.0, 0.0, 0.0};
+    // Diagonal blocks of the full panel as 4 x 4 sub-blocks: with A = B = the Gram operand, v_mfma_f64_4x4x4_4b_f64 gives the four
+    // sub-blocks (b, b) of a 16 x 16 block at once; with B rotated by 4 (8) lanes inside each 16-lane row the sub-blocks
+    // (b, b -+ 1) ((b, b + 2)): three instructions of 16 cycles cover the block (the wrapped sub-blocks are transposes of
+    // wanted ones) where the 16x16x4 instruction spends 64 cycles, half of them below the diagonal.
+    constexpr bool DIAG4 = PINNED && (MBAR_FUSED_DIAG4 != 0);
+    double Dg[DIAG4 ? NB : 1][3];
+#pragma unroll
+    for (int I = 0; I < (DIAG4 ? NB : 1); ++I) Dg[I][0] = Dg[I][1] = Dg[I][2] = 0.0;
 
     const int rd_base = ks * (TS * 8);
     int pos[GROUPS];
@@ -2563,7 +2577,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
             }
             auto mfma = [&](int b, double x, double y) {
                 if constexpr (PINNED) {
-                    if (b < GRAM_AGPR_BLOCKS)
+                    if (DIAG4 || b < GRAM_AGPR_BLOCKS)  // (without the diagonal blocks all 28 fit the AGPRs)
                         asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(G[b]) : "v"(x), "v"(y));
                     else
                         asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(G[b]) : "v"(x), "v"(y));
@@ -2571,30 +2585,60 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                     G[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, G[b], 0, 0, 0);
                 }
             };
+            // rotated copies of the diagonal operands, three in flight: panel 0's here, panel I + 1's behind the first 16x16x4
+            // block of row I (the last panel's one row earlier, so that a VALU result never meets an asm matrix instruction
+            // without matrix work in between)
+            double rot[3][2];
+            auto rotate = [&](int I) {
+                rot[I % 3][0] = dpp_move<0x124>(p[I]);  // row_ror:4
+                rot[I % 3][1] = dpp_move<0x128>(p[I]);  // row_ror:8
+            };
+            auto diag4 = [&](double& d, double x, double y) {
+                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
+            };
+            if constexpr (DIAG4) rotate(0);
             if constexpr (PINNED) {  // (asm MFMAs are opaque to the scheduler and the hazard recogniser: see k_gram)
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 7");
             }
-            int b = 0;
+            constexpr int NM = DIAG4 ? NBLK - NB : NBLK;  // 16x16x4 instructions per group
+            int b = 0, nm = 0;
 #pragma unroll
             for (int I = 0; I < NB; ++I) {
                 if (NB == 1 && g >= 2) {
                     mfma4(sacc[2 * (g & 1)], opa[0], opb[0], true);
                     mfma4(sacc[2 * (g & 1) + 1], opa[1], opb[1], true);
                 }
+                if constexpr (DIAG4) {
+                    diag4(Dg[I][0], p[I], p[I]);
+                    diag4(Dg[I][1], p[I], rot[I % 3][0]);
+                    diag4(Dg[I][2], p[I], rot[I % 3][1]);
+                }
 #pragma unroll
                 for (int J = I; J < NB; ++J) {
+                    if (DIAG4 && J == I) {
+                        ++b;
+                        continue;
+                    }
                     mfma(b, p[I], p[J]);
                     if constexpr (PINNED) {
-                        if (b == 0 || b == 1) {
+                        if (nm == 0 || nm == 1) {
                             __builtin_amdgcn_sched_barrier(0);
-                            if (b == 0) request_next(); else request_steps();
+                            if (nm == 0) request_next(); else request_steps();
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    if (g == GROUPS - 1) {  // pieces [b NDMA / NBLK, (b + 1) NDMA / NBLK) of the tile after next; the last = weights
+                    if constexpr (DIAG4) {
+                        const int nxt = (J == I + 1 && I + 1 < NB - 1) ? I + 1 : ((I == NB - 3 && J == NB - 1) ? NB - 1 : -1);
+                        if (nxt > 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            rotate(nxt);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (g == GROUPS - 1) {  // pieces [nm NDMA / NM, (nm + 1) NDMA / NM) of the tile after next; the last = weights
 #pragma unroll
-                        for (int j = b * NDMA / NBLK; j < (b + 1) * NDMA / NBLK; ++j) {
+                        for (int j = nm * NDMA / NM; j < (nm + 1) * NDMA / NM; ++j) {
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                             if (j < ROWS / 8)
                                 stage_piece<true>(P + rows(8 * j) * ld + tstage * TS, so.off[j & 1], cbuf + j * 1024, lane);
@@ -2604,6 +2648,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                         }
                     }
                     ++b;
+                    ++nm;
                 }
                 // 4x4x4 steps of the next tile after every row of blocks but the last (so that the accumulators are long
                 // complete when the VALU reads them): fused_steps_done(I) of the group's 2 NB steps are issued by row I
@@ -2654,10 +2699,35 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
             if (lane < 16) psum_part[(gw * 2 + f) * ROWS + 16 * I + lane] = v;
         }
     }
+    {
+        int b = 0;
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b)
+        for (int I = 0; I < NB; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = G[b][r];
+            for (int J = I; J < NB; ++J, ++b) {
+                if (DIAG4 && J == I) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = G[b][r];
+            }
+    }
+    if constexpr (DIAG4) {
+        // the 4 x 4 sub-blocks into the 16 x 16 record the 16x16x4 instruction would have left (element (r, c) at r 16 + c):
+        // lane j + 4 b + 16 i holds (4 b + i, 4 b' + j), b' = the block the rotated operand came from -- asked of the same
+        // DPP controls, so the direction of the rotation is not assumed.  (b, b) and (b, b + 2) land once each, (b, b -+ 1) also
+        // transposed: all 16 sub-blocks of the record are written.
+        const int jj = lane & 3, bb = (lane >> 2) & 3, ii = lane >> 4;
+        const int b1 = __builtin_amdgcn_update_dpp(0, bb, 0x124, 0xF, 0xF, true);
+        const int b2 = __builtin_amdgcn_update_dpp(0, bb, 0x128, 0xF, 0xF, true);
+        const int row = 4 * bb + ii;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double* rec = gram_part + (gw * NBLK + (I * NB - (I * (I - 1)) / 2)) * 256;
+            rec[row * 16 + 4 * bb + jj] = Dg[I][0];
+            rec[row * 16 + 4 * b1 + jj] = Dg[I][1];
+            rec[(4 * b1 + jj) * 16 + row] = Dg[I][1];
+            rec[row * 16 + 4 * b2 + jj] = Dg[I][2];
+        }
+    }
 }
 
 // Same reduction as k_reduce for TWO partial-record arrays with the same number of records in one launch
