@@ -2777,7 +2777,9 @@ __device__ __forceinline__ double gram_elem(const double* __restrict__ g, int nb
 // squares of the Cholesky diagonal, so "pivot <= 0" is exactly the Cholesky breakdown test of the host path): step j
 // needs only column j, which its owners publish through a double-buffered LDS vector -- row j of the live block is the
 // same vector by symmetry -- so a step is one barrier, 2 R + 1 LDS reads and at most R R FMAs per thread, and there are no
-// triangular solves: x_i = b_i / pivot_i at the end.  The whole kernel is bound by the fp64 issue rate of ONE compute
+// triangular solves: x_i = b_i / pivot_i at the end.  Pivots are taken TWO per barrier (both columns are published as they
+// stand and every thread reconstructs what the second step would have read): half the latency chains for ~10 % more
+// arithmetic -- 127 unknowns 68 -> 65 us (the 8 x 8 tiles are arithmetic-bound by then), 39 / 63 unknowns ~-30 %.  The whole kernel is bound by the fp64 issue rate of ONE compute
 // unit, so it is written for instruction count:
 //   * columns left of the pivot are never read again; they are left stale (whole tile columns c < j / T: skipped
 //     statically, the step loop is unrolled over j / T) or take garbage, and the pivots are kept in their own vector;
@@ -2791,7 +2793,7 @@ template <int T, int R>
 __global__ void __launch_bounds__(T * T)
 k_newton(AdaptArgs q) {
     constexpr int NC = R * T, NT = T * T;
-    __shared__ double colbuf[2][NC];
+    __shared__ double colbuf[2][2][NC];  // [parity of the step][column j, column j + 1]
     __shared__ double pv[NC], rh[NC], xs[NC + 1];
     __shared__ double s_f[128], s_ps[128], s_nk[128], s_ln[128];  // per-state vectors (Kp <= 128)
     __shared__ double s_cc[128], s_a0[128];                       // P mode: current multipliers, build point
@@ -2859,9 +2861,58 @@ k_newton(AdaptArgs q) {
 #pragma unroll
     for (int jc = 0; jc < R; ++jc) {
         const int jend = M < T * (jc + 1) ? M : T * (jc + 1);
-        for (int j = T * jc; j < jend; ++j) {
+        int j = T * jc;
+        // Two pivots per barrier (the step is a latency chain, not arithmetic): columns j and j + 1 are published as they
+        // stand, every thread forms the multiplier l = A[j+1][j] / p1 of row j + 1, the second pivot p2 = A[j+1][j+1] - l A[j+1][j]
+        // and, for its rows and columns, what the second elimination step would have read:
+        //   column j + 1 after step j: c2_i = A[i][j+1] - m1_i A[j][j+1],   row j + 1 after step j: r2_k = A[j+1][k] - l A[j][k]
+        // and then applies both rank-1 updates at once.  Pivot rows: m1_j = 0, m2_{j+1} = 0 (row j is still cleared of its
+        // (j + 1) entry by the second pivot, row j + 1 of its j entry by the first).
+        for (; j + 1 < jend; j += 2) {
             const int jt = j - T * jc;
-            double* cb = colbuf[j & 1];
+            double* ca = colbuf[(j >> 1) & 1][0];
+            double* cb = colbuf[(j >> 1) & 1][1];
+            if (tx == jt || tx == jt + 1) {  // owners of columns j and j + 1
+                double* cx = tx == jt ? ca : cb;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r < R - 1 || ty != T - 1) cx[ty + T * r] = A[r][jc];  // (slot NC-1 belongs to b)
+            }
+            if (tx == T - 1) {
+                if (ty == jt) ca[NC - 1] = A[jc][R - 1];      // b_j
+                if (ty == jt + 1) cb[NC - 1] = A[jc][R - 1];  // b_{j+1}
+            }
+            __syncthreads();
+            const double p1 = ca[j], a12 = ca[j + 1], a22 = cb[j + 1];
+            const double inv1 = recip_fast(p1);
+            const double l = a12 * inv1;
+            const double p2 = fma(-l, a12, a22);
+            const double inv2 = recip_fast(p2);
+            if (tid == 0) {
+                pv[j] = p1;
+                pv[j + 1] = p2;
+            }
+            if (!(p1 > piv_thr) || !isfinite(p1) || !(p2 > piv_thr) || !isfinite(p2)) bad = true;  // the same in every thread
+            double m1[R], m2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double x1 = ca[ty + T * r], x2 = cb[ty + T * r];
+                m1[r] = x1 * inv1;
+                if (ty == jt && r == jc) m1[r] = 0.0;  // pivot row j
+                m2[r] = fma(-m1[r], a12, x2) * inv2;
+                if (ty == jt + 1 && r == jc) m2[r] = 0.0;  // pivot row j + 1
+            }
+#pragma unroll
+            for (int c = jc; c < R; ++c) {
+                const double r1 = ca[tx + T * c];
+                const double r2 = fma(-l, r1, cb[tx + T * c]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) A[r][c] = fma(-m2[r], r2, fma(-m1[r], r1, A[r][c]));
+            }
+        }
+        for (; j < jend; ++j) {  // (an odd pivot left over in this tile column)
+            const int jt = j - T * jc;
+            double* cb = colbuf[(j >> 1) & 1][0];
             if (tx == jt) {  // owners of column j
 #pragma unroll
                 for (int r = 0; r < R; ++r)
