@@ -196,6 +196,7 @@ def main():
     dm.set_option("device_loop", args.device_loop)
     dm.set_option("pmode", args.pmode)
     dm.set_option("fused", args.fused)
+    dm.set_option("timing", 1)  # HIP-event pairs around the sweeps (off by default in the library)
     dm.set_option("graph", 0)  # eager launches: per-kernel HIP-event timers inside the timed region (the GPU queue never
     #                            runs dry at this size: an iteration is ~5 ms of kernels against ~0.1 ms of enqueueing)
     dm.set_Nk(N_k)

@@ -89,8 +89,9 @@ int mbar_device_synchronize(int device);
  *   "pmode"          1 = the device-resident loop keeps P = exp(a0 - u - logden(a0)) resident (one more K x N array, built
  *                    once per solve) and sweeps that: no exponentials in the loop (default); 0 = sweeps recompute them from u
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
- *   "timing"         HIP-event timers (mbar_ctx_timing): 1 = event records around a launch (default), 2 = events bound to
- *                    the kernel dispatch in the device-resident loop (no marker packets between kernels), 0 = off */
+ *   "timing"         HIP-event timers (mbar_ctx_timing): 0 = off (default: an event pair per sweep costs ~10 us, a fifth of an
+ *                    iteration at the problem sizes pymbar is mostly used on), 1 = event records around a launch, 2 = events
+ *                    bound to the kernel dispatch in the device-resident loop (no marker packets between kernels) */
 int mbar_ctx_set_option(mbar_ctx* ctx, const char* key, int64_t value);
 
 /* ---- data ---------------------------------------------------------------------------------- */

@@ -236,7 +236,7 @@ struct mbar_ctx {
     size_t part_g_doubles = 0;
     double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
     // options
-    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 1, opt_graph = 1, opt_small = 1, opt_wide = 1;
+    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
     int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1;
     // comm
@@ -1288,9 +1288,15 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         return MBAR_OK;
     };
 
+    // Batches between two looks at the control words: 6, 2, 4, then `adapt_batch` (8) each.  Iterations enqueued past convergence
+    // are no-ops of ~3.5 us per kernel; real solves take 5-8 iterations, and for the small problems pymbar is mostly used on
+    // (config 5: 62 us per iteration) two wasted iterations of a fixed batch of 8 were a tenth of the solve.  Only full-size
+    // batches replay a captured hipGraph (eager launches are as fast at these kernel counts: the queue never runs dry), so a
+    // short solve never pays for a capture.
     const int64_t batch = c->opt_adapt_batch;
-    const bool use_graph = c->opt_graph && !c->comm && (maxiter - res.iterations) >= batch;
-    if (use_graph) {
+    const bool use_graph = c->opt_graph && !c->comm;
+    auto prepare_graph = [&]() -> int {
+
         const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 12) ^ (pmode ? 128 : 0) ^ (fused ? 256 : 0) ^
                             (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (int64_t)nb;
         if (!c->ad_graph || c->ad_graph_batch != batch || c->ad_graph_sig != sig) {
@@ -1318,13 +1324,20 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             c->ad_graph_batch = batch;
             c->ad_graph_sig = sig;
         }
-    }
+        return MBAR_OK;
+    };
     int64_t it = res.iterations;
     const int64_t it_start = it;
     bool done = false;
+    int64_t nbatch = 0;
     while (it < maxiter && !done) {
-        const int64_t nbat = std::min(batch, maxiter - it);
+        static const int64_t first_batches[3] = {6, 2, 4};
+        const int64_t want = nbatch < 3 ? std::min(batch, first_batches[nbatch]) : batch;
+        ++nbatch;
+        const int64_t nbat = std::min(want, maxiter - it);
         if (use_graph && nbat == batch) {
+            rc = prepare_graph();
+            if (rc) return rc;
             HIPCHK(c, hipGraphLaunch(c->ad_graph, c->stream));
         } else {
             for (int64_t b = 0; b < nbat; ++b) {

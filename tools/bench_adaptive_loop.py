@@ -21,6 +21,7 @@ def run(dm, K, label, steps):
                        ("device eager", dict(device_loop=1, graph=0, timing=1, pmode=1, fused=1)),
                        ("device eager 2sweep", dict(device_loop=1, graph=0, timing=1, pmode=1, fused=0)),
                        ("device eager notime", dict(device_loop=1, graph=0, timing=0, pmode=1, fused=1)),
+                       ("library defaults", dict(device_loop=1, graph=1, timing=0, pmode=1, fused=1)),
                        ("host loop", dict(device_loop=0, graph=1, timing=1, pmode=1, fused=1))):
         for k, v in opts.items():
             dm.set_option(k, v)

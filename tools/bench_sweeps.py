@@ -23,6 +23,7 @@ def main():
         N_k[-1] += N - N_k.sum()
         with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
             dm.set_Nk(N_k)
+            dm.set_option("timing", 1)  # (HIP-event timers are off by default)
             f = ts.harmonic_free_energies(K_k)
             f2 = np.stack([f, f * 0.99])
             gb = 8.0 * K * N * 1e-9
