@@ -3178,6 +3178,10 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
         const int by_lds = blocks_per_cu_for(g.lds_bytes);
         const int by_reg = occ[tile_rows / 16];
         cap = (int64_t)num_cu * (by_lds < by_reg ? by_lds : by_reg);
+        // (... once a wave has ~32 tiles to work on: every wave writes a partial record -- see fused_geometry)
+        int64_t by_work = (ntiles + 127) / 128;
+        if (by_work < num_cu) by_work = num_cu;
+        if (cap > by_work) cap = by_work;
     }
     if (grid_override > 0) cap = grid_override;
     if (want < 1) want = 1;
@@ -3734,6 +3738,12 @@ LaunchGeom fused_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_overr
         static const int occ[6] = {1, 4, 4, 3, 2, 2};
         const int by_lds = blocks_per_cu_for(g.lds_bytes);
         cap = (int64_t)num_cu * (by_lds < occ[nb] ? by_lds : occ[nb]);
+        // ... but every wave leaves a partial record (NB (NB + 1) / 2 blocks of 2 KB + the per-state sums) and pays a prologue:
+        // a second workgroup per CU only once a wave has ~32 tiles to work on (config 5, K = 40, N = 95 000: 58 instead of
+        // 64 us per iteration with one workgroup per CU; K = 32, N = 1e6 is fastest at two)
+        int64_t by_work = (ntiles + 127) / 128;
+        if (by_work < num_cu) by_work = num_cu;
+        if (cap > by_work) cap = by_work;
     }
     if (grid_override > 0) cap = grid_override;
     if (want < 1) want = 1;
