@@ -12,7 +12,7 @@ from pymbar_amd import testsystems as ts  # noqa: E402
 from pymbar_amd.device import DeviceMatrix  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-for K, N in ((128, 1_000_000), (256, 400_000), (192, 300_000), (112, 500_000), (32, 2_000_000), (16, 1_000_000)):
+for K, N in ((128, 1_000_003), (128, 10_000_000), (256, 400_000), (192, 300_000), (112, 500_000), (40, 95_001), (32, 2_000_000), (16, 1_000_000)):
     O_k, K_k, N_k = ts.config3_params(K=K, N=N)
     N_k[-1] += N - N_k.sum()
     with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=1) as dm:
@@ -34,8 +34,22 @@ for K, N in ((128, 1_000_000), (256, 400_000), (192, 300_000), (112, 500_000), (
             _, _, G0 = dm.eval(f2, gram=True)
             d = np.max(np.abs(G0 - G)) / np.max(np.abs(G))
             assert d < 1e-13, d
-        fs, res = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
-        fs2, res2 = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
-        assert np.array_equal(fs, fs2) and res["iterations"] == res2["iterations"]
-        print(f"K={K:4d} N={N:8d}: {reps} evaluations bit-identical ({ref[:12]}), solve reproducible in {res['iterations']} iterations")
+        # the device-resident loop (resident probability matrix, fused sweep with hand-placed matrix instructions, LDS-DMA three
+        # quarters of an iteration ahead): the whole solve bit for bit, with and without bootstrap multiplicities
+        sreps = max(4, reps // 4)
+        for weighted in (False, True):
+            if weighted:
+                c_n = np.zeros(N)
+                start = 0
+                for n_k in N_k:
+                    c_n[start:start + n_k] = np.bincount(rng.integers(0, n_k, size=n_k), minlength=n_k)
+                    start += n_k
+                dm.set_sample_weights(c_n)
+            fs, res = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+            for r in range(sreps):
+                fs2, res2 = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+                assert np.array_equal(fs, fs2) and res["iterations"] == res2["iterations"], f"K={K} weighted={weighted}: solve {r} differs"
+                assert np.array_equal(np.asarray(res.get("history", 0)), np.asarray(res2.get("history", 0)))
+        dm.set_sample_weights(None)
+        print(f"K={K:4d} N={N:8d}: {reps} evaluations bit-identical ({ref[:12]}), 2 x {sreps} solves reproducible ({res['iterations']} iterations weighted)")
 print("OK")
