@@ -106,10 +106,17 @@ int mbar_ctx_download_u(mbar_ctx* ctx, double* out, int64_t ld_out);
  * N x (K + NL + S) array the reference builds (mbar.py:886-903).
  *   upload_rows: whole rows [row0, row0 + nrows) from a C-contiguous host array rows_host[nrows][ld_host >= N_local];
  *   copy_rows:   device-to-device from another context on the same device with the same N_local;
- *   row_sub:     u[row][n] -= v_host[n]  (v = log A_n); v_host = NULL subtracts the vector of the previous call again. */
+ *   row_sub:     u[row][n] -= v_host[n]  (v = log A_n); v_host = NULL subtracts the vector of the previous call again;
+ *   rows_sub:    u[dst_row0 + r][n] = u[src_row0 + r][n] - v_host[n] for r < nrows in ONE launch (one observable evaluated at
+ *                a run of states: the state rows are copied and shifted in the same pass); dst_row0 == src_row0: in place,
+ *                otherwise the ranges must not overlap; v_host = NULL as for row_sub;
+ *   rows_rsub:   u[dst_row0 + r][n] = u[src_row0 + r][n] - u[dst_row0 + r][n]: many DIFFERENT observables -- their log A rows are
+ *                uploaded in one upload_rows call and turned into observable rows in one launch (disjoint ranges). */
 int mbar_ctx_upload_rows(mbar_ctx* ctx, int64_t row0, int64_t nrows, const double* rows_host, int64_t ld_host);
 int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows);
 int mbar_ctx_row_sub(mbar_ctx* ctx, int64_t row, const double* v_host);
+int mbar_ctx_rows_sub(mbar_ctx* ctx, int64_t dst_row0, int64_t src_row0, int64_t nrows, const double* v_host);
+int mbar_ctx_rows_rsub(mbar_ctx* ctx, int64_t dst_row0, int64_t src_row0, int64_t nrows);
 /* Free-energy-surface histograms (fes.py:1383-1402: one extra column of W per populated bin, W[n, K+i] = exp(log_w_n + f_i)
  * on the bin's samples and 0 elsewhere): rows [row0, row0 + nrows) of the augmented matrix become
  *   u[row0 + i][n] = label[n] == i ? v[n] : +inf      (v = the target potential u_n; label[n] = bin of sample n, -1 = none)

@@ -1639,6 +1639,35 @@ int mbar_ctx_row_sub(mbar_ctx* c, int64_t row, const double* v_host) {
     return sync_stream(c);
 }
 
+int mbar_ctx_rows_sub(mbar_ctx* c, int64_t dst_row0, int64_t src_row0, int64_t nrows, const double* v_host) {
+    if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (nrows < 0 || dst_row0 < 0 || src_row0 < 0 || dst_row0 + nrows > c->K || src_row0 + nrows > c->K)
+        return fail(c, MBAR_ERR_ARG, "row range out of bounds");
+    if (dst_row0 != src_row0 && dst_row0 < src_row0 + nrows && src_row0 < dst_row0 + nrows)
+        return fail(c, MBAR_ERR_ARG, "mbar_ctx_rows_sub: the row ranges overlap");
+    if (!v_host && !c->vec_tmp) return fail(c, MBAR_ERR_STATE, "mbar_ctx_rows_sub: no vector has been uploaded yet");
+    if (nrows == 0) return MBAR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->vec_tmp) HIPCHK(c, cache_malloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
+    if (v_host)  // NULL: the vector of the previous call again (one observable at many states)
+        HIPCHK(c, hipMemcpyAsync(c->vec_tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rows_sub(c->stream, c->u + dst_row0 * c->ld, c->u + src_row0 * c->ld, c->ld, nrows, c->vec_tmp, c->N));
+    c->u_checked = false;
+    return sync_stream(c);
+}
+
+int mbar_ctx_rows_rsub(mbar_ctx* c, int64_t dst_row0, int64_t src_row0, int64_t nrows) {
+    if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (nrows < 0 || dst_row0 < 0 || src_row0 < 0 || dst_row0 + nrows > c->K || src_row0 + nrows > c->K)
+        return fail(c, MBAR_ERR_ARG, "row range out of bounds");
+    if (dst_row0 < src_row0 + nrows && src_row0 < dst_row0 + nrows) return fail(c, MBAR_ERR_ARG, "mbar_ctx_rows_rsub: the row ranges overlap");
+    if (nrows == 0) return MBAR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_rows_rsub(c->stream, c->u + dst_row0 * c->ld, c->u + src_row0 * c->ld, c->ld, nrows, c->N));
+    c->u_checked = false;
+    return sync_stream(c);
+}
+
 int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const double* v_host, const int32_t* label_host) {
     if (!c || !v_host || !label_host) return fail(c, MBAR_ERR_ARG, "NULL argument");
     if (row0 < 0 || nrows < 0 || row0 + nrows > c->K) return fail(c, MBAR_ERR_ARG, "row range out of bounds");

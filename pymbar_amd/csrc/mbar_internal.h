@@ -81,6 +81,8 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
 // that both compute every operand
 LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, int64_t grid_override, int nb8_variant);
 hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n);  // row[i] -= v[i]
+hipError_t launch_rows_sub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, const double* v, int64_t n);
+hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n);
 // rows[i][k] = label[k] == i ? v[k] : +inf,  i < nrows (row pitch ld)
 hipError_t launch_fill_masked_rows(hipStream_t s, double* rows, int64_t ld, int64_t n, int64_t nrows, const double* v,
                                    const int* label);

@@ -3575,6 +3575,35 @@ hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n
     return hipGetLastError();
 }
 
+// dst[r][i] = src[r][i] - v[i] for r < nrows (rows `ld` apart; dst == src: in place)
+__global__ void __launch_bounds__(256) k_rows_sub(double* __restrict__ dst, const double* __restrict__ src, int64_t ld, int64_t nrows,
+                                                  const double* __restrict__ v, int64_t n) {
+    for (int64_t r = blockIdx.y; r < nrows; r += gridDim.y)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            dst[r * ld + i] = src[r * ld + i] - v[i];
+}
+// dst[r][i] = src[r][i] - dst[r][i]  (the observable rows arrive as log A and leave as u - log A)
+__global__ void __launch_bounds__(256) k_rows_rsub(double* __restrict__ dst, const double* __restrict__ src, int64_t ld, int64_t nrows,
+                                                   int64_t n) {
+    for (int64_t r = blockIdx.y; r < nrows; r += gridDim.y)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            dst[r * ld + i] = src[r * ld + i] - dst[r * ld + i];
+}
+hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n) {
+    const int64_t want = (n + 255) / 256;
+    const unsigned gx = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+    const unsigned gy = (unsigned)(nrows < 1024 ? (nrows < 1 ? 1 : nrows) : 1024);
+    hipLaunchKernelGGL(k_rows_rsub, dim3(gx, gy), dim3(256), 0, s, dst, src, ld, nrows, n);
+    return hipGetLastError();
+}
+hipError_t launch_rows_sub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, const double* v, int64_t n) {
+    const int64_t want = (n + 255) / 256;
+    const unsigned gx = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+    const unsigned gy = (unsigned)(nrows < 1024 ? (nrows < 1 ? 1 : nrows) : 1024);
+    hipLaunchKernelGGL(k_rows_sub, dim3(gx, gy), dim3(256), 0, s, dst, src, ld, nrows, v, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_sci_update(hipStream_t s, const double* part, int64_t nparts, int64_t rows, const double* Nk,
                              const double* lnNk, int64_t K, int64_t Kp, int first_state, double tol, double* f,
                              double* aden, double* f_hist, double* delta_out) {

@@ -125,6 +125,22 @@ class DeviceMatrix:
             raise ValueError("v_n must have N_local entries")
         self._check(self._lib.mbar_ctx_row_sub(self._ctx, int(row), _dptr(v_n)))
 
+    def rows_sub(self, dst_row0, src_row0, nrows, v_n=None):
+        """``u[dst_row0 + r, :] = u[src_row0 + r, :] - v_n`` for ``r < nrows`` in one launch (``v_n=None``: the vector of the
+        previous call): an observable evaluated at a run of states, the state rows copied and shifted in the same pass."""
+        if v_n is None:
+            self._check(self._lib.mbar_ctx_rows_sub(self._ctx, int(dst_row0), int(src_row0), int(nrows), None))
+            return
+        v_n = np.ascontiguousarray(v_n, dtype=np.float64)
+        if v_n.shape != (self.N_local,):
+            raise ValueError("v_n must have N_local entries")
+        self._check(self._lib.mbar_ctx_rows_sub(self._ctx, int(dst_row0), int(src_row0), int(nrows), _dptr(v_n)))
+
+    def rows_rsub(self, dst_row0, src_row0, nrows):
+        """``u[dst_row0 + r, :] = u[src_row0 + r, :] - u[dst_row0 + r, :]`` for ``r < nrows`` in one launch: rows uploaded as
+        ``log A`` become observable rows ``u - log A``."""
+        self._check(self._lib.mbar_ctx_rows_rsub(self._ctx, int(dst_row0), int(src_row0), int(nrows)))
+
     def fill_masked_rows(self, row0, nrows, v_n, label_n):
         """Rows ``row0 + i`` (``i < nrows``) become ``v_n`` on the samples with ``label_n == i`` and ``+inf`` (weight zero)
         elsewhere: one extra "state" per histogram bin of a free energy surface, built on the device."""

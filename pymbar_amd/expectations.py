@@ -44,21 +44,43 @@ def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device):
     dm = DeviceMatrix.empty(K + NL + S, N, device=device)
     dm.copy_rows_from(mbar._dm, 0, 0, K)
     resident = u_ln is mbar.u_kn
-    for j, l in enumerate(L_list):
-        if resident:
-            dm.copy_rows_from(mbar._dm, K + j, int(l), 1)
-        else:
+
+    def runs(pairs):
+        """(dst, src) row pairs -> maximal (dst0, src0, n) runs with both indices consecutive: one device call per run."""
+        out = []
+        for d, s_ in pairs:
+            if out and out[-1][0] + out[-1][2] == d and out[-1][1] + out[-1][2] == s_:
+                out[-1][2] += 1
+            else:
+                out.append([d, s_, 1])
+        return out
+
+    if resident:
+        for d0, s0, n in runs([(K + j, int(l)) for j, l in enumerate(L_list)]):
+            dm.copy_rows_from(mbar._dm, d0, s0, n)
+    else:
+        for j, l in enumerate(L_list):
             dm.upload_rows(K + j, u_ln[int(l)][np.newaxis, :])
     col = {int(l): K + j for j, l in enumerate(L_list)}
-    for i in np.unique(obs_rows) if S > 0 else []:  # one upload of log A_i, subtracted at every state it is evaluated at
+    uniq = np.unique(obs_rows) if S > 0 else []
+    if len(uniq) > 2 and len(uniq) * 2 > S:
+        # mostly DIFFERENT observables (entropy / enthalpy: the K reduced potentials, each at its own state): their log A rows
+        # go up in ONE transfer, straight into the observable rows, and become u - log A in one launch per run of rows
+        log_A = A_n[np.asarray(obs_rows, dtype=int)]  # (a gather: already a private array)
+        with np.errstate(divide="ignore"):
+            np.log(log_A, out=log_A)
+        dm.upload_rows(K + NL, log_A)
+        del log_A
+        for d0, s0, n in runs([(K + NL + s, col[int(state_rows[s])]) for s in range(S)]):
+            dm.rows_rsub(d0, s0, n)
+        uniq = []
+    for i in uniq:  # one upload of log A_i, subtracted at every state it is evaluated at
         with np.errstate(divide="ignore"):
             log_A = np.log(A_n[int(i)])
         first = True
-        for s in range(S):
-            if int(obs_rows[s]) != int(i):
-                continue
-            dm.copy_rows_from(dm, K + NL + s, col[int(state_rows[s])], 1)
-            dm.row_sub(K + NL + s, log_A if first else None)
+        # observable rows = state rows - log A_i, written in one pass per run of consecutive rows (no copy + subtract pair)
+        for d0, s0, n in runs([(K + NL + s, col[int(state_rows[s])]) for s in range(S) if int(obs_rows[s]) == int(i)]):
+            dm.rows_sub(d0, s0, n, log_A if first else None)
             first = False
     N_aug = np.zeros(K + NL + S, dtype=np.float64)
     N_aug[:K] = mbar.N_k
@@ -311,7 +333,7 @@ def compute_entropy_and_enthalpy(mbar, u_kn=None, uncertainty_method=None, verbo
         u_kn = mbar.u_kn
     K, N = np.shape(u_kn)
     state_map = np.vstack([np.arange(K), np.arange(K)])
-    inner = compute_expectations_inner(mbar, np.array(u_kn, dtype=np.float64), u_kn, state_map, return_theta=True,
+    inner = compute_expectations_inner(mbar, u_kn, u_kn, state_map, return_theta=True,  # (the observables are copied there)
                                        uncertainty_method=uncertainty_method, warning_cutoff=warning_cutoff)
     # covariance of (ln c_Ua, ln c_a, ln c_a again) -> u, f and s = u - f   (mbar.py:1600-1610)
     Theta = np.zeros([3 * K, 3 * K], dtype=np.float64)

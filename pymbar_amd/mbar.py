@@ -12,6 +12,7 @@ The ``Log_W_nk`` consumers (``compute_expectations*``, ``compute_perturbed_free_
 methods below.  Not mirrored (not on the K x N solver path): FES, timeseries, the other estimators.
 """
 import copy
+import contextlib
 import logging
 
 import numpy as np
@@ -51,6 +52,32 @@ def _resolve_protocol(protocol, default, robust, maximum_iterations, verbose, pn
             opts["maxiter"] = maximum_iterations
         opts.setdefault("verbose", verbose)
     return protocol
+
+
+@contextlib.contextmanager
+def _small_blas(K):
+    """A few hundred states: the eigendecomposition / pseudo-inverse / products of the covariance are K x K host matrices, and a
+    BLAS that wakes every core of a large host for them spends tens of milliseconds on its threads (16-95 ms instead of 3 at
+    K = 120 on a 256-thread box).  One thread while they run, if threadpoolctl is there to ask."""
+    global _BLAS_CONTROLLER
+    if K > 512 or K < 48:  # (below ~50 states the products are too small for the BLAS to thread at all)
+        yield
+        return
+    if _BLAS_CONTROLLER is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+
+            _BLAS_CONTROLLER = ThreadpoolController()  # (scans the loaded libraries once; threadpool_limits() does it per call)
+        except Exception:  # pragma: no cover - optional dependency
+            _BLAS_CONTROLLER = False
+    if not _BLAS_CONTROLLER:
+        yield
+        return
+    with _BLAS_CONTROLLER.limit(limits=1):
+        yield
+
+
+_BLAS_CONTROLLER = None
 
 
 class MBAR:
@@ -307,6 +334,10 @@ class MBAR:
             return G
         Ndiag = np.diag(N_k)
         ident = np.identity(K, dtype=np.float64)
+        with _small_blas(K):
+            return self._theta_dense(G, N_k, method, W, dm, f_full, Ndiag, ident)
+
+    def _theta_dense(self, G, N_k, method, W, dm, f_full, Ndiag, ident):
         if method == "svd":
             if W is None:
                 if dm is None:

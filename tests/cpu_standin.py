@@ -55,6 +55,14 @@ class OracleMatrix:
             self._last_v = np.asarray(v_n, dtype=np.float64).copy()
         self.u[row] -= self._last_v
 
+    def rows_sub(self, dst_row0, src_row0, nrows, v_n=None):
+        if v_n is not None:
+            self._last_v = np.asarray(v_n, dtype=np.float64).copy()
+        self.u[dst_row0:dst_row0 + nrows] = self.u[src_row0:src_row0 + nrows] - self._last_v
+
+    def rows_rsub(self, dst_row0, src_row0, nrows):
+        self.u[dst_row0:dst_row0 + nrows] = self.u[src_row0:src_row0 + nrows] - self.u[dst_row0:dst_row0 + nrows]
+
     def fill_masked_rows(self, row0, nrows, v_n, label_n):
         v_n = np.asarray(v_n, dtype=np.float64)
         label_n = np.asarray(label_n)
