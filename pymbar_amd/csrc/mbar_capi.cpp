@@ -775,16 +775,35 @@ bool chol_solve(std::vector<double>& A, std::vector<double>& b, int m) {
     double dmax = 0.0;
     for (int j = 0; j < m; ++j) dmax = std::max(dmax, A[(size_t)j * m + j]);
     const double thr = dmax * std::numeric_limits<double>::epsilon() * m;
-    for (int j = 0; j < m; ++j) {
-        double d = A[(size_t)j * m + j];
-        for (int k = 0; k < j; ++k) d -= A[(size_t)j * m + k] * A[(size_t)j * m + k];
-        if (!(d > thr) || !std::isfinite(d)) return false;
-        d = std::sqrt(d);
-        A[(size_t)j * m + j] = d;
-        for (int i = j + 1; i < m; ++i) {
-            double s = A[(size_t)i * m + j];
-            for (int k = 0; k < j; ++k) s -= A[(size_t)i * m + k] * A[(size_t)j * m + k];
-            A[(size_t)i * m + j] = s / d;
+    // Right-looking, panels of 4 columns: the trailing update is a rank-4 update whose inner loops run along rows without a
+    // reduction, so the compiler vectorises them as they stand (255 unknowns: 0.57 ms against 1.38 ms for the dot-product form
+    // -- at 129..256 states, where the loop is host-driven, this solve was most of the time between two sweeps).
+    constexpr int P = 4;
+    std::vector<double> col((size_t)P * m);
+    for (int j0 = 0; j0 < m; j0 += P) {
+        const int j1 = std::min(j0 + P, m);
+        for (int c = j0; c < j1; ++c) {
+            double d = A[(size_t)c * m + c];
+            if (!(d > thr) || !std::isfinite(d)) return false;
+            d = std::sqrt(d);
+            A[(size_t)c * m + c] = d;
+            const double inv = 1.0 / d;
+            double* cc = col.data() + (size_t)(c - j0) * m;
+            for (int i = c + 1; i < m; ++i) cc[i] = (A[(size_t)i * m + c] *= inv);
+            for (int i = c + 1; i < m; ++i) {  // the rest of the panel's columns
+                const double li = cc[i];
+                double* row = A.data() + (size_t)i * m;
+                const int kend = std::min(i, j1 - 1);
+                for (int k = c + 1; k <= kend; ++k) row[k] -= li * cc[k];
+            }
+        }
+        if (j1 - j0 == P) {  // (a short last panel has no trailing block)
+            const double *c0 = col.data(), *c1 = c0 + m, *c2 = c1 + m, *c3 = c2 + m;
+            for (int i = j1; i < m; ++i) {
+                const double l0 = c0[i], l1 = c1[i], l2 = c2[i], l3 = c3[i];
+                double* row = A.data() + (size_t)i * m;
+                for (int k = j1; k <= i; ++k) row[k] -= l0 * c0[k] + l1 * c1[k] + l2 * c2[k] + l3 * c3[k];
+            }
         }
     }
     for (int i = 0; i < m; ++i) {
