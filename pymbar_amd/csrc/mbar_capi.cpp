@@ -485,6 +485,28 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
         }
         return MBAR_OK;
     }
+    // 257 .. 512 states: the rows of a tile split over the eight waves of a workgroup -- ONE read of the matrix per candidate
+    // (the layout-agnostic kernels below read it twice: log-sum-exp pass + column-sum pass)
+    if (!c->opt_force_generic && c->opt_staging == 0 && !wide_pitch(c) && rows <= 512 && rows % 64 == 0 && c->opt_wide) {
+        for (int i = 0; i < nf; ++i) {
+            int blocks = 0;
+            int rc = ensure(c, &c->part, &c->part_doubles, (size_t)c->num_cu * (rows + 1));
+            if (rc) return rc;
+            rc = ensure(c, &c->scratch, &c->scratch_doubles, (size_t)(c->num_cu / 32 + 2) * (rows + 1));
+            if (rc) return rc;
+            double* ldst = i == 0 ? ld0 : ld1;
+            double* obj_part = c->part + (size_t)c->num_cu * rows;
+            {
+                ScopedTimer t(c, MBAR_TIMER_LSE);
+                HIPCHK(c, launch_lse_split(c->stream, c->num_cu, c->u, c->ld, c->N, rows, d_aden(c) + i * rows, c->cw, ldst, dn,
+                                           c->part, obj_part, &blocks));
+            }
+            ScopedTimer t(c, MBAR_TIMER_REDUCE);
+            HIPCHK(c, launch_reduce(c->stream, c->part, blocks, rows, c->scratch, c->red + i * rows));
+            HIPCHK(c, launch_reduce(c->stream, obj_part, blocks, 1, c->scratch, c->red + nf * rows + i));
+        }
+        return MBAR_OK;
+    }
     // generic: one f at a time
     for (int i = 0; i < nf; ++i) {
         int blocks = 0, cblocks = 0;

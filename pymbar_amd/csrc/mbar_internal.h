@@ -95,6 +95,8 @@ hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, bool dma, const La
                            int64_t row_i0, int64_t row_j0, double* gram_part);
 
 // ---- layout-agnostic fallbacks (any K) ---------------------------------------------------------
+hipError_t launch_lse_split(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
+                            const double* cw, double* logden, const double* dn, double* psum_part, double* obj_part, int* blocks_out);
 hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
                               const double* aden, const double* cw, double* logden, const double* dn,
                               double* obj_part /*[blocks]*/, int* blocks_out);

@@ -1080,6 +1080,130 @@ k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Evaluation pass for 257 .. 512 states in ONE read of the matrix (the layout-agnostic path below reads it twice: a log-sum-exp
+// pass and a column-sum pass).  A 16-sample tile of 512 rows is 64 KB -- too much for one wave's registers and LDS share -- so
+// the EIGHT waves of a workgroup split the rows of one tile (16 NBW rows each, their own LDS-DMA, their own double buffer) and
+// meet twice per tile through two small LDS vectors: the per-sample maxima (so that every wave uses the same shift and there
+// is ONE exponential per element) and the per-sample sums.  Rows past the allocated pitch are never requested (their LDS rows
+// stay zero and their a_k is -inf).  Partial records: one per workgroup, `rows` entries + one objective term.
+// ---------------------------------------------------------------------------------------------
+template <int NBW>
+__global__ void __launch_bounds__(512, 1)
+k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, int64_t rows,
+            const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden,
+            const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RW = NBW * 16;                  // rows per wave
+    constexpr int NP = RW / 8;                    // LDS-DMA pieces per wave and tile
+    constexpr int U_BYTES = RW * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the tile's 16 sample weights
+    constexpr int NW = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ks = lane & 15, ns = lane >> 4;
+    exp_table_init(smem);
+    double* xmax = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);  // [NW][TS]
+    double* xsum = xmax + NW * TS;                                     // [NW][TS]
+    char* buf = smem + EXP_TABLE_BYTES + 2 * NW * TS * 8 + wave * (2 * TILE_BYTES);
+    const int64_t r0 = (int64_t)wave * RW;
+    const StageOffsets so = make_stage_offsets(ld, lane);
+    // rows this wave never requests: zero once, in both buffers
+    for (int j = 0; j < NP; ++j)
+        if (r0 + 8 * j >= rows) {
+            for (int bsel = 0; bsel < 2; ++bsel) *reinterpret_cast<double2*>(buf + bsel * TILE_BYTES + j * 1024 + lane * 16) = double2{0.0, 0.0};
+        }
+    __syncthreads();
+    double a[NBW], acc[NBW], objl = 0.0;
+#pragma unroll
+    for (int I = 0; I < NBW; ++I) {
+        const int64_t r = r0 + 16 * I + ks;
+        a[I] = r < rows ? aden[r] : -INFINITY;
+        acc[I] = 0.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NBW; ++I) settle(a[I]);
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    auto stage = [&](int64_t tile, char* dst) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (r0 + 8 * j < rows) stage_piece<true>(u + (r0 + 8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
+        stage_vec16<true>(cw, tile * TS, dst + U_BYTES, lane);
+    };
+    const int64_t G = gridDim.x;
+    int64_t t = blockIdx.x;
+    int cur = 0;
+    if (t < ntiles) stage(t, buf);
+    for (; t < ntiles; t += G) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        wait_vm<0>();  // this tile (requested a tile period ago) and the previous tile's logden stores
+        if (t + G < ntiles) stage(t + G, buf + (cur ^ 1) * TILE_BYTES);
+        double x[GROUPS][NBW], w[GROUPS], mloc[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            w[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) x[g][I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) x[g][I] = a[I] - x[g][I];
+            mloc[g] = row16_max(tree_max<NBW>(x[g]));
+            if (ks == 0) xmax[wave * TS + 4 * g + ns] = mloc[g];
+        }
+        __syncthreads();
+        double m2[GROUPS], sloc[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            double m = xmax[4 * g + ns];
+#pragma unroll
+            for (int wv = 1; wv < NW; ++wv) m = fmax(m, xmax[wv * TS + 4 * g + ns]);
+            m2[g] = m * LOG2E_S;
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) x[g][I] = fma(x[g][I], LOG2E_S, -m2[g]);
+            exp2s_batch<NBW>(x[g]);
+            sloc[g] = row16_sum(tree_sum<NBW>(x[g]));
+            if (ks == 0) xsum[wave * TS + 4 * g + ns] = sloc[g];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            double ssum = xsum[4 * g + ns];
+#pragma unroll
+            for (int wv = 1; wv < NW; ++wv) ssum += xsum[wv * TS + 4 * g + ns];  // (fixed order: every wave gets the same bits)
+            const double r = w[g] * recip_fast(ssum);
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) acc[I] = fma(x[g][I], r, acc[I]);
+            if (wave == 0 && ks == 0) {  // logden_n = shift + log(sum), one lane per sample
+                const int64_t n = t * TS + 4 * g + ns;
+                if (n < N) {
+                    const double ldv = fma(m2[g], LN2_OVER_S, log_pos(ssum));
+                    if (logden) logden[n] = ldv;
+                    objl = fma(w[g], dn ? (ldv - dn[n]) : ldv, objl);
+                }
+            }
+        }
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int I = 0; I < NBW; ++I) {
+        double v = acc[I];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int64_t r = r0 + 16 * I + lane;
+        if (lane < 16 && r < rows) psum_part[(int64_t)blockIdx.x * rows + r] = v;
+    }
+    if (wave == 0) {
+        const double o = wave_sum(objl);
+        if (lane == 0) obj_part[blockIdx.x] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Evaluation pass, paired-wave variant for wide panels (NB >= 6), where one 16-sample tile is 12-32 KB
 // and LDS (not registers) would limit the unpaired kernel to one wave per SIMD.  Two waves share each
 // tile stream (workgroup = STREAMS streams x 2 halves, one barrier per tile); half h evaluates the 4-sample
@@ -3444,6 +3568,32 @@ static int stream_blocks(int num_cu, int64_t N) {
     int64_t cap = (int64_t)num_cu * 8;
     if (want < 1) want = 1;
     return (int)(want < cap ? want : cap);
+}
+
+// 257 .. 512 states in one read: rows = allocated row count (a multiple of 64); returns the number of partial records.
+hipError_t launch_lse_split(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
+                            const double* cw, double* logden, const double* dn, double* psum_part, double* obj_part, int* blocks_out) {
+    const int nbw = (int)((rows + 127) / 128);
+    if (nbw < 1 || nbw > 4) return hipErrorInvalidValue;
+    const int64_t ntiles = (N + TS - 1) / TS;
+    const size_t tile = (size_t)nbw * 16 * TS * 8 + TS * 8;
+    const size_t lds = EXP_TABLE_BYTES + (size_t)2 * 8 * TS * 8 + (size_t)8 * 2 * tile;
+    const int blocks = (int)(ntiles < num_cu ? (ntiles < 1 ? 1 : ntiles) : num_cu);
+    *blocks_out = blocks;
+    auto go = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, u, ld, N, ntiles, rows, aden, cw, logden, dn, psum_part, obj_part);
+        return hipGetLastError();
+    };
+    switch (nbw) {
+        case 1: return go(k_lse_split<1>);
+        case 2: return go(k_lse_split<2>);
+        case 3: return go(k_lse_split<3>);
+        default: return go(k_lse_split<4>);
+    }
 }
 
 hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
