@@ -1659,9 +1659,13 @@ int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t s
     if (nrows == 0) return MBAR_OK;
     HIPCHK(dst, hipSetDevice(dst->device));
     HIPCHK(dst, hipStreamSynchronize(src->stream));  // whatever produced the source rows has finished
-    HIPCHK(dst, hipMemcpy2DAsync(dst->u + dst_row0 * dst->ld, (size_t)dst->ld * sizeof(double), src->u + src_row0 * src->ld,
-                                 (size_t)src->ld * sizeof(double), (size_t)dst->N * sizeof(double), (size_t)nrows,
-                                 hipMemcpyDeviceToDevice, dst->stream));
+    if (dst->ld == src->ld)  // same pitch (same N_local): the rows are one contiguous block, padding included (it is zero in both)
+        HIPCHK(dst, hipMemcpyAsync(dst->u + dst_row0 * dst->ld, src->u + src_row0 * src->ld, (size_t)nrows * dst->ld * sizeof(double),
+                                   hipMemcpyDeviceToDevice, dst->stream));
+    else
+        HIPCHK(dst, hipMemcpy2DAsync(dst->u + dst_row0 * dst->ld, (size_t)dst->ld * sizeof(double), src->u + src_row0 * src->ld,
+                                     (size_t)src->ld * sizeof(double), (size_t)dst->N * sizeof(double), (size_t)nrows,
+                                     hipMemcpyDeviceToDevice, dst->stream));
     dst->u_checked = false;
     return sync_stream(dst);
 }
