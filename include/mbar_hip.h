@@ -146,9 +146,19 @@ int mbar_ctx_comm_init(mbar_ctx* ctx, const void* id128, int rank, int nranks); 
 typedef int (*mbar_allreduce_fn)(double* buf, int64_t count, int op, void* user);
 /* Replaces an RCCL communicator if one is attached (the two transports never coexist on a context). */
 int mbar_ctx_set_host_allreduce(mbar_ctx* ctx, mbar_allreduce_fn fn, void* user, int rank, int nranks);
-/* Detach whatever transport is attached (RCCL communicator destroyed); the context is single-rank again.  When
+/* Detach whatever transport is attached (RCCL communicator destroyed, in-process group left); the context is single-rank again.  When
  * RCCL cannot be initialised on EVERY rank, every rank must call this before falling back to the host transport. */
 int mbar_ctx_comm_destroy(mbar_ctx* ctx);
+
+/* In-process transport: several contexts of ONE process on ONE device (one caller thread each) all-reduce on their compute
+ * streams -- events across the streams, a rendezvous of the caller threads per collective, no host-device synchronisation.
+ * It drives the same code as an RCCL communicator (collectives on the stream: the device-resident solver loop runs across
+ * the "ranks"), which RCCL itself cannot be made to do on a one-GPU box (it refuses two ranks on one device); results are
+ * summed in rank order on every rank, hence bit-identical across ranks.  nranks <= 8; every rank must issue the same calls. */
+typedef struct mbar_loopback mbar_loopback;
+int mbar_loopback_create(mbar_loopback** out, int nranks);
+void mbar_loopback_destroy(mbar_loopback* group);
+int mbar_ctx_set_loopback(mbar_ctx* ctx, mbar_loopback* group, int rank);
 
 /* ---- L1 evaluation (replaces mbar_solvers.py L1 functions) -------- */
 /* One fused sweep of u_kn for nf (1 or 2) free-energy vectors f[nf][K]:
@@ -179,7 +189,7 @@ typedef struct mbar_solve_result {
     int64_t nr_iter;    /* ... of which Newton-Raphson steps were accepted       */
     int64_t sci_iter;   /* ... of which self-consistent steps were accepted      */
     int32_t success;    /* convergence test of mbar_solvers.py:636 met           */
-    int32_t gram_sweeps; /* separate Gram sweeps executed (fused loop: 1 + rejected speculations)     */
+    int32_t gram_sweeps; /* separate Gram sweeps executed (fused loop: rejected speculations only)     */
     double max_delta;   /* last relative change                                  */
     double gnorm;       /* |g| at the returned f                                 */
     double wall_ms;     /* host wall time of the loop                            */
@@ -188,9 +198,11 @@ typedef struct mbar_solve_result {
 /* Adaptive NR/SCI on the states with N_k > 0 (others are left untouched).  f_inout[K].
  * history (may be NULL): rows of 4 doubles {choice(0 sci,1 nr), |g_sci|, |g_nr|, max_delta}.
  * check_convergence = 0 runs exactly maxiter iterations (benchmarking).
- * Up to 128 states the whole iteration is device-resident (Gram sweep, K x K Newton solve in one workgroup, candidate
- * construction, two-candidate sweep, choice and convergence test; the host reads 8 control words per batch of
- * iterations, replayed from a hipGraph on a single rank, with ncclAllReduce on the stream across ranks).  With the
+ * Up to 128 states the whole iteration is device-resident (K x K Newton solve in one workgroup, candidate construction,
+ * ONE fused sweep for both candidates' gradients and the next Hessian's Gram matrix, choice and convergence test; the host
+ * reads a few control words per batch of iterations, replayed from a hipGraph on a single rank, with ONE ncclAllReduce on
+ * the stream per iteration across ranks; when the accepted candidate is not the one the sweep speculated on, the loop
+ * pauses and the host enqueues that candidate's Gram sweep).  With the
  * host all-reduce transport, above 128 states, or when the device hands a solve back (Newton system not positive
  * definite, candidates > 300 kT apart, non-finite candidate) the same iteration runs host-driven. */
 int mbar_solve_adaptive(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxiter,

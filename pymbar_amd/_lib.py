@@ -75,6 +75,9 @@ SIGNATURES = {
     "mbar_ctx_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "mbar_ctx_set_host_allreduce": (C.c_int, [_ctx, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]),
     "mbar_ctx_comm_destroy": (C.c_int, [_ctx]),
+    "mbar_loopback_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "mbar_loopback_destroy": (None, [C.c_void_p]),
+    "mbar_ctx_set_loopback": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "mbar_eval": (C.c_int, [_ctx, _dp, C.c_int, C.c_uint, _dp, _dp, _dp]),
     "mbar_ctx_set_objective_offset": (C.c_int, [_ctx, _dp]),
     "mbar_lognum": (C.c_int, [_ctx, _dp, _dp]),

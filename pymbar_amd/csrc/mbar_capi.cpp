@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -186,6 +187,26 @@ struct TimerPair {
 
 }  // namespace
 
+// In-process transport: the contexts of several caller threads on ONE device meet in a stream-ordered all-reduce (events
+// across their streams, a rendezvous of the host threads per collective, no host-device synchronisation).  It drives exactly
+// the code a RCCL communicator drives -- the collective sits on the compute stream, so the device-resident loop runs across
+// "ranks" -- and exists so that this code can be tested on a one-GPU box (RCCL refuses two ranks on one device).
+struct mbar_loopback {
+    int nranks = 0, device = -1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    bool broken = false;
+    std::vector<const double*> src;
+    std::vector<int64_t> cnt;
+    std::vector<int> op;
+    std::vector<hipEvent_t> ready, done;
+    std::vector<double*> tmp;
+    std::vector<size_t> tmp_doubles;
+    std::vector<int> attached;
+};
+
 struct mbar_ctx {
     int device = 0;
     int num_cu = 256;
@@ -241,6 +262,7 @@ struct mbar_ctx {
     int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1;
     // comm
     ncclComm_t comm = nullptr;
+    mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
     mbar_allreduce_fn host_reduce = nullptr;
     void* host_reduce_user = nullptr;
     int rank = 0, nranks = 1;
@@ -386,8 +408,77 @@ bool f_is_finite(const mbar_ctx* c, const double* f, int nf) {
 }
 
 // ---- collectives -------------------------------------------------------------------------------
+// a transport whose collective is enqueued on the compute stream (no host in the loop)
+inline bool stream_transport(const mbar_ctx* c) { return c->comm != nullptr || c->loop != nullptr; }
+
+bool loop_barrier(mbar_loopback* g) {  // rendezvous of the caller threads; false: a peer never came (or failed)
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->broken) return false;
+    const uint64_t my = g->gen;
+    if (++g->arrived == g->nranks) {
+        g->arrived = 0;
+        ++g->gen;
+        g->cv.notify_all();
+        return true;
+    }
+    if (!g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->gen != my || g->broken; })) {
+        g->broken = true;
+        g->cv.notify_all();
+        return false;
+    }
+    return !g->broken;
+}
+void loop_break(mbar_loopback* g) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->broken = true;
+    g->cv.notify_all();
+}
+int allreduce_loop(mbar_ctx* c, double* dev, int64_t count, int op) {
+    mbar_loopback* g = c->loop;
+    const int r = c->rank;
+#define LOOPCHK(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            loop_break(g);                                                                               \
+            return fail(c, MBAR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+        }                                                                                                \
+    } while (0)
+    if (g->tmp_doubles[r] < (size_t)count) {
+        if (g->tmp[r]) LOOPCHK(cache_free(g->tmp[r]));
+        g->tmp[r] = nullptr;
+        g->tmp_doubles[r] = 0;
+        LOOPCHK(cache_malloc((void**)&g->tmp[r], (size_t)count * sizeof(double)));
+        g->tmp_doubles[r] = (size_t)count;
+    }
+    LOOPCHK(hipEventRecord(g->ready[r], c->stream));  // my contribution is complete once this event has happened
+    g->src[r] = dev;
+    g->cnt[r] = count;
+    g->op[r] = op;
+    if (!loop_barrier(g)) return fail(c, MBAR_ERR_COMM, "in-process all-reduce: a peer did not arrive");
+    LoopSrc ls;
+    ls.n = g->nranks;
+    for (int q = 0; q < g->nranks; ++q) {
+        if (g->cnt[q] != count || g->op[q] != op) {
+            loop_break(g);
+            return fail(c, MBAR_ERR_COMM, "in-process all-reduce: the ranks disagree on the collective (count / operation)");
+        }
+        ls.p[q] = g->src[q];
+        if (q != r) LOOPCHK(hipStreamWaitEvent(c->stream, g->ready[q], 0));
+    }
+    LOOPCHK(launch_loop_reduce(c->stream, ls, count, op, g->tmp[r]));  // rank order on every rank: bit-identical results
+    LOOPCHK(hipEventRecord(g->done[r], c->stream));
+    if (!loop_barrier(g)) return fail(c, MBAR_ERR_COMM, "in-process all-reduce: a peer did not arrive");
+    for (int q = 0; q < g->nranks; ++q)  // nobody overwrites its buffer before everybody has read it
+        if (q != r) LOOPCHK(hipStreamWaitEvent(c->stream, g->done[q], 0));
+    LOOPCHK(hipMemcpyAsync(dev, g->tmp[r], (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+#undef LOOPCHK
+    return MBAR_OK;
+}
+
 int allreduce_dev(mbar_ctx* c, double* dev, int64_t count, int op) {
     if (c->nranks <= 1 && !c->comm) return MBAR_OK;
+    if (c->loop) return allreduce_loop(c, dev, count, op);
     if (c->comm) {
         ncclResult_t r = g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax,
                                           c->comm, c->stream);
@@ -410,7 +501,7 @@ int allreduce_dev(mbar_ctx* c, double* dev, int64_t count, int op) {
 }
 int allreduce_host(mbar_ctx* c, double* host, int64_t count, int op) {
     if (c->nranks <= 1 && !c->comm) return MBAR_OK;
-    if (c->host_reduce && !c->comm) {
+    if (c->host_reduce && !stream_transport(c)) {
         if (c->host_reduce(host, count, op, c->host_reduce_user) != 0)
             return fail(c, MBAR_ERR_COMM, "host all-reduce callback failed");
         return MBAR_OK;
@@ -1075,7 +1166,7 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
 // enqueued past convergence are no-ops (every kernel looks at CTL_DONE first).
 bool device_loop_eligible(const mbar_ctx* c) {
     if (!c->opt_device_loop || !use_fast(c) || c->Kp > 128) return false;
-    if (c->nranks > 1 && !c->comm) return false;  // the host transport needs the host in the loop
+    if (c->nranks > 1 && !stream_transport(c)) return false;  // the host transport needs the host in the loop
     if (c->Kp == 128 && gram_variant_for(c) != 2) return false;
     const int64_t ntiles = (c->N + TS - 1) / TS;
     const LaunchGeom gl = lse_geometry((int)(c->Kp / 16), 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
@@ -1105,6 +1196,18 @@ int ensure_ad(mbar_ctx* c, int64_t hist_rows) {
     return MBAR_OK;
 }
 
+// A decision that changes the SEQUENCE of collectives (which sweeps run, which buffers are reduced) must be the same on every
+// rank, or the ranks wait for each other in different all-reduces: `ok` is MIN-reduced over the ranks (a collective itself:
+// every rank calls it at the same point whatever its local outcome).
+int agree_all_ok(mbar_ctx* c, bool& ok) {
+    if (c->nranks <= 1) return MBAR_OK;
+    double v = ok ? 0.0 : 1.0;
+    int rc = allreduce_host(c, &v, 1, 1);
+    if (rc) return rc;
+    ok = !(v > 0.0);
+    return MBAR_OK;
+}
+
 // Returns MBAR_OK with handed_back = true when the loop stopped early for the host loop to continue (f, res updated).
 int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t maxiter, int64_t min_sc_iter, double gamma,
                          int check_convergence, double* history, int64_t history_rows, mbar_solve_result& res,
@@ -1116,24 +1219,37 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const bool dma = c->opt_staging == 0;
     handed_back = false;
     psum.assign(K, 0.0);
-    int rc = ensure_ad(c, history ? history_rows : 0);
-    if (rc) return rc;
-    // P mode: the sweeps run on the resident probability matrix (one more K x N array); if it does not fit, or with
-    // register staging, the classic sweeps on u are used
+    // ---- buffers.  Every allocation of the solve happens here, and the ranks agree on the outcome before the first sweep:
+    // a rank that could not get its buffers (or its resident probability matrix) must not wander off into a different
+    // sequence of collectives than its peers.
+    // P mode: the sweeps run on the resident probability matrix (one more K x N array); if it does not fit ON ANY RANK, or with
+    // register staging, every rank runs the classic sweeps on u.
     bool pmode = c->opt_pmode && dma && !c->P_failed;
-    if (pmode && !c->P) {
-        rc = drop_graphs(c);
-        if (rc) return rc;
-        if (cache_malloc((void**)&c->P, (size_t)Kp * c->ld * sizeof(double)) != hipSuccess) {
-            (void)hipGetLastError();
-            c->P = nullptr;
-            c->P_failed = true;
-            pmode = false;
-        } else {
-            HIPCHK(c, hipMemsetAsync(c->P, 0, (size_t)Kp * c->ld * sizeof(double), c->stream));
+    int arc = ensure_ad(c, history ? history_rows : 0);
+    if (!arc && pmode && !c->P) {
+        arc = drop_graphs(c);
+        if (!arc) {
+            if (cache_malloc((void**)&c->P, (size_t)Kp * c->ld * sizeof(double)) != hipSuccess) {
+                (void)hipGetLastError();
+                c->P = nullptr;
+                c->P_failed = true;
+                pmode = false;
+            } else if (hipMemsetAsync(c->P, 0, (size_t)Kp * c->ld * sizeof(double), c->stream) != hipSuccess) {
+                arc = fail(c, MBAR_ERR_HIP, "hipMemsetAsync(P) failed");
+            }
         }
     }
-    if (pmode && !c->pm_vec) HIPCHK(c, cache_malloc((void**)&c->pm_vec, (size_t)3 * Kp * sizeof(double)));
+    {
+        bool p_ok = pmode;
+        int rc = agree_all_ok(c, p_ok);
+        if (rc) return rc;
+        if (pmode && !p_ok) {  // a peer has no room for its P: classic sweeps everywhere (this rank keeps its array for later)
+            pmode = false;
+            c->error = "resident probability matrix does not fit on every rank: classic sweeps";
+        }
+    }
+    if (!arc && pmode && !c->pm_vec && cache_malloc((void**)&c->pm_vec, (size_t)3 * Kp * sizeof(double)) != hipSuccess)
+        arc = fail(c, MBAR_ERR_HIP, "allocation of the P-mode vectors failed");
     const bool fused = pmode && c->opt_fused;
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
@@ -1150,31 +1266,36 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const size_t rec_g = (size_t)nb * (nb + 1) / 2 * 256;
     const size_t rec_l = (size_t)2 * Kp;
     const size_t off_gram = rec_l + 2;
-    rc = ensure_red(c, off_gram + rec_g);
-    if (rc) return rc;
-    rc = ensure(c, &c->part, &c->part_doubles,
-                std::max(std::max((size_t)gg.nwaves * rec_g, (size_t)gl.nwaves * (rec_l + 2)), (size_t)gb.nwaves * Kp));
-    if (rc) return rc;
-    rc = ensure(c, &c->scratch, &c->scratch_doubles,
-                std::max(std::max(((size_t)gg.nwaves / 32 + 1) * rec_g, ((size_t)gl.nwaves / 32 + 1) * (rec_l + 2)),
-                         ((size_t)gb.nwaves / 32 + 1) * Kp));
-    if (rc) return rc;
-    if (c->weighted && !c->lden_eff) return fail(c, MBAR_ERR_STATE, "weighted context without its logden buffer");
-    if (fused) {
-        rc = ensure(c, &c->part_g, &c->part_g_doubles, (size_t)gl.nwaves * rec_g);
+    if (!arc) arc = ensure_red(c, off_gram + rec_g);
+    if (!arc)
+        arc = ensure(c, &c->part, &c->part_doubles,
+                     std::max(std::max((size_t)gg.nwaves * rec_g, (size_t)gl.nwaves * (rec_l + 2)), (size_t)gb.nwaves * Kp));
+    // (level-1 scratch of the widest reduction: the fused loop reduces the per-state sums and the Gram records in ONE pair of launches)
+    if (!arc)
+        arc = ensure(c, &c->scratch, &c->scratch_doubles,
+                     std::max(((size_t)std::max(gg.nwaves, gl.nwaves) / 32 + 1) * (rec_g + rec_l + 2), ((size_t)gb.nwaves / 32 + 1) * (Kp + rec_g)));
+    if (!arc && c->weighted && !c->lden_eff) arc = fail(c, MBAR_ERR_STATE, "weighted context without its logden buffer");
+    if (!arc && fused) arc = ensure(c, &c->part_g, &c->part_g_doubles, (size_t)gl.nwaves * rec_g);
+    {
+        bool ok = arc == MBAR_OK;
+        const std::string local_err = c->error;
+        int rc = agree_all_ok(c, ok);
         if (rc) return rc;
+        if (arc) return arc;
+        if (!ok) return fail(c, MBAR_ERR_STATE, "a peer rank could not allocate its solver buffers");
+        c->error = local_err;
     }
+    int rc = MBAR_OK;
     // initial gradient (mbar_solvers.py:570).  Classic: the evaluation sweep, logden(f) stays in slot 0.  P mode: the
     // same sweep also writes P = exp(a0 - u - logden(a0)) with a0 = aden(f) and leaves 1 / s = 1 in slot 0; in the fused
     // loop it accumulates the first Hessian's Gram matrix as well (its reduced blocks wait in `red` for k_newton).
     if (!pmode) {
         rc = eval_core(c, f.data(), 1, 0, c->logden[0], nullptr, psum.data(), nullptr, nullptr);
         if (rc) return rc;
-        rc = ensure_red(c, off_gram + rec_g);  // (eval_core may have re-sized nothing; kept for symmetry)
-        if (rc) return rc;
     } else {
         build_aden(c, f.data(), c->hstage, Kp);
         HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, (size_t)Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->red, 0, off_gram * sizeof(double), c->stream));
         {
             ScopedTimer t(c, MBAR_TIMER_OTHER);
             if (fused)
@@ -1183,15 +1304,16 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             else
                 HIPCHK(c, launch_build_sweep(c->stream, nb, gb, c->u, c->ld, c->N, d_aden(c), c->cw, c->P, c->logden[0], c->part));
         }
-        HIPCHK(c, launch_reduce(c->stream, c->part, gb.nwaves, Kp, c->scratch, c->red));
-        rc = allreduce_dev(c, c->red, Kp, 0);
+        if (fused) {  // per-state sums and the Gram matrix at the anchor: one pair of reduction launches, ONE all-reduce
+            HIPCHK(c, launch_reduce2(c->stream, c->part, Kp, c->part_g, (int64_t)rec_g, gb.nwaves, c->scratch, c->red,
+                                     c->red + off_gram));
+            rc = allreduce_dev(c, c->red, (int64_t)(off_gram + rec_g), 0);
+        } else {
+            HIPCHK(c, launch_reduce(c->stream, c->part, gb.nwaves, Kp, c->scratch, c->red));
+            rc = allreduce_dev(c, c->red, Kp, 0);
+        }
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(c->hred, c->red, (size_t)Kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        if (fused) {  // Gram matrix at the anchor: reduced (and all-reduced) into the slot k_newton reads
-            HIPCHK(c, launch_reduce(c->stream, c->part_g, gb.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
-            rc = allreduce_dev(c, c->red + off_gram, (int64_t)rec_g, 0);
-            if (rc) return rc;
-        }
         rc = sync_stream(c);
         if (rc) return rc;
         for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k];
@@ -1215,6 +1337,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         // its build sweep accumulated (multipliers cgram = 1 at the anchor)
         hi[CTL_NEEDGRAM] = fused ? 0 : 1;
         hi[CTL_GRAMSWEEPS] = 0;
+        hi[CTL_SPEC] = 1;
         hi[CTL_ITER] = (int)res.iterations;
         hi[CTL_SCI] = (int)res.sci_iter;
         hi[CTL_NR] = (int)res.nr_iter;
@@ -1264,10 +1387,14 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     lc_slot.unclamped = lc_flat.unclamped = c->u_checked && !c->u_posinf;
     lc_slot.pmode = lc_flat.pmode = pmode;
 
-    auto enqueue_iteration = [&](bool timed) -> int {
-        // ---- pass A: Gram at f with the known logden (the slot of the accepted candidate) ----
-        const double* lden = c->logden[0];  // (P mode: the slots hold the reciprocals 1 / s_n instead of logden)
+    // Gram sweep at the current f with the known logden (the slot of the accepted candidate; P mode: the slots hold the
+    // reciprocals 1 / s_n instead), reduced and all-reduced into the blocks k_newton reads.  Two-sweep loops: once per
+    // iteration.  Fused loop: only after a pause (k_select found that the accepted candidate is not the one the sweep
+    // speculated on) -- the host enqueues it, un-pausing first.
+    auto enqueue_gram = [&](bool timed) -> int {
+        const double* lden = c->logden[0];
         LoopCtl lca = lc_slot;
+        if (fused) HIPCHK(c, launch_ctl_resume(c->stream, c->ad_ints));
         if (c->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent / the reciprocal
             if (pmode)
                 HIPCHK(c, launch_rinv_weighted(c->stream, c->logden[0], c->cw, c->N, c->lden_eff, lc_slot));
@@ -1282,7 +1409,6 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             if (timed) { tp.a = get_event(c); tp.b = get_event(c); }
             const bool ext = tp.a && tp.b && c->opt_timing == 2;
             if (ext) { lca.ev_start = tp.a; lca.ev_stop = tp.b; }
-            lca.cond_needgram = fused;  // fused-sweep loop: this sweep runs only when the speculated Gram matrix is not the one needed
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
             HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, gram_part,
                                        nullptr, lca));
@@ -1290,12 +1416,21 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             if (tp.a && tp.b) c->pending.push_back(tp);
         }
         HIPCHK(c, launch_reduce(c->stream, gram_part, gg.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
-        if (c->comm) {
+        if (stream_transport(c)) {
             int r2 = allreduce_dev(c, c->red + off_gram, (int64_t)rec_g, 0);
             if (r2) return r2;
         }
+        return MBAR_OK;
+    };
+    // One iteration.  Fused loop: {k_newton, fused sweep, ONE reduction of its per-state sums and Gram records, ONE all-reduce
+    // of both, k_select} -- the Gram matrix the next k_newton needs comes out of the same sweep as the gradients.  Two-sweep
+    // loops: the Gram sweep first.
+    auto enqueue_iteration = [&](bool timed) -> int {
+        if (!fused) {
+            int r2 = enqueue_gram(timed);
+            if (r2) return r2;
+        }
         HIPCHK(c, launch_newton(c->stream, q));
-        // ---- pass B: both candidates in one sweep ----
         double* psum_part = c->part;
         double* obj_part = c->part + (size_t)gl.nwaves * rec_l;
         {
@@ -1317,12 +1452,18 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
             if (tp.a && tp.b) c->pending.push_back(tp);
         }
-        if (pmode)  // (no objective sums in P mode: the adaptive loop does not use them)
+        int64_t ar_count = (int64_t)(rec_l + 2);
+        if (fused) {
+            HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, gram_part, (int64_t)rec_g, gl.nwaves, c->scratch, c->red,
+                                     c->red + off_gram));
+            ar_count = (int64_t)(off_gram + rec_g);
+        } else if (pmode) {  // (no objective sums in P mode: the adaptive loop does not use them)
             HIPCHK(c, launch_reduce(c->stream, psum_part, gl.nwaves, (int64_t)rec_l, c->scratch, c->red));
-        else
+        } else {
             HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, obj_part, 2, gl.nwaves, c->scratch, c->red, c->red + rec_l));
-        if (c->comm) {
-            int r2 = allreduce_dev(c, c->red, (int64_t)(rec_l + 2), 0);
+        }
+        if (stream_transport(c)) {
+            int r2 = allreduce_dev(c, c->red, ar_count, 0);
             if (r2) return r2;
         }
         HIPCHK(c, launch_select(c->stream, q));
@@ -1330,16 +1471,16 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     };
 
     // Batches between two looks at the control words: 6, 2, 4, then `adapt_batch` (8) each.  Iterations enqueued past convergence
-    // are no-ops of ~3.5 us per kernel; real solves take 5-8 iterations, and for the small problems pymbar is mostly used on
-    // (config 5: 62 us per iteration) two wasted iterations of a fixed batch of 8 were a tenth of the solve.  Only full-size
-    // batches replay a captured hipGraph (eager launches are as fast at these kernel counts: the queue never runs dry), so a
-    // short solve never pays for a capture.
+    // (or past a pause of the fused loop) are no-ops of ~3.5 us per kernel; real solves take 5-8 iterations, and for the small
+    // problems pymbar is mostly used on two wasted iterations of a fixed batch of 8 were a tenth of the solve.  After a pause the
+    // batches restart at 1, 2, 4: a phase in which the self-consistent candidate keeps winning pauses every iteration.  Only
+    // full-size batches replay a captured hipGraph (eager launches are as fast at these kernel counts: the queue never runs
+    // dry), so a short solve never pays for a capture.
     const int64_t batch = c->opt_adapt_batch;
-    const bool use_graph = c->opt_graph && !c->comm;
+    const bool use_graph = c->opt_graph && !stream_transport(c);
     auto prepare_graph = [&]() -> int {
-
         const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 12) ^ (pmode ? 128 : 0) ^ (fused ? 256 : 0) ^
-                            (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (int64_t)nb;
+                            (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (lc_slot.unclamped ? 512 : 0) ^ (int64_t)nb;
         if (!c->ad_graph || c->ad_graph_batch != batch || c->ad_graph_sig != sig) {
             if (c->ad_graph) HIPCHK(c, hipGraphExecDestroy(c->ad_graph));
             c->ad_graph = nullptr;
@@ -1370,11 +1511,13 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     int64_t it = res.iterations;
     const int64_t it_start = it;
     bool done = false;
-    int64_t nbatch = 0;
+    int64_t nbatch = 0, ramp = batch;  // ramp: cap on the batch size while recovering from a pause
+    int32_t gram_sweeps = 0;
     while (it < maxiter && !done) {
         static const int64_t first_batches[3] = {6, 2, 4};
-        const int64_t want = nbatch < 3 ? std::min(batch, first_batches[nbatch]) : batch;
+        const int64_t want = std::min(ramp, nbatch < 3 ? std::min(batch, first_batches[nbatch]) : batch);
         ++nbatch;
+        ramp = std::min(batch, ramp * 2);
         const int64_t nbat = std::min(want, maxiter - it);
         if (use_graph && nbat == batch) {
             rc = prepare_graph();
@@ -1396,6 +1539,16 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         } else if (c->h_ctl[CTL_DONE] == 2) {
             handed_back = true;
             done = true;
+        } else if (c->h_ctl[CTL_DONE] == 3) {
+            // the fused loop paused itself after iteration it_new (the rest of the batch were no-ops): the accepted candidate's
+            // Gram matrix has to be swept separately.  Every rank sees the same control words, so every rank comes by here.
+            if (it_new <= it || it_new > it + nbat) return fail(c, MBAR_ERR_STATE, "device-resident adaptive loop lost count of its iterations");
+            if (it_new < maxiter) {
+                rc = enqueue_gram(c->opt_timing != 0);
+                if (rc) return rc;
+                ++gram_sweeps;
+                ramp = 1;
+            }
         } else if (it_new != it + nbat) {
             return fail(c, MBAR_ERR_STATE, "device-resident adaptive loop lost count of its iterations");
         }
@@ -1405,9 +1558,11 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     {
         std::vector<double> h(ad_off_hist(c));
         HIPCHK(c, hipMemcpyAsync(h.data(), c->ad, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        const int64_t rows = history ? std::min<int64_t>(std::min<int64_t>(it, history_rows), c->ad_hist_cap) : 0;
-        if (rows > 0)
-            HIPCHK(c, hipMemcpyAsync(history, c->ad + ad_off_hist(c), (size_t)rows * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        // (only the rows of the iterations that ran HERE: after a hand-back the host loop wrote rows of its own in between)
+        const int64_t row1 = history ? std::min<int64_t>(std::min<int64_t>(it, history_rows), c->ad_hist_cap) : 0;
+        if (row1 > it_start)
+            HIPCHK(c, hipMemcpyAsync(history + 4 * it_start, c->ad + ad_off_hist(c) + 4 * it_start, (size_t)(row1 - it_start) * 4 * sizeof(double),
+                                     hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (int64_t k = 0; k < K; ++k) {
             f[k] = h[ad_off_f(c) + k];
@@ -1418,9 +1573,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     res.iterations = it;
     res.sci_iter = c->h_ctl[CTL_SCI];
     res.nr_iter = c->h_ctl[CTL_NR];
-    // (a sweep requested by the very last iteration was never run)
-    res.gram_sweeps += fused ? c->h_ctl[CTL_GRAMSWEEPS] - (c->h_ctl[CTL_NEEDGRAM] && c->h_ctl[CTL_DONE] != 2 ? 1 : 0)
-                             : (int32_t)(it - it_start);
+    res.gram_sweeps += fused ? gram_sweeps : (int32_t)(it - it_start);
     if (handed_back) {
         static const char* why[] = {"", "the Newton system is not positive definite", "a candidate is too far from the point the sweeps are anchored at",
                                     "a candidate is not finite"};
@@ -1830,6 +1983,7 @@ int mbar_comm_unique_id(void* id128) {
 
 int mbar_ctx_comm_init(mbar_ctx* c, const void* id128, int rank, int nranks) {
     if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MBAR_ERR_ARG, "bad argument");
+    if (c->loop) return fail(c, MBAR_ERR_STATE, "the context has an in-process transport (mbar_ctx_comm_destroy first)");
     std::string err;
     if (!g_rccl.load(err)) return fail(c, MBAR_ERR_COMM, err);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1847,12 +2001,62 @@ int mbar_ctx_comm_init(mbar_ctx* c, const void* id128, int rank, int nranks) {
     return MBAR_OK;
 }
 
+int mbar_loopback_create(mbar_loopback** out, int nranks) {
+    if (!out || nranks < 1 || nranks > 8) return fail(nullptr, MBAR_ERR_ARG, "mbar_loopback_create: 1 <= nranks <= 8");
+    mbar_loopback* g = new mbar_loopback();
+    g->nranks = nranks;
+    g->src.assign(nranks, nullptr);
+    g->cnt.assign(nranks, 0);
+    g->op.assign(nranks, 0);
+    g->ready.assign(nranks, nullptr);
+    g->done.assign(nranks, nullptr);
+    g->tmp.assign(nranks, nullptr);
+    g->tmp_doubles.assign(nranks, 0);
+    g->attached.assign(nranks, 0);
+    *out = g;
+    return MBAR_OK;
+}
+
+void mbar_loopback_destroy(mbar_loopback* g) {
+    if (!g) return;
+    if (g->device >= 0) (void)hipSetDevice(g->device);
+    for (auto e : g->ready) if (e) (void)hipEventDestroy(e);
+    for (auto e : g->done) if (e) (void)hipEventDestroy(e);
+    for (auto t : g->tmp) if (t) (void)cache_free(t);
+    delete g;
+}
+
+int mbar_ctx_set_loopback(mbar_ctx* c, mbar_loopback* g, int rank) {
+    if (!c || !g || rank < 0 || rank >= g->nranks) return fail(c, MBAR_ERR_ARG, "bad argument");
+    if (c->comm || c->host_reduce || c->loop) return fail(c, MBAR_ERR_STATE, "the context already has a transport (mbar_ctx_comm_destroy first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (g->device >= 0 && g->device != c->device) return fail(c, MBAR_ERR_ARG, "in-process transport: all contexts must be on one device");
+        if (g->attached[rank]) return fail(c, MBAR_ERR_ARG, "in-process transport: rank already taken");
+        g->device = c->device;
+        g->attached[rank] = 1;
+    }
+    HIPCHK(c, hipEventCreateWithFlags(&g->ready[rank], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming));
+    c->loop = g;
+    c->rank = rank;
+    c->nranks = g->nranks;
+    c->u_checked = false;
+    return drop_graphs(c);
+}
+
 int mbar_ctx_comm_destroy(mbar_ctx* c) {
     if (!c) return fail(c, MBAR_ERR_ARG, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     c->comm = nullptr;
+    if (c->loop) {
+        std::lock_guard<std::mutex> lk(c->loop->mu);
+        c->loop->attached[c->rank] = 0;
+    }
+    c->loop = nullptr;
     c->host_reduce = nullptr;
     c->host_reduce_user = nullptr;
     c->rank = 0;
@@ -1863,6 +2067,7 @@ int mbar_ctx_comm_destroy(mbar_ctx* c) {
 
 int mbar_ctx_set_host_allreduce(mbar_ctx* c, mbar_allreduce_fn fn, void* user, int rank, int nranks) {
     if (!c || nranks < 1 || rank < 0 || rank >= nranks || (!fn && nranks > 1)) return fail(c, MBAR_ERR_ARG, "bad argument");
+    if (c->loop) return fail(c, MBAR_ERR_STATE, "the context has an in-process transport (mbar_ctx_comm_destroy first)");
     if (c->comm) {
         // the host transport REPLACES an RCCL communicator: a rank that kept issuing ncclAllReduce while its peers
         // reduce on the host would deadlock every later sweep

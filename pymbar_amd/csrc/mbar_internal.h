@@ -30,7 +30,9 @@ inline int lse_nb_for(int64_t Kp) {
 // replayed from a hipGraph -- without the host knowing which candidate the previous one accepted.
 enum : int {
     CTL_SLOT = 0,    // logden slot of the current f
-    CTL_DONE = 1,    // 0 = running, 1 = converged, 2 = handed back to the host (CTL_REASON says why)
+    CTL_DONE = 1,    // 0 = running, 1 = converged, 2 = handed back to the host (CTL_REASON says why), 3 = fused loop paused:
+                     // the accepted candidate is not the one whose Gram matrix the sweep speculated on, the host enqueues
+                     // the separate Gram sweep and resumes
     CTL_ITER = 2,    // iterations executed
     CTL_SCI = 3,     // ... of which self-consistent steps were accepted
     CTL_NR = 4,      // ... of which Newton-Raphson steps were accepted
@@ -38,7 +40,10 @@ enum : int {
                      // 3 = non-finite candidate
     CTL_NEEDGRAM = 6,  // fused sweep: 1 = the accepted candidate's Gram matrix is NOT the speculated one: run the Gram sweep
     CTL_GRAMSWEEPS = 7,  // separate Gram sweeps requested so far
-    CTL_WORDS = 8
+    CTL_SPEC = 8,    // fused sweep: candidate whose Gram matrix the sweep accumulates (always the SECOND multiplier row it is
+                     // handed): 1 = Newton-Raphson (default), 0 = self-consistent (while self-consistent steps are forced,
+                     // mbar_solvers.py:607 `sci_iter < min_sc_iter`: k_newton then hands the two rows over in swapped order)
+    CTL_WORDS = 12
 };
 struct LoopCtl {
     const int* ctl = nullptr;
@@ -138,6 +143,13 @@ hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink);
 hipError_t launch_reduce2(hipStream_t s, const double* partA, int64_t countA, const double* partB, int64_t countB,
                           int64_t nparts, double* scratch, double* outA, double* outB);
 
+// In-process all-reduce (several contexts of one process on one device): out[i] = op over the ranks' buffers, in rank order
+struct LoopSrc {
+    const double* p[8];
+    int n;
+};
+hipError_t launch_loop_reduce(hipStream_t s, const LoopSrc& src, int64_t count, int op /*0 sum, 1 max*/, double* out);
+
 // ---- device-resident adaptive iteration (mbar_solvers.py:575-640 without the host in the loop) --------------------
 // State of one solve, all in device memory.  Up to 128 padded states (one diagonal Gram panel).
 struct AdaptArgs {
@@ -195,5 +207,7 @@ hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double*
 hipError_t launch_newton(hipStream_t s, const AdaptArgs& a);
 // gradient norms of both candidates, choice (mbar_solvers.py:607), convergence test (:627-640), next Gram operand
 hipError_t launch_select(hipStream_t s, const AdaptArgs& a);
+// fused loop paused by k_select (CTL_DONE = 3): clear the pause and the Gram request (in front of the Gram sweep)
+hipError_t launch_ctl_resume(hipStream_t s, int* ctl);
 
 }  // namespace mbar

@@ -3073,6 +3073,12 @@ k_newton(AdaptArgs q) {
     const int first = smp[0];
     const double shift = s_f[first] - log(s_ps[first] / s_nk[first]);
     int flags = bad ? 1 : 0;
+    // Fused sweep: the Gram matrix it accumulates is that of the SECOND multiplier row.  While self-consistent steps are
+    // forced (:607, sci_iter < min_sc_iter) that row is the self-consistent candidate's -- the one that WILL be accepted --
+    // so that the speculation is never thrown away (the reference's default min_sc_iter = 2 cost two extra sweeps before).
+    const bool swap = q.fused && q.ctl[CTL_SCI] < (int)q.prm[2];
+    const int o_sci = swap ? q.Kp : 0, o_nr = swap ? 0 : q.Kp;
+    if (tid == 0) q.ctl[CTL_SPEC] = swap ? 0 : 1;
     for (int k = tid; k < q.Kp; k += NT) {
         const bool sampled = k < q.K && s_nk[k] > 0.0;
         const double fk = s_f[k];
@@ -3102,8 +3108,8 @@ k_newton(AdaptArgs q) {
         q.cand[k] = fs;
         q.cand[q.Kp + k] = fn;
         q.ratio[k] = rt;
-        q.aden[k] = a0;
-        q.aden[q.Kp + k] = rt;
+        q.aden[o_sci + k] = a0;
+        q.aden[o_nr + k] = rt;
     }
     flags = __syncthreads_or(flags);
     if (flags != 0 && tid == 0) {
@@ -3143,11 +3149,14 @@ k_select(AdaptArgs q) {
     const double nk = in ? q.Nk[tid] : 0.0;
     const bool sampled = in && tid < q.K && nk > 0.0;
     // the sweeps accumulate UNSCALED per-state sums: times the candidate's per-state constant = its psum
-    // (classic: ratio c_k of the second candidate only; P mode: exp(a - a0) of both, kept in aden)
-    const double m0 = (in && q.pmode) ? q.aden[tid] : 1.0;
-    const double m1 = in ? (q.pmode ? q.aden[Kp + tid] : q.ratio[tid]) : 0.0;
-    const double ps0 = in ? q.lse_red[tid] * m0 : 0.0;
-    const double ps1 = in ? q.lse_red[Kp + tid] * m1 : 0.0;
+    // (classic: ratio c_k of the second candidate only; P mode: exp(a - a0) of both, kept in aden).  Index 0 = the
+    // self-consistent candidate, 1 = Newton-Raphson; the fused sweep may have been handed them in swapped order (CTL_SPEC).
+    const bool swap = q.fused && ctl[CTL_SPEC] == 0;
+    const int o_sci = swap ? Kp : 0, o_nr = swap ? 0 : Kp;
+    const double m0 = (in && q.pmode) ? q.aden[o_sci + tid] : 1.0;
+    const double m1 = in ? (q.pmode ? q.aden[o_nr + tid] : q.ratio[tid]) : 0.0;
+    const double ps0 = in ? q.lse_red[o_sci + tid] * m0 : 0.0;
+    const double ps1 = in ? q.lse_red[o_nr + tid] * m1 : 0.0;
     const double fo = in ? q.f[tid] : 0.0, fs = in ? q.cand[tid] : 0.0, fn = in ? q.cand[Kp + tid] : 0.0;
     const double lnk = in ? q.lnNk[tid] : 0.0;
     const double ga = sampled ? ps0 - nk : 0.0, gb = sampled ? ps1 - nk : 0.0;
@@ -3175,8 +3184,9 @@ k_select(AdaptArgs q) {
     // Fused sweep: the Gram matrix of the Newton-Raphson candidate is already there.  It serves the next iteration when
     // that candidate was accepted -- or when the two candidates coincide to 1e-10 (at the fixed point the choice is
     // round-off noise; the Hessian of one is the Hessian of the other far below any tolerance it is used at).
-    const bool reuse = q.fused && (ch == 1 || max_diff <= 1e-10);
-    if (q.fused && in) q.cgram[tid] = reuse ? m1 : (ch == 0 ? m0 : m1);
+    const int spec = swap ? 0 : 1;  // the candidate the sweep speculated on
+    const bool reuse = q.fused && (ch == spec || max_diff <= 1e-10);
+    if (q.fused && in) q.cgram[tid] = (reuse ? spec : ch) == 0 ? m0 : m1;
     if (tid == 0) {
         const int it = ctl[CTL_ITER];
         if (it < q.hist_cap) {
@@ -3189,12 +3199,33 @@ k_select(AdaptArgs q) {
         const bool stop = check && (max_delta != max_delta || (max_delta < tol && max_diff < sqrt(tol)));  // :636
         ctl[CTL_ITER] = it + 1;
         if (ch == 0) ctl[CTL_SCI] += 1; else ctl[CTL_NR] += 1;
-        ctl[CTL_SLOT] = (ctl[CTL_SLOT] + (ch == 0 ? 1 : 2)) % 3;
+        // (the sweep wrote the reciprocals of its first multiplier row to slot + 1, of its second to slot + 2)
+        ctl[CTL_SLOT] = (ctl[CTL_SLOT] + ((ch == 0) != swap ? 1 : 2)) % 3;
         if (q.fused) {
             ctl[CTL_NEEDGRAM] = reuse ? 0 : 1;
             if (!reuse) ctl[CTL_GRAMSWEEPS] += 1;
         }
-        if (stop) ctl[CTL_DONE] = 1;
+        if (stop)
+            ctl[CTL_DONE] = 1;
+        else if (q.fused && !reuse)
+            ctl[CTL_DONE] = 3;  // pause: the host enqueues the Gram sweep of the accepted candidate (same flags on every rank)
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_loop_reduce(LoopSrc src, int64_t count, int op, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double v = src.p[0][i];
+    for (int r = 1; r < src.n; ++r) v = op == 0 ? v + src.p[r][i] : fmax(v, src.p[r][i]);
+    out[i] = v;
+}
+
+// Fused loop, resumed after a pause (CTL_DONE = 3): the host enqueues this in front of the accepted candidate's Gram sweep.
+__global__ void k_ctl_resume(int* ctl) {
+    if (threadIdx.x == 0 && ctl[CTL_DONE] == 3) {
+        ctl[CTL_DONE] = 0;
+        ctl[CTL_NEEDGRAM] = 0;
     }
 }
 
@@ -3804,6 +3835,17 @@ hipError_t launch_newton(hipStream_t s, const AdaptArgs& a) {
         hipLaunchKernelGGL((k_newton<16, 4>), dim3(1), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((k_newton<16, 8>), dim3(1), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_loop_reduce(hipStream_t s, const LoopSrc& src, int64_t count, int op, double* out) {
+    if (count < 1 || src.n < 1 || src.n > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_loop_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src, count, op, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_ctl_resume(hipStream_t s, int* ctl) {
+    hipLaunchKernelGGL(k_ctl_resume, dim3(1), dim3(64), 0, s, ctl);
     return hipGetLastError();
 }
 

@@ -203,6 +203,13 @@ class DeviceMatrix:
         self._check(self._lib.mbar_ctx_set_host_allreduce(self._ctx, self._cb, None, rank, nranks))
         self.rank, self.nranks, self.allreduce_kind = rank, nranks, "host"
 
+    def set_loopback(self, group, rank):
+        """Join the in-process transport ``group`` (:class:`LoopbackGroup`) as ``rank``: collectives run on the compute stream
+        like RCCL's, between contexts of this process on one device (one caller thread per context)."""
+        self._check(self._lib.mbar_ctx_set_loopback(self._ctx, group._h, int(rank)))
+        self._loop = group  # (keeps the group alive)
+        self.rank, self.nranks, self.allreduce_kind = int(rank), group.nranks, "loopback"
+
     def comm_destroy(self):
         """Detach the cross-rank transport (destroys an RCCL communicator); the matrix is single-rank again."""
         self._check(self._lib.mbar_ctx_comm_destroy(self._ctx))
@@ -309,6 +316,27 @@ class DeviceMatrix:
         t = C.c_double(0.0)
         self._check(self._lib.mbar_mfma_f64_peak(self._ctx, C.byref(t)))
         return t.value
+
+
+class LoopbackGroup:
+    """``mbar_loopback``: stream-ordered all-reduce between the contexts of several threads of this process on one GPU."""
+
+    def __init__(self, nranks):
+        self._lib = _lib.load_library()
+        self.nranks = int(nranks)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.mbar_loopback_create(C.byref(self._h), self.nranks))
+
+    def close(self):
+        if self._h:
+            self._lib.mbar_loopback_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def device_info(device=0):

@@ -51,8 +51,13 @@ def _send_msg(sock, payload):
     sock.sendall(struct.pack("<q", len(payload)) + payload)
 
 
+_MAX_MSG = 64 << 20  # the largest legitimate message is a Gram all-reduce of a few MB
+
+
 def _recv_msg(sock):
     (n,) = struct.unpack("<q", _recv_exact(sock, 8))
+    if n < 0 or n > _MAX_MSG:  # a peer that is not one of ours (or a desynchronised stream): never allocate on its say-so
+        raise ConnectionError(f"rendezvous: implausible message length {n}")
     return _recv_exact(sock, n) if n else b""
 
 
@@ -66,9 +71,13 @@ class HostGroup:
     Port: the launcher's ``MASTER_PORT`` usually belongs to the launcher's own store (the elastic launcher keeps it
     bound), so rank 0 binds the first free port in ``[base, base + 24)`` with ``base = MASTER_PORT + 1``
     (or ``MBAR_RDZV_PORT``) and the clients probe the same range; a handshake token derived from the launch
-    (address, port, run id, world size) tells this group's hub from anything else listening there."""
+    (address, port, run id, world size -- plus ``MBAR_RDZV_SECRET`` when the launcher exports one, which ``bench.py``'s own
+    spawner does with a random value) tells this group's hub from anything else listening there.  Rank 0 binds the interface
+    of ``MASTER_ADDR`` only (loopback for a single node), never the wildcard address.  ``timeout`` bounds the rendezvous;
+    once the group stands, a collective may wait ``data_timeout`` (default one hour) for a slow peer -- ranks skew by minutes
+    when one of them uploads tens of GB first."""
 
-    def __init__(self, rank, world, addr="127.0.0.1", base_port=29501, token="", timeout=120.0):
+    def __init__(self, rank, world, addr="127.0.0.1", base_port=29501, token="", timeout=120.0, data_timeout=3600.0):
         self.rank, self.world = int(rank), int(world)
         self._socks = {}     # rank 0: peer rank -> socket
         self._sock = None    # other ranks: socket to rank 0
@@ -78,8 +87,10 @@ class HostGroup:
         tok = hashlib.sha256(f"{token}|{self.world}".encode()).digest()[:16]
         deadline = time.time() + timeout
         if self.rank == 0:
-            bind_addr = addr if addr in ("127.0.0.1", "localhost", "::1") else ""
-            if bind_addr == "localhost":
+            bind_addr = "127.0.0.1" if addr in ("localhost", "::1") else addr
+            try:
+                bind_addr = socket.gethostbyname(bind_addr)  # the interface MASTER_ADDR names, not 0.0.0.0
+            except OSError:
                 bind_addr = "127.0.0.1"
             last = None
             for port in range(base_port, base_port + _PORT_SPAN):
@@ -112,7 +123,7 @@ class HostGroup:
                         conn.close()
                         continue
                     conn.sendall(b"OK")
-                    conn.settimeout(timeout)
+                    conn.settimeout(data_timeout)
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     self._socks[peer] = conn
                 except (OSError, ConnectionError, struct.error):
@@ -130,7 +141,7 @@ class HostGroup:
                         s.settimeout(3.0)
                         s.sendall(hello)
                         if _recv_exact(s, 2) == b"OK":
-                            s.settimeout(timeout)
+                            s.settimeout(data_timeout)
                             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                             self._sock = s
                             break
@@ -150,7 +161,7 @@ class HostGroup:
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         mport = int(os.environ.get("MASTER_PORT", "29500"))
         base = int(os.environ.get("MBAR_RDZV_PORT", mport + 1))
-        token = f"{addr}:{mport}:{os.environ.get('TORCHELASTIC_RUN_ID', '')}"
+        token = f"{addr}:{mport}:{os.environ.get('TORCHELASTIC_RUN_ID', '')}:{os.environ.get('MBAR_RDZV_SECRET', '')}"
         return cls(rank, world, addr=addr, base_port=base, token=token, timeout=timeout)
 
     # ---- collectives -----------------------------------------------------------------------------------

@@ -84,23 +84,30 @@ class MBAR:
     """Multistate Bennett acceptance ratio estimator; free energies are solved on construction.
 
     Parameters follow pymbar/mbar.py:85-99.  ``u_kn`` is (K, N) [or (K, L, N_max) ``u_kln``];
-    ``N_k`` (K,) may contain zeros.  Extra keyword: ``device`` selects the GPU."""
+    ``N_k`` (K,) may contain zeros.  Extra keywords: ``device`` selects the GPU; ``copy=False`` keeps a read-only reference to a
+    float64 C-contiguous ``u_kn`` instead of the reference's host copy (the caller must then leave the array alone)."""
 
     def __init__(self, u_kn, N_k, maximum_iterations=10000, relative_tolerance=1.0e-7, verbose=False,
                  initial_f_k=None, solver_protocol=None, initialize="zeros", x_kindices=None, n_bootstraps=0,
-                 bootstrap_solver_protocol=None, rseed=None, device=None):
+                 bootstrap_solver_protocol=None, rseed=None, device=None, copy=True):
         from .device import DeviceMatrix
 
         self.N_k = np.array(N_k, dtype=np.int64)
         self.N = int(np.sum(self.N_k))
         if len(np.shape(u_kn)) == 3:
             u_kn = kln_to_kn(u_kn, N_k=self.N_k)
-        # The OWNED copy of the matrix is the device-resident one (uploaded below, kept for the object's lifetime).  On
-        # the host ``self.u_kn`` REFERENCES the caller's array when it already is a float64 C-contiguous ndarray (the
-        # reference makes a second host copy here, mbar.py:243 -- 10 GB and several seconds at K=128, N=1e7); it is
-        # only read again by initialize="BAR" / "mean-reduced-potential", the verbose same-state scan and as the
-        # default ``u_kn`` of the expectation family, never written.
-        self.u_kn = np.ascontiguousarray(u_kn, dtype=np.float64)
+        # Like the reference (mbar.py:243) the object keeps its OWN host copy of the matrix by default: the device copy is
+        # frozen at construction, and a caller who goes on to modify or recycle the array must not make the two diverge (the
+        # host copy is read again by initialize="BAR" in the bootstrap loop, by "mean-reduced-potential" and as the default
+        # ``u_kn`` / ``A_n`` of the expectation family).  ``copy=False`` (extension; for matrices of many GB, where a second host
+        # copy is 10 GB and seconds) REFERENCES a float64 C-contiguous input instead, through a read-only view.
+        if copy:
+            self.u_kn = np.array(u_kn, dtype=np.float64)
+        else:
+            self.u_kn = np.ascontiguousarray(u_kn, dtype=np.float64)
+            if self.u_kn is u_kn or self.u_kn.base is not None:
+                self.u_kn = self.u_kn.view()
+                self.u_kn.setflags(write=False)
         if self.u_kn.ndim != 2:
             raise ParameterError("u_kn must be a K x N (or K x L x N_max) array.")
         K, N = self.u_kn.shape

@@ -6,8 +6,8 @@ matrix runs in ``libmbar_hip.so`` on the GPU (include/mbar_hip.h).  There is no 
 a machine without the library or without a gfx950 device these functions raise
 ``pymbar_amd._lib.BackendUnavailable``.
 
-``u_kn`` may be a numpy array (uploaded for the duration of the call, like the reference's jitted
-functions re-send it, pymbar/mbar_solvers.py:255-257) or a resident
+``u_kn`` may be a numpy array (uploaded on first sight and kept in a small cache of device copies, so that the reference's
+unchanged ``MBAR`` class uploads its matrix once per object, not once per call -- see ``_ResidentCache``) or a resident
 :class:`pymbar_amd.device.DeviceMatrix` (or any object with the same methods: the tests drive the
 protocol logic below with a CPU stand-in built from the oracle).
 
@@ -72,9 +72,82 @@ def _is_handle(u_kn):
     return hasattr(u_kn, "eval") and hasattr(u_kn, "set_Nk")
 
 
+class _ResidentCache:
+    """Device copies of recently used HOST matrices, so that the literal drop-in -- the reference's unchanged ``MBAR`` class,
+    which calls this module several times with the same ``self.u_kn`` (mbar.py:413 ``solve_mbar_for_all_states``, :455
+    ``mbar_log_W_nk``, :910 again per expectation) -- uploads the matrix ONCE instead of once per call.
+
+    A host array is recognised by (address, shape, strides) AND a digest of 4096 elements spread evenly over it plus its first
+    and last row: the array object may have been freed and another one allocated at the same address, or modified in place
+    (``u_kn -= shift`` changes every sampled element; a caller who pokes single elements into a matrix between two calls of this
+    module is not detected and must call :func:`drop_resident_cache` -- the reference's ``MBAR`` never writes to its copy).
+    Bounded: ``PYMBAR_AMD_RESIDENT_CACHE`` entries (default 2; 0 switches the cache off) and
+    ``PYMBAR_AMD_RESIDENT_CACHE_GB`` (default 64) of device memory; least recently used first out."""
+
+    def __init__(self):
+        from collections import OrderedDict
+
+        self.entries = OrderedDict()  # key -> (handle, nbytes)
+        self.uploads = 0              # (counted for the boundary test)
+        self.hits = 0
+
+    @staticmethod
+    def limits():
+        return (int(os.environ.get("PYMBAR_AMD_RESIDENT_CACHE", "2")),
+                float(os.environ.get("PYMBAR_AMD_RESIDENT_CACHE_GB", "64")) * 1e9)
+
+    @staticmethod
+    def key_of(a):
+        import hashlib
+
+        flat = a.reshape(-1)  # (a view: the array is C-contiguous)
+        idx = np.linspace(0, flat.size - 1, min(flat.size, 4096)).astype(np.int64)
+        h = hashlib.blake2b(digest_size=16)
+        h.update(flat[idx].tobytes())
+        h.update(a[0].tobytes())
+        h.update(a[-1].tobytes())
+        return (a.ctypes.data, a.shape, a.strides, h.digest())
+
+    def get(self, u_kn):
+        """A resident handle for the host array, or ``(None, None)`` when it cannot be cached (caller uploads a temporary)."""
+        max_entries, max_bytes = self.limits()
+        a = u_kn
+        if (max_entries <= 0 or not isinstance(a, np.ndarray) or a.ndim != 2 or a.dtype != np.float64
+                or not a.flags.c_contiguous or a.size == 0 or a.nbytes > max_bytes):
+            return None, None
+        key = self.key_of(a)
+        hit = self.entries.get(key)
+        if hit is not None:
+            self.entries.move_to_end(key)
+            self.hits += 1
+            return hit[0], key
+        from .device import DeviceMatrix  # deferred: importing this module must not need a GPU
+
+        handle = DeviceMatrix.from_host(a)
+        self.uploads += 1
+        self.entries[key] = (handle, a.nbytes)
+        while len(self.entries) > max_entries or sum(b for _, b in self.entries.values()) > max_bytes:
+            _, (old, _) = self.entries.popitem(last=False)
+            old.close()
+        return handle, key
+
+    def clear(self):
+        while self.entries:
+            _, (old, _) = self.entries.popitem(last=False)
+            old.close()
+
+
+_resident_cache = _ResidentCache()
+
+
+def drop_resident_cache():
+    """Release the device copies this module keeps of recently used host matrices (see :class:`_ResidentCache`)."""
+    _resident_cache.clear()
+
+
 class _Resident:
-    """Context manager yielding a device-resident handle for ``u_kn`` (uploading a numpy array for
-    the duration of the block, passing handles through untouched)."""
+    """Context manager yielding a device-resident handle for ``u_kn``: handles pass through untouched, a float64 C-contiguous
+    host array gets (or re-uses) a cached device copy, anything else is uploaded for the duration of the block."""
 
     def __init__(self, u_kn):
         self.u_kn = u_kn
@@ -83,6 +156,9 @@ class _Resident:
     def __enter__(self):
         if _is_handle(self.u_kn):
             return self.u_kn
+        handle, _ = _resident_cache.get(self.u_kn)
+        if handle is not None:
+            return handle
         from .device import DeviceMatrix  # deferred: importing this module must not need a GPU
 
         self.owned = DeviceMatrix.from_host(self.u_kn)

@@ -42,3 +42,13 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _fresh_resident_cache():
+    """The drop-in solver module keeps device copies of recently used host matrices (pymbar_amd.mbar_solvers._ResidentCache):
+    no test inherits another one's."""
+    yield
+    from pymbar_amd import mbar_solvers
+
+    mbar_solvers.drop_resident_cache()

@@ -87,7 +87,39 @@ def main():
         ea = ref.compute_expectations(A_n, uncertainty_method="bootstrap")
         eb = new.compute_expectations(A_n, uncertainty_method="bootstrap")
         cmp(f"{cname}/bootstrap/expectation_sigma", ea["sigma"], eb["sigma"], 1e-9)
+    # Residency behind the literal drop-in: ONE upload per construction of the unchanged pymbar.MBAR (its calls at mbar.py:413 and
+    # :455 hand over the same self.u_kn), none for the expectation / perturbed-free-energy calls that follow (:910 passes
+    # self.u_kn again), one per bootstrap replicate (a gathered matrix each).
+    uploads = []
+
+    class Counting(OracleMatrix):
+        @classmethod
+        def from_host(cls, u_kn, device=None, columns=None):
+            uploads.append(np.shape(u_kn))
+            return super().from_host(u_kn, device=device, columns=columns)
+
+    pymbar_amd.device.DeviceMatrix = Counting
+    u_kn, N_k = cases["ladder_K12"]
+    pymbar.mbar.mbar_solvers = amd_solvers
+    try:
+        amd_solvers.drop_resident_cache()
+        m = pymbar.MBAR(u_kn, N_k)
+        n_ctor = len(uploads)
+        m.compute_free_energy_differences()
+        m.compute_overlap()
+        n_after = len(uploads)
+        amd_solvers.drop_resident_cache()
+        del uploads[:]
+        pymbar.MBAR(u_kn, N_k, n_bootstraps=3, rseed=5)
+        n_boot = len(uploads)
+    finally:
+        pymbar.mbar.mbar_solvers = ref_solvers
+        pymbar_amd.device.DeviceMatrix = OracleMatrix
+    if (n_ctor, n_after, n_boot) != (1, 1, 4):
+        print(json.dumps({"mismatch": "uploads per pymbar.MBAR construction", "uploads": [n_ctor, n_after, n_boot]}))
+        sys.exit(1)
     print(json.dumps({"ok": True, "worst_deviation": max(worst.values()), "checks": len(worst),
+                      "uploads_per_construction": n_ctor, "uploads_per_construction_with_3_bootstraps": n_boot,
                       "worst": sorted(worst.items(), key=lambda kv: -kv[1])[:5]}))
 
 

@@ -191,3 +191,18 @@ def test_no_gpu_means_loud_failure():
 
     with pytest.raises(_lib.BackendUnavailable):
         pymbar_amd.MBAR(np.zeros((2, 8)), np.array([4, 4]))
+
+
+def test_bench_without_a_launcher_refuses_to_measure_fewer_ranks_than_asked():
+    """``python bench.py --gpus 2`` with no WORLD_SIZE in the environment spawns its own ranks; on a box with fewer GPUs (here:
+    none) it must fail loudly with exit code 3 instead of printing a one-rank line."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stderr[-400:])
+    assert "GPU(s) visible" in p.stderr and not p.stdout.strip()

@@ -107,3 +107,21 @@ def test_initialize_bar_and_unnormalized_log_weights(golden):
     u_n = 0.5 * (g["u_kn"][1] + g["u_kn"][3])
     ref = -1.0 * logsumexp(mbar.f_k + u_n[:, np.newaxis] - mbar.u_kn.T, b=mbar.N_k, axis=1)
     np.testing.assert_allclose(mbar._computeUnnormalizedLogWeights(u_n), ref, rtol=1e-12, atol=1e-12)
+
+
+def test_host_copy_of_u_kn_is_private_by_default(golden):
+    """mbar.py:243: the object owns its copy of ``u_kn`` -- a caller who recycles the array afterwards must not change what the
+    object reads (the device copy is frozen at construction).  ``copy=False`` (extension) keeps a READ-ONLY reference instead."""
+    g = golden("config1_ho_K5_N5000.npz")
+    u = np.array(g["u_kn"])
+    m = pymbar_amd.MBAR(u, g["N_k"])
+    ref = m.compute_perturbed_free_energies(m.u_kn)["Delta_f"].copy()
+    u += 1.0e3 * np.arange(u.shape[0])[:, None]  # the caller re-uses its buffer
+    np.testing.assert_array_equal(m.u_kn, g["u_kn"])
+    np.testing.assert_allclose(m.compute_perturbed_free_energies(m.u_kn)["Delta_f"], ref, atol=1e-12)
+    u2 = np.array(g["u_kn"])
+    m2 = pymbar_amd.MBAR(u2, g["N_k"], copy=False)
+    assert np.shares_memory(m2.u_kn, u2) and not m2.u_kn.flags.writeable
+    with pytest.raises(ValueError):
+        m2.u_kn[0, 0] = 1.0
+    np.testing.assert_allclose(m2.f_k, m.f_k, atol=1e-12)

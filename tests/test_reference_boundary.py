@@ -23,3 +23,6 @@ def test_unchanged_reference_MBAR_on_the_drop_in_solver_module():
     verdict = json.loads(out.stdout.strip().splitlines()[-1])
     assert verdict["ok"] and verdict["checks"] >= 60, verdict
     assert verdict["worst_deviation"] < 1e-9, verdict
+    # the drop-in keeps the matrix resident between the unchanged MBAR's calls into the solver module: one upload per object
+    # (+ one per bootstrap replicate, each a freshly gathered matrix)
+    assert verdict["uploads_per_construction"] == 1 and verdict["uploads_per_construction_with_3_bootstraps"] == 4, verdict
