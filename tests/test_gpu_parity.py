@@ -365,7 +365,11 @@ def test_adaptive_solves_above_128_states_match_the_oracle(DM, K, N):
     """Adaptive solves beyond one Gram panel (129-256 states: paneled Gram sweeps; 257-512: row-split evaluation sweep; above:
     layout-agnostic sweeps) against the oracle's loop (mbar_solvers.py:575-640): free energies, iteration counts, the choice
     and both gradient norms of EVERY iteration -- with an unsampled state, with forced self-consistent steps, and for a
-    bootstrap replicate (draw counts on the resident matrix against the oracle on the explicitly gathered columns)."""
+    bootstrap replicate (draw counts on the resident matrix against the oracle on the explicitly gathered columns).
+    Tolerance 1e-10: with ~20 samples per state the last step of a solve to 1e-12 changes f by 5e-13 ... 1.5e-12 in the
+    reference itself (round-off of the gradient times the condition number of the Hessian), so whether iteration 5 or 6 passes
+    the test of :636 is noise there; at 1e-10 the count is pinned with two orders of magnitude to spare on either side."""
+    tol = 1e-10
     u_kn, N_k, _ = random_problem(K, N, seed=K + 7, unsampled=(K // 3,))
     sws = np.where(N_k > 0)[0]
     Nf = N_k[sws].astype(float)
@@ -381,12 +385,12 @@ def test_adaptive_solves_above_128_states_match_the_oracle(DM, K, N):
         for case in (dict(min_sc_iter=0), dict(min_sc_iter=2), dict(min_sc_iter=0, boot=True)):
             u_or = u_kn[:, rints] if case.get("boot") else u_kn
             hist = []
-            r_or = oracle.adaptive(np.ascontiguousarray(u_or[sws]), Nf, np.zeros(len(sws)), tol=1e-12, min_sc_iter=case["min_sc_iter"],
+            r_or = oracle.adaptive(np.ascontiguousarray(u_or[sws]), Nf, np.zeros(len(sws)), tol=tol, min_sc_iter=case["min_sc_iter"],
                                    history=hist)
             assert r_or["success"]
             dm.set_sample_weights(np.bincount(rints, minlength=N) if case.get("boot") else None)
             try:
-                fa, ra = dm.solve_adaptive(np.zeros(K), tol=1e-12, maxiter=300, min_sc_iter=case["min_sc_iter"], history_rows=300)
+                fa, ra = dm.solve_adaptive(np.zeros(K), tol=tol, maxiter=300, min_sc_iter=case["min_sc_iter"], history_rows=300)
             finally:
                 dm.set_sample_weights(None)
             assert ra["success"] and ra["iterations"] == r_or["iterations"], (case, ra["iterations"], r_or["iterations"])
