@@ -88,6 +88,10 @@ int mbar_device_synchronize(int device);
  *                    Newton-Raphson candidate, the separate Gram sweep runs only when that candidate is rejected (default)
  *   "pmode"          1 = the device-resident loop keeps P = exp(a0 - u - logden(a0)) resident (one more K x N array, built
  *                    once per solve) and sweeps that: no exponentials in the loop (default); 0 = sweeps recompute them from u
+ *   "gram_quad"      1 = 129 <= K <= 256: the Gram sweep reads the matrix ONCE, the four waves of a workgroup share the tile
+ *                    stream and split the panel's 78 / 136 blocks (default); 0 = 128-state panels + 64 x 128 rectangles (2.5 reads)
+ *   "device_loop_wide" 1 = the device-resident loop also serves 129 <= K <= 256 (Newton system by a blocked Cholesky
+ *                    factorisation in device memory; default); 0 = host-driven loop there
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
  *   "timing"         HIP-event timers (mbar_ctx_timing): 0 = off (default: an event pair per sweep costs ~10 us, a fifth of an
  *                    iteration at the problem sizes pymbar is mostly used on), 1 = event records around a launch, 2 = events
@@ -198,6 +202,7 @@ typedef struct mbar_solve_result {
 /* Adaptive NR/SCI on the states with N_k > 0 (others are left untouched).  f_inout[K].
  * history (may be NULL): rows of 4 doubles {choice(0 sci,1 nr), |g_sci|, |g_nr|, max_delta}.
  * check_convergence = 0 runs exactly maxiter iterations (benchmarking).
+ * Up to 256 states the whole iteration is device-resident (129 .. 256: classic two-sweep form, blocked Cholesky solve).
  * Up to 128 states the whole iteration is device-resident (K x K Newton solve in one workgroup, candidate construction,
  * ONE fused sweep for both candidates' gradients and the next Hessian's Gram matrix, choice and convergence test; the host
  * reads a few control words per batch of iterations, replayed from a hipGraph on a single rank, with ONE ncclAllReduce on

@@ -256,10 +256,11 @@ struct mbar_ctx {
     double* part_g = nullptr;       // Gram partial records of the fused-sweep loop (the psum records use `part`)
     size_t part_g_doubles = 0;
     double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
+    double* chol = nullptr;         // workspace of the blocked Cholesky Newton solve (129 .. 256 states)
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -639,9 +640,9 @@ struct GramPlan {
     std::vector<Item> items;
     size_t total_blocks = 0;
 };
-GramPlan gram_plan(int64_t Kp) {
+GramPlan gram_plan(int64_t Kp, bool quad = false) {
     GramPlan p;
-    if (Kp <= 128) {
+    if (Kp <= 128 || quad) {  // (quad: 129 .. 256 states as ONE panel, its blocks split over the four waves of a workgroup)
         int nb = (int)(Kp / 16);
         p.items.push_back({true, 0, 0, nb, nb, nb * (nb + 1) / 2, 0});
         p.total_blocks = (size_t)nb * (nb + 1) / 2;
@@ -683,6 +684,10 @@ GramPlan gram_plan(int64_t Kp) {
     return p;
 }
 
+// 129 .. 256 states: the one-read kernel (k_gram_quad) needs LDS-DMA staging
+bool use_quad(const mbar_ctx* c) { return c->opt_quad && c->opt_staging == 0 && use_fast(c) && c->Kp > 128 && c->Kp <= 256; }
+GramPlan plan_for(const mbar_ctx* c) { return gram_plan(c->Kp, use_quad(c)); }
+
 // Gram pass with operand exp(anum_k - u_kn - logden_n); anum (device) has Kp entries.
 // Results: gram blocks at red + red_off (plan order).  The per-state operand sums are not accumulated on the
 // device: rows of p sum to one (sum_k p_nk = 1, resp. sum_k N_k W_nk = 1), so they are column sums of the
@@ -695,6 +700,21 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
         logden = c->lden_eff;
     }
     for (const auto& it : plan.items) {
+        if (it.diag && it.nbi > 8) {  // one read of the matrix: the four waves of a workgroup split the panel's blocks
+            const LaunchGeom g = gram_quad_geometry(it.nbi, c->num_cu, ntiles, c->opt_grid);
+            const size_t rec = (size_t)it.nblk * 256;
+            int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
+            if (rc) return rc;
+            rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * rec);
+            if (rc) return rc;
+            {
+                ScopedTimer t(c, MBAR_TIMER_GRAM);
+                HIPCHK(c, launch_gram_quad(c->stream, it.nbi, g, c->u, c->ld, c->N, anum_dev + it.ri, logden, c->part));
+            }
+            ScopedTimer t(c, MBAR_TIMER_REDUCE);
+            HIPCHK(c, launch_reduce(c->stream, c->part, g.nwaves, (int64_t)rec, c->scratch, c->red + red_off + it.off * 256));
+            continue;
+        }
         const int tile_rows = it.diag ? it.nbi * 16 : (it.nbi + it.nbj) * 16;
         LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
         const size_t rec = (size_t)it.nblk * 256;
@@ -803,7 +823,7 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
     }
     const int64_t rows = lse_rows(c);
     GramPlan plan;
-    if (want_gram) plan = gram_plan(c->Kp);
+    if (want_gram) plan = plan_for(c);
     const size_t n_ps = (size_t)nf * rows, n_obj = nf;
     const size_t off_gram = n_ps + n_obj, n_gram = plan.total_blocks * 256;
     const size_t total = off_gram + n_gram;
@@ -1030,7 +1050,7 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
     int rc = eval_core(c, f.data(), 1, 0, c->logden[cur], nullptr, psum.data(), nullptr, nullptr);
     if (rc) return rc;
     bool done = false;
-    const GramPlan plan = gram_plan(c->Kp);
+    const GramPlan plan = plan_for(c);
     const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
     double tA = 0, tH = 0, tB = 0;
     const int64_t it0 = res.iterations;
@@ -1165,11 +1185,13 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
 // and the convergence test never leave the device, and the host reads eight control words per batch.  Iterations
 // enqueued past convergence are no-ops (every kernel looks at CTL_DONE first).
 bool device_loop_eligible(const mbar_ctx* c) {
-    if (!c->opt_device_loop || !use_fast(c) || c->Kp > 128) return false;
+    if (!c->opt_device_loop || !use_fast(c)) return false;
     if (c->nranks > 1 && !stream_transport(c)) return false;  // the host transport needs the host in the loop
     if (c->Kp == 128 && gram_variant_for(c) != 2) return false;
     const int64_t ntiles = (c->N + TS - 1) / TS;
     const LaunchGeom gl = lse_geometry((int)(c->Kp / 16), 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+    // 129 .. 256 states: the one-read Gram kernel, the four-waves-per-CU evaluation kernel and the blocked Cholesky solve
+    if (c->Kp > 128) return c->opt_device_loop_wide && use_quad(c) && gl.variant == 5;
     return gl.variant == 1;
 }
 
@@ -1224,8 +1246,11 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // sequence of collectives than its peers.
     // P mode: the sweeps run on the resident probability matrix (one more K x N array); if it does not fit ON ANY RANK, or with
     // register staging, every rank runs the classic sweeps on u.
-    bool pmode = c->opt_pmode && dma && !c->P_failed;
+    const bool wide = Kp > 128;  // 129 .. 256 states: one-read Gram kernel, classic sweeps (no resident probability matrix yet)
+    bool pmode = c->opt_pmode && dma && !c->P_failed && !wide;
     int arc = ensure_ad(c, history ? history_rows : 0);
+    if (!arc && wide && !c->chol && cache_malloc((void**)&c->chol, NEWTON_CHOL_WORK * sizeof(double)) != hipSuccess)
+        arc = fail(c, MBAR_ERR_HIP, "allocation of the Newton workspace failed");
     if (!arc && pmode && !c->P) {
         arc = drop_graphs(c);
         if (!arc) {
@@ -1252,7 +1277,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         arc = fail(c, MBAR_ERR_HIP, "allocation of the P-mode vectors failed");
     const bool fused = pmode && c->opt_fused;
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
-    LaunchGeom gg = gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
+    LaunchGeom gg = wide ? gram_quad_geometry(nb, c->num_cu, ntiles, c->opt_grid)
+                         : gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
     const LaunchGeom gl = fused ? fused_geometry(nb, c->num_cu, ntiles, c->opt_grid)
                           : pmode ? psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid)
                                   : lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
@@ -1410,8 +1436,11 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             const bool ext = tp.a && tp.b && c->opt_timing == 2;
             if (ext) { lca.ev_start = tp.a; lca.ev_stop = tp.b; }
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
-            HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, gram_part,
-                                       nullptr, lca));
+            if (wide)
+                HIPCHK(c, launch_gram_quad(c->stream, nb, gg, c->u, c->ld, c->N, d_anum(c), lden, gram_part, lca));
+            else
+                HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, gram_part,
+                                           nullptr, lca));
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
             if (tp.a && tp.b) c->pending.push_back(tp);
         }
@@ -1430,7 +1459,10 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             int r2 = enqueue_gram(timed);
             if (r2) return r2;
         }
-        HIPCHK(c, launch_newton(c->stream, q));
+        if (wide)
+            HIPCHK(c, launch_newton_chol(c->stream, q, c->chol));
+        else
+            HIPCHK(c, launch_newton(c->stream, q));
         double* psum_part = c->part;
         double* obj_part = c->part + (size_t)gl.nwaves * rec_l;
         {
@@ -1711,6 +1743,7 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->pm_vec) (void)cache_free(c->pm_vec);
     if (c->part_g) (void)cache_free(c->part_g);
     if (c->cwsq) (void)cache_free(c->cwsq);
+    if (c->chol) (void)cache_free(c->chol);
     if (c->ad_ints) (void)cache_free(c->ad_ints);
     if (c->h_ctl) (void)cache_host_free(c->h_ctl);
     if (c->ad_graph) (void)hipGraphExecDestroy(c->ad_graph);
@@ -1773,6 +1806,8 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "device_loop") c->opt_device_loop = value;
     else if (k == "pmode") c->opt_pmode = value;
     else if (k == "fused") c->opt_fused = value;
+    else if (k == "gram_quad") c->opt_quad = value;
+    else if (k == "device_loop_wide") c->opt_device_loop_wide = value;
     else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;
@@ -2217,7 +2252,7 @@ int mbar_gram_w(mbar_ctx* c, const double* f, double* gramW, double* wsum) {
         if (wsum) std::fill(wsum, wsum + c->K, std::numeric_limits<double>::quiet_NaN());
         return MBAR_OK;
     }
-    GramPlan plan = gram_plan(c->Kp);
+    GramPlan plan = plan_for(c);
     const size_t n_gram = plan.total_blocks * 256, total = n_gram;
     rc = ensure_red(c, total);
     if (rc) return rc;

@@ -99,6 +99,13 @@ hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, bool dma, const La
                            int64_t N, const double* anum_i, const double* anum_j, const double* logden,
                            int64_t row_i0, int64_t row_j0, double* gram_part);
 
+// 129 .. 256 states (nbt = 12 or 16 blocks of 16) in ONE read: the four waves of a workgroup share a tile stream and split
+// the nbt (nbt + 1) / 2 upper-triangular blocks; gram_part: [blocks][nblk][256], block b = (I, J), I <= J, row-major.
+// LDS-DMA staging only.  lc.pmode: `u` is the resident probability matrix, `logden` the reciprocals 1 / s_n.
+LaunchGeom gram_quad_geometry(int nbt, int num_cu, int64_t ntiles, int64_t grid_override);
+hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                            const double* anum, const double* logden, double* gram_part, const LoopCtl& lc = LoopCtl());
+
 // ---- layout-agnostic fallbacks (any K) ---------------------------------------------------------
 hipError_t launch_lse_split(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
                             const double* cw, double* logden, const double* dn, double* psum_part, double* obj_part, int* blocks_out);
@@ -205,6 +212,10 @@ hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double*
                                 const LoopCtl& lc = LoopCtl());
 // K x K Newton system (gauge-fixed, Gauss-Jordan in registers, one workgroup) + both candidates + sweep inputs
 hipError_t launch_newton(hipStream_t s, const AdaptArgs& a);
+// ... for 128 .. 255 unknowns: blocked Cholesky in device memory (a pair of small kernels per block column of 32);
+// work: NEWTON_CHOL_WORK doubles
+constexpr size_t NEWTON_CHOL_WORK = (size_t)256 * 256 + 8;
+hipError_t launch_newton_chol(hipStream_t s, const AdaptArgs& a, double* work);
 // gradient norms of both candidates, choice (mbar_solvers.py:607), convergence test (:627-640), next Gram operand
 hipError_t launch_select(hipStream_t s, const AdaptArgs& a);
 // fused loop paused by k_select (CTL_DONE = 3): clear the pause and the Gram request (in front of the Gram sweep)

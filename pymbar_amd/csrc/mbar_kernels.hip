@@ -977,8 +977,14 @@ __global__ void __launch_bounds__(256, 1)
 k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
            const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
            double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
-           double* __restrict__ obj_part) {
+           double* __restrict__ obj_part, const int* __restrict__ ctl, int64_t slot_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl) {  // device-resident solver loop: stop flag + rotating logden slots (logden0 = base of the three vectors)
+        if (ctl[CTL_DONE] != 0) return;
+        const int s = ctl[CTL_SLOT];
+        logden1 = logden0 + (int64_t)((s + 2) % 3) * slot_stride;
+        logden0 = logden0 + (int64_t)((s + 1) % 3) * slot_stride;
+    }
     constexpr int ROWS = NB * 16;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
@@ -1490,6 +1496,228 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     for (int b = 0; b < NBLK; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = acc[b][r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram pass for 129 .. 256 states in ONE read of the matrix.  A panel of NBT = 12 / 16 blocks of 16 states has 78 / 136
+// upper-triangular 16 x 16 blocks -- four times what one wave's register file holds (k_gram above covers such panels with
+// four launches: two diagonal 128-state panels and two 64 x 128 rectangles, 2.5 reads of the matrix and every exponential
+// computed 2.2 times).  Here the FOUR waves of a workgroup (one per SIMD, one workgroup per CU) share one tile stream:
+//   [wait own LDS-DMA: a quarter of the tile's rows + an own copy of its 16 logden values]
+//   [each wave turns its quarter of the rows into operands IN PLACE: p = exp(a - u - logden), or P / s in P mode]
+//   [ONE barrier] [the next tile is requested into the other buffer behind the first matrix instructions]
+//   [each wave reads the operands of all NBT row blocks, group by group, and issues ITS blocks: every fourth
+//   block of the row-major upper triangle -- 34 of 136 (20 / 19 of 78), in the pinned AGPR / VGPR classes of k_gram]
+// so the matrix is read once, every exponential is computed once (16 per lane and tile instead of 52), and the matrix pipe
+// runs 34 x 4 x 64 = 8704 cycles per tile and SIMD against ~1500 (P mode: ~150) cycles of operand work and one barrier.
+// Partial records: ONE per workgroup (NBLK blocks of 256 doubles, block b = (I, J), I <= J, row-major: the layout of the
+// single-panel kernel, so the reduction, the K x K solve and the host-side unpacking are the ones of K <= 128).
+// ---------------------------------------------------------------------------------------------
+constexpr int quad_blocks_of(int nbt, int w) { return (nbt * (nbt + 1) / 2 - w + 3) / 4; }
+template <int NBT, int WV, bool WIDE, bool PMODE>
+__device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+                                               const double* __restrict__ anum, const double* __restrict__ logden,
+                                               double* __restrict__ gram_part, char* smem, int lane) {
+    constexpr int ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + one copy of the tile's 16 logden values per wave (a 1 KB LDS-DMA piece each)
+    constexpr int NBLK = NBT * (NBT + 1) / 2, NMINE = quad_blocks_of(NBT, WV);
+    constexpr bool PINNED = NMINE > GRAM_AGPR_BLOCKS;
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem + EXP_TABLE_BYTES;  // two tile buffers shared by the four waves
+    const RowIdentity rows{0};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+    const int64_t G = gridDim.x;
+
+    double aS[NQ];  // exponent constants of the rows this wave turns into operands, in table units
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        double a = PMODE ? 0.0 : anum[16 * (WV * NQ + i) + ks];
+        if constexpr (!PMODE) settle(a);
+        aS[i] = a * LOG2E_S;
+    }
+    v4d acc[NMINE];
+#pragma unroll
+    for (int b = 0; b < NMINE; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    // this wave's quarter of a tile's rows (QDMA LDS-DMA instructions of 8 rows) and its OWN copy of the tile's 16 logden values
+    // (behind the tile, one 128-byte slot per wave): everything a wave needs to turn its rows into operands it has staged
+    // itself, so that step needs no barrier
+    auto stage_piece_j = [&](int64_t tile, char* dst, int j) {
+        stage_piece<true>(u + rows(8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
+    };
+    // (a full-wave LDS-DMA of 1 KB: lanes 0 .. 7 bring the 16 values, the others repeat them -- no exec-masked branch among the
+    // matrix instructions: the register allocator handles the pinned accumulators only in straight-line code)
+    const char* lsrc = reinterpret_cast<const char*>(logden) + (lane & 7) * 16;
+    auto stage_l = [&](int64_t tile, char* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + tile * (TS * 8)),
+                                         (__attribute__((address_space(3))) void*)(dst + U_BYTES + WV * 1024), 16, 0, 0);
+    };
+    auto stage = [&](int64_t tile, char* dst) {
+#pragma unroll
+        for (int j = WV * QDMA; j < (WV + 1) * QDMA; ++j) stage_piece_j(tile, dst, j);
+        stage_l(tile, dst);
+    };
+    auto read_group = [&](const char* tb, int g, double (&x)[NBT]) {
+#pragma unroll
+        for (int I = 0; I < NBT; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
+    };
+    auto mfma = [&](int b, double x, double y) {
+        if constexpr (PINNED) {
+            if (b < GRAM_AGPR_BLOCKS)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(x), "v"(y));
+            else
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(x), "v"(y));
+        } else {
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[b], 0, 0, 0);
+        }
+    };
+
+    // Per tile: [own LDS-DMA landed] [own rows -> operands, in place] [ONE barrier] [request the next tile into the other
+    // buffer, behind the first matrix instructions] [own blocks].  The barrier of tile t says "every wave has finished the
+    // blocks of tile t - 1", which is what frees the other buffer; the request then has the whole block phase to land.
+    // this wave's own rows of a tile (and its logden values) out of LDS: requested for tile t + 1 behind the last blocks of tile t,
+    // so that the operand step at the loop top starts on registers
+    double x[GROUPS * NQ], ldc[GROUPS];
+    auto read_own = [&](const char* tb) {
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            ldc[g] = *reinterpret_cast<const double*>(tb + U_BYTES + WV * 1024 + (4 * g + ns) * 8);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                x[g * NQ + i] = *reinterpret_cast<const double*>(tb + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]);
+        }
+    };
+    int64_t t = blockIdx.x;
+    int cur = 0;
+    // (the 78-block panel's waves hold 19 / 20 compiler-managed accumulators: there the early request measured slower)
+    constexpr bool PREFETCH = PINNED;
+    if (t < ntiles) {
+        stage(t, buf);
+        if constexpr (PREFETCH) {
+            wait_vm<0>();
+            read_own(buf);
+        }
+    }
+    for (; t < ntiles; t += G) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+        const int64_t tnext = t + G < ntiles ? t + G : t;  // (past the end this tile is requested again and never looked at)
+        if constexpr (!PREFETCH) {
+            wait_vm<0>();
+            read_own(cbuf);
+        }
+        // ---- operands of this wave's rows, in place
+        {
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                const bool valid = (t * TS + 4 * g + ns) < N;
+                if constexpr (PMODE) {
+                    const double rin = valid ? ldc[g] : 0.0;  // 1 / s_n (times sqrt(c_n) when weighted); padded samples: 0
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) x[g * NQ + i] *= rin;
+                } else {
+                    const double lde = (valid ? ldc[g] : INFINITY) * LOG2E_S;  // padded samples / multiplicity zero: exp(-inf) = 0
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) x[g * NQ + i] = fma(x[g * NQ + i], -LOG2E_S, aS[i] - lde);
+                }
+            }
+            if constexpr (!PMODE) exp2s_batch<GROUPS * NQ>(x);
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g)
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+                    *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i];
+        }
+        __syncthreads();  // every row of tile t holds operands; every wave is done with the other buffer
+        // ---- this wave's blocks, group by group; the operands of the next group are requested behind the first block, the
+        // LDS-DMA pieces of the next tile behind the blocks that follow in group 0
+        double p[2][NBT];
+        read_group(cbuf, 0, p[0]);
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            if constexpr (PINNED) {  // (asm matrix instructions are opaque to the scheduler and the hazard recogniser: see k_gram)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7");
+            }
+            int b = 0, mine = 0;
+#pragma unroll
+            for (int I = 0; I < NBT; ++I)
+#pragma unroll
+                for (int J = I; J < NBT; ++J) {
+                    if ((b & 3) == WV) {
+                        mfma(mine, p[g & 1][I], p[g & 1][J]);
+                        if (mine == 0 && g < GROUPS - 1) {
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                            read_group(cbuf, g + 1, p[(g + 1) & 1]);
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (g == 0 && mine >= 1 && mine <= QDMA + 1) {  // one piece behind each of the next blocks (the last: logden)
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                            if (mine <= QDMA)
+                                stage_piece_j(tnext, nbuf, WV * QDMA + mine - 1);
+                            else
+                                stage_l(tnext, nbuf);
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (PREFETCH && g == GROUPS - 1 && mine == 1) {  // the next tile was requested three groups ago: its rows into registers
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                            wait_vm<0>();
+                            read_own(nbuf);
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ++mine;
+                    }
+                    ++b;
+                }
+            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+    }
+    if constexpr (PINNED) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // matrix result -> VALU read distance
+    {
+        int b = 0, mine = 0;
+#pragma unroll
+        for (int I = 0; I < NBT; ++I)
+#pragma unroll
+            for (int J = I; J < NBT; ++J) {
+                if ((b & 3) == WV) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gram_part[(((int64_t)blockIdx.x * NBLK + b) * 4 + r) * 64 + lane] = acc[mine][r];
+                    ++mine;
+                }
+                ++b;
+            }
+    }
+}
+
+template <int NBT, bool WIDE, bool PMODE>
+__global__ void __launch_bounds__(256, 1)
+k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ anum,
+            const double* __restrict__ logden, double* __restrict__ gram_part, const int* __restrict__ ctl,
+            int64_t slot_stride, int cond_needgram) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl) {  // device-resident solver loop: stop flag + the logden / reciprocal slot of the current f
+        if (ctl[CTL_DONE] != 0) return;
+        if (cond_needgram && ctl[CTL_NEEDGRAM] == 0) return;
+        logden += (int64_t)ctl[CTL_SLOT] * slot_stride;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (!PMODE) {
+        exp_table_init(smem);
+        __syncthreads();
+    }
+    switch (wave) {
+        case 0: gram_quad_body<NBT, 0, WIDE, PMODE>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane); break;
+        case 1: gram_quad_body<NBT, 1, WIDE, PMODE>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane); break;
+        case 2: gram_quad_body<NBT, 2, WIDE, PMODE>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane); break;
+        default: gram_quad_body<NBT, 3, WIDE, PMODE>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane); break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2889,6 +3117,78 @@ __device__ __forceinline__ double gram_elem(const double* __restrict__ g, int nb
     return g[(int64_t)b * 256 + (ki & 15) * 16 + (kj & 15)];
 }
 
+// fixed-order sums / maxima over a workgroup of 256 threads
+__device__ __forceinline__ double block256_sum(double v, double* red /*[4]*/) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double block256_max(double v, double* red /*[4]*/) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// Both candidates and the inputs of the candidate sweep from the Newton direction xs (LDS: xs[i] for the i-th sampled state,
+// xs[0] = 0 -- the gauge), shared by the register Gauss-Jordan solve (k_newton, up to 127 unknowns) and the blocked Cholesky
+// solve (k_chol_*, up to 255).  `bad`: the elimination met a pivot that counts as zero.  All threads of the workgroup call it.
+template <int NT>
+__device__ __forceinline__ void newton_tail(const AdaptArgs& q, const double* xs, bool bad, const double* s_f, const double* s_ps,
+                                            const double* s_nk, const double* s_ln, const double* s_a0, const int* smp,
+                                            const int* pos, int tid) {
+    const double gamma = q.prm[0];
+    const int first = smp[0];
+    const double shift = s_f[first] - log(s_ps[first] / s_nk[first]);
+    int flags = bad ? 1 : 0;
+    // Fused sweep: the Gram matrix it accumulates is that of the SECOND multiplier row.  While self-consistent steps are
+    // forced (:607, sci_iter < min_sc_iter) that row is the self-consistent candidate's -- the one that WILL be accepted --
+    // so that the speculation is never thrown away (the reference's default min_sc_iter = 2 cost two extra sweeps before).
+    const bool swap = q.fused && q.ctl[CTL_SCI] < (int)q.prm[2];
+    const int o_sci = swap ? q.Kp : 0, o_nr = swap ? 0 : q.Kp;
+    if (tid == 0) q.ctl[CTL_SPEC] = swap ? 0 : 1;
+    for (int k = tid; k < q.Kp; k += NT) {
+        const bool sampled = k < q.K && s_nk[k] > 0.0;
+        const double fk = s_f[k];
+        double fs = fk, fn = fk, a0 = -INFINITY, rt = 1.0;
+        if (sampled) {
+            fn = fk - gamma * xs[pos[k]];                        // :584
+            fs = (fk - log(s_ps[k] / s_nk[k])) - shift;          // :587-588
+            a0 = fs + s_ln[k];
+            const double a1 = fn + s_ln[k];
+            if (q.pmode) {
+                // multipliers of both candidates relative to the build point of P; too far from it (250 kT: the
+                // flushed tail of P would start to matter near e^700) hands back, the host rebuilds P at the current f
+                const double d0 = a0 - s_a0[k], d1 = a1 - s_a0[k];
+                if (!(fabs(d0) < 250.0) || !(fabs(d1) < 250.0)) flags |= 2;
+                a0 = exp(d0);
+                rt = exp(d1);
+            } else {
+                const double d = a1 - a0;
+                rt = exp(d);
+                if (!(fabs(d) < 300.0)) flags |= 2;
+            }
+            if (!isfinite(fs) || !isfinite(fn)) flags |= 4;
+        } else if (q.pmode) {
+            a0 = 0.0;
+            rt = 0.0;
+        }
+        q.cand[k] = fs;
+        q.cand[q.Kp + k] = fn;
+        q.ratio[k] = rt;
+        q.aden[o_sci + k] = a0;
+        q.aden[o_nr + k] = rt;
+    }
+    flags = __syncthreads_or(flags);
+    if (flags != 0 && tid == 0) {
+        q.ctl[CTL_REASON] = (flags & 1) ? 1 : ((flags & 4) ? 3 : 2);
+        q.ctl[CTL_DONE] = 2;
+    }
+}
+
 // Newton direction + both candidates, ONE workgroup of T x T threads with an R x R tile each (up to R T - 1 unknowns:
 // 8 x 8 threads x 4 x 4 -> 31, 16 x 16 x 4 x 4 -> 63, 16 x 16 x 8 x 8 -> 127).
 //   H = diag(psum) - G on the sampled states, g = psum - N_k (:581, :284-292); gauge x[first] = 0, so the system is the
@@ -3069,72 +3369,248 @@ k_newton(AdaptArgs q) {
     if (tid < M) xs[tid + 1] = rh[tid] / pv[tid];
     __syncthreads();
 
-    const double gamma = q.prm[0];
-    const int first = smp[0];
-    const double shift = s_f[first] - log(s_ps[first] / s_nk[first]);
-    int flags = bad ? 1 : 0;
-    // Fused sweep: the Gram matrix it accumulates is that of the SECOND multiplier row.  While self-consistent steps are
-    // forced (:607, sci_iter < min_sc_iter) that row is the self-consistent candidate's -- the one that WILL be accepted --
-    // so that the speculation is never thrown away (the reference's default min_sc_iter = 2 cost two extra sweeps before).
-    const bool swap = q.fused && q.ctl[CTL_SCI] < (int)q.prm[2];
-    const int o_sci = swap ? q.Kp : 0, o_nr = swap ? 0 : q.Kp;
-    if (tid == 0) q.ctl[CTL_SPEC] = swap ? 0 : 1;
-    for (int k = tid; k < q.Kp; k += NT) {
-        const bool sampled = k < q.K && s_nk[k] > 0.0;
-        const double fk = s_f[k];
-        double fs = fk, fn = fk, a0 = -INFINITY, rt = 1.0;
-        if (sampled) {
-            fn = fk - gamma * xs[pos[k]];                        // :584
-            fs = (fk - log(s_ps[k] / s_nk[k])) - shift;          // :587-588
-            a0 = fs + s_ln[k];
-            const double a1 = fn + s_ln[k];
+    newton_tail<NT>(q, xs, bad, s_f, s_ps, s_nk, s_ln, s_a0, smp, pos, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same K x K step for 128 .. 255 unknowns (129 .. 256 states): the register Gauss-Jordan solve above holds 127 unknowns
+// in one workgroup's registers and no more, so here the gauge-fixed Newton system is solved by a BLOCKED right-looking
+// Cholesky factorisation of the matrix in device memory (512 KB: it lives in L2), one pair of small kernels per block column
+// of CB = 32 -- kernel boundaries are the grid barriers, everything is enqueued ahead like the rest of the iteration:
+//   k_chol_setup   A = H[1:, 1:] (lower triangle) from the reduced Gram blocks, with b = g[1:] appended as ROW M: the
+//                  factorisation then leaves y = L^-1 b in that row, i.e. the forward substitution rides along;
+//   k_chol_panel   (one workgroup) Cholesky of the 32 x 32 diagonal block by one wave (a lane per row, the finished column
+//                  broadcast through LDS), then every row below solves against it (a thread per row, incl. row M);
+//   k_chol_update  (one workgroup per 32 x 32 tile of the trailing lower triangle, incl. row M) A_ik -= L_i L_k^T;
+//   k_chol_finish  (one workgroup) back substitution L^T x = y in blocks of 32, then the candidates (newton_tail).
+// A pivot that counts as zero (the threshold of k_newton / the host path) hands the solve back (CTL_DONE = 2).
+// ~18 launches of 2-5 us for 255 unknowns: ~0.1 ms against >= 4 ms of sweeps at these state counts (the host-driven loop paid
+// two synchronisations, a 0.5 MB download and a 0.57 ms host factorisation per iteration).
+// ---------------------------------------------------------------------------------------------
+constexpr int CHOL_NP = 256;  // row pitch of the workspace (unknowns + the appended right-hand-side row <= 256)
+constexpr int CB = 32;
+__global__ void __launch_bounds__(256)
+k_chol_setup(AdaptArgs q, double* __restrict__ Aw, double* __restrict__ thr_out) {
+    __shared__ double red[4];
+    if (q.ctl[CTL_DONE] != 0) return;
+    const int M = q.m - 1, nb = q.Kp / 16;
+    const int i = blockIdx.y * 16 + (threadIdx.x >> 4), k = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (i > M || k > i || k >= M) {
+        // (the whole workspace is defined: the panel kernel reads and writes full 32-column runs of its rows)
+        if (i < CHOL_NP && k < CHOL_NP) Aw[i * CHOL_NP + k] = (i == k) ? 1.0 : 0.0;
+    } else {
+        const int kk = q.sampled[k + 1];
+        double v;
+        if (i < M) {
+            const int ki = q.sampled[i + 1];
+            v = -gram_elem(q.gram_red, nb, ki, kk);
             if (q.pmode) {
-                // multipliers of both candidates relative to the build point of P; too far from it (250 kT: the
-                // flushed tail of P would start to matter near e^700) hands back, the host rebuilds P at the current f
-                const double d0 = a0 - s_a0[k], d1 = a1 - s_a0[k];
-                if (!(fabs(d0) < 250.0) || !(fabs(d1) < 250.0)) flags |= 2;
-                a0 = exp(d0);
-                rt = exp(d1);
-            } else {
-                const double d = a1 - a0;
-                rt = exp(d);
-                if (!(fabs(d) < 300.0)) flags |= 2;
+                const double* cc = q.fused ? q.cgram : q.ccur;  // the multipliers the Gram sweep left out
+                v *= cc[ki] * cc[kk];
             }
-            if (!isfinite(fs) || !isfinite(fn)) flags |= 4;
-        } else if (q.pmode) {
-            a0 = 0.0;
-            rt = 0.0;
+            if (i == k) v += q.psum[ki];
+        } else {
+            v = q.psum[kk] - q.Nk[kk];  // row M: the gradient (:284-292)
         }
-        q.cand[k] = fs;
-        q.cand[q.Kp + k] = fn;
-        q.ratio[k] = rt;
-        q.aden[o_sci + k] = a0;
-        q.aden[o_nr + k] = rt;
+        Aw[i * CHOL_NP + k] = v;
     }
-    flags = __syncthreads_or(flags);
-    if (flags != 0 && tid == 0) {
-        q.ctl[CTL_REASON] = (flags & 1) ? 1 : ((flags & 4) ? 3 : 2);
-        q.ctl[CTL_DONE] = 2;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {  // (uniform per workgroup)
+        // pivots below eps * M * (largest per-state sum, which bounds the diagonal of H) count as zero (see k_newton)
+        const int t = threadIdx.x;
+        double pm = 0.0;
+        for (int s = t; s < q.m; s += 256) pm = fmax(pm, q.psum[q.sampled[s]]);
+        pm = block256_max(pm, red);
+        if (t == 0) thr_out[0] = pm * 2.220446049250313e-16 * (double)(M > 0 ? M : 1);
     }
+}
+
+// 1 / sqrt(d) for d > 0: hardware estimate + two Newton steps (the sqrt and the divide each expand to ~30 instructions)
+__device__ __forceinline__ double rsqrt_fast(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * fma(fma(-d * r, r, 1.0), 0.5, 1.0);
+    r = r * fma(fma(-d * r, r, 1.0), 0.5, 1.0);
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_chol_panel(AdaptArgs q, double* __restrict__ Aw, const double* __restrict__ thr_in, int j0) {
+    __shared__ double D[CB][CB + 1];   // the factor of the diagonal block (lower triangle), row-major
+    __shared__ double colv[CB], rdiag[CB];
+    __shared__ int s_bad;
+    if (q.ctl[CTL_DONE] != 0) return;
+    const int M = q.m - 1, tid = threadIdx.x;
+    const int nc = M - j0 < CB ? M - j0 : CB;  // columns of this panel (the last one may be short: padded with the identity)
+    const double thr = thr_in[0];
+    if (tid == 0) s_bad = 0;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c2 = e % CB;
+        D[r][c2] = (r < nc && c2 <= r) ? Aw[(j0 + r) * CHOL_NP + j0 + c2] : (r == c2 ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (tid < 64) {  // one wave: lane r owns row r of the block (the upper lanes repeat rows 0 .. 31: same values, same addresses;
+        //                a store under `tid < CB` inside the unrolled loop keeps the row array out of registers)
+        const int r = tid & (CB - 1);
+        double row[CB];
+#pragma unroll
+        for (int c2 = 0; c2 < CB; ++c2) row[c2] = D[r][c2];
+        bool bad = false;
+#pragma unroll
+        for (int c2 = 0; c2 < CB; ++c2) {
+            // column c2 is final for rows >= c2 once the updates of columns < c2 are in: publish it
+            colv[r] = row[c2];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const double d = colv[c2];
+            if (c2 < nc && (!(d > thr) || !isfinite(d))) bad = true;
+            const double inv = rsqrt_fast(d);       // 1 / L[c2][c2]
+            const double t = row[c2] * (inv * inv);  // L[r][c2] / L[c2][c2]
+            // trailing entries of this row: row[k] -= L[r][c2] L[k][c2] = t colv[k]
+#pragma unroll
+            for (int k2 = c2 + 1; k2 < CB; ++k2) row[k2] = fma(-t, colv[k2], row[k2]);
+            row[c2] *= inv;
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < CB; ++c2) D[r][c2] = c2 <= r ? row[c2] : 0.0;
+        rdiag[r] = 1.0 / D[r][r];
+        if (bad && tid == 0) s_bad = 1;
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) {
+            q.ctl[CTL_REASON] = 1;
+            q.ctl[CTL_DONE] = 2;
+        }
+        return;
+    }
+    // the factor of the diagonal block back to the workspace
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c2 = e % CB;
+        if (r < nc && c2 <= r) Aw[(j0 + r) * CHOL_NP + j0 + c2] = D[r][c2];
+    }
+    // rows below the block (up to and including the right-hand-side row M): L_i = A_i D^-T, a thread per row
+    // (full 32-column runs, also for a short last panel: the workspace is defined everywhere, the block is identity-padded, and
+    // what lands beyond column M of the right-hand-side row is never read -- conditional loads here cost 2.7 KB of scratch)
+    const int i = j0 + nc + tid;
+    if (i <= M) {
+        double a[CB];
+#pragma unroll
+        for (int c2 = 0; c2 < CB; ++c2) a[c2] = Aw[i * CHOL_NP + j0 + c2];
+#pragma unroll
+        for (int c2 = 0; c2 < CB; ++c2) {
+            // (fenced: left alone, the scheduler hoists all 528 LDS reads of the unrolled solve to the top and spills)
+            __builtin_amdgcn_sched_barrier(0);
+            double v = a[c2];
+#pragma unroll
+            for (int k2 = 0; k2 < c2; ++k2) v = fma(-a[k2], D[c2][k2], v);
+            a[c2] = v * rdiag[c2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c2 = 0; c2 < CB; ++c2) Aw[i * CHOL_NP + j0 + c2] = a[c2];
+    }
+}
+
+// trailing update after the panel at column j0: tile (bi, bk) of 32 x 32, bk <= bi, rows / columns from j0 + CB on
+__global__ void __launch_bounds__(256)
+k_chol_update(AdaptArgs q, double* __restrict__ Aw, int j0) {
+    __shared__ double Li[CB][CB + 1], Lk[CB][CB + 1];
+    if (q.ctl[CTL_DONE] != 0) return;
+    const int M = q.m - 1, tid = threadIdx.x;
+    // linear tile index -> (bi, bk), bk <= bi
+    int bi = 0, rem = blockIdx.x;
+    while (rem > bi) { rem -= bi + 1; ++bi; }
+    const int bk = rem;
+    const int r0 = j0 + CB + bi * CB, c0 = j0 + CB + bk * CB;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c2 = e % CB;
+        Li[r][c2] = (r0 + r <= M) ? Aw[(r0 + r) * CHOL_NP + j0 + c2] : 0.0;
+        Lk[r][c2] = (c0 + r <= M) ? Aw[(c0 + r) * CHOL_NP + j0 + c2] : 0.0;
+    }
+    __syncthreads();
+    const int r = tid >> 3, cg = (tid & 7) * 4;  // a thread: one row, four columns
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+    for (int k2 = 0; k2 < CB; ++k2) {
+        const double l = Li[r][k2];
+        s0 = fma(l, Lk[cg][k2], s0);
+        s1 = fma(l, Lk[cg + 1][k2], s1);
+        s2 = fma(l, Lk[cg + 2][k2], s2);
+        s3 = fma(l, Lk[cg + 3][k2], s3);
+    }
+    const int gi = r0 + r;
+    if (gi <= M) {
+        const double sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gk = c0 + cg + e;
+            if (gk <= gi && gk < M) Aw[gi * CHOL_NP + gk] -= sv[e];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_chol_finish(AdaptArgs q, const double* __restrict__ Aw) {
+    __shared__ double y[CHOL_NP], xs[CHOL_NP + 1], Lbb[CB][CB + 1];
+    __shared__ double s_f[256], s_ps[256], s_nk[256], s_ln[256], s_a0[256];
+    __shared__ int smp[CHOL_NP + 1], pos[256];
+    if (q.ctl[CTL_DONE] != 0) return;
+    const int M = q.m - 1, tid = threadIdx.x;
+    for (int k = tid; k < q.Kp; k += 256) {
+        s_f[k] = k < q.K ? q.f[k] : 0.0;
+        s_ps[k] = q.psum[k];
+        s_nk[k] = q.Nk[k];
+        s_ln[k] = q.lnNk[k];
+        s_a0[k] = q.pmode ? q.a0[k] : 0.0;
+        pos[k] = 0;
+    }
+    for (int i = tid; i < q.m; i += 256) smp[i] = q.sampled[i];
+    for (int i = tid; i < CHOL_NP; i += 256) y[i] = i < M ? Aw[M * CHOL_NP + i] : 0.0;  // y = L^-1 b
+    __syncthreads();
+    for (int i = tid; i < q.m; i += 256) pos[smp[i]] = i;
+    // L^T x = y from the last block of 32 upwards (right-looking: a solved block is folded into every unknown above it at once)
+    const int nblk = (M + CB - 1) / CB;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int c0 = b * CB, nc = M - c0 < CB ? M - c0 : CB;
+        for (int e = tid; e < CB * CB; e += 256) {  // the block's own triangle (identity-padded)
+            const int r = e / CB, c2 = e % CB;
+            Lbb[r][c2] = (r < nc && c2 <= r) ? Aw[(c0 + r) * CHOL_NP + c0 + c2] : (r == c2 ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (tid < 64) {  // one wave: lane c holds unknown c0 + c
+            const int c = tid & (CB - 1);
+            double yv = y[c0 + c];  // (zero beyond M)
+            const double rd = 1.0 / Lbb[c][c];
+#pragma unroll
+            for (int c2 = CB - 1; c2 >= 0; --c2) {
+                const double x = __shfl(yv, c2) * __shfl(rd, c2);
+                if (c == c2) yv = x;
+                if (c < c2) yv = fma(-Lbb[c2][c], x, yv);
+            }
+            if (tid < CB) y[c0 + c] = yv;
+        }
+        __syncthreads();
+        {
+            const int c = tid;  // (c0 <= 224: one thread per remaining unknown)
+            if (c < c0) {
+                double acc = 0.0;
+#pragma unroll 8
+                for (int r = 0; r < CB; ++r)
+                    if (r < nc) acc = fma(Aw[(c0 + r) * CHOL_NP + c], y[c0 + r], acc);
+                y[c] -= acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) xs[0] = 0.0;
+    for (int i = tid; i < M; i += 256) xs[i + 1] = y[i];
+    __syncthreads();
+    newton_tail<256>(q, xs, false, s_f, s_ps, s_nk, s_ln, s_a0, smp, pos, tid);
 }
 
 // Choice between the candidates and convergence test, one workgroup of 256 threads (one state per thread).  The two
 // gradient norms are fixed-order tree sums (deterministic; the host loop adds the same terms serially, so a round-off
 // tie between the candidates may fall differently there), the convergence measures are maxima.
-__device__ __forceinline__ double block256_sum(double v, double* red /*[4]*/) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-__device__ __forceinline__ double block256_max(double v, double* red /*[4]*/) {
-    v = wave_max(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
 __global__ void __launch_bounds__(256)
 k_select(AdaptArgs q) {
     __shared__ double red[4];
@@ -3458,7 +3934,7 @@ static hipError_t launch_lse_small_t(hipStream_t s, const LaunchGeom& g, const d
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,
                       int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
                       const double* dn, double* pp, double* op, const LoopCtl& lc) {
-    if (lc.ctl && (g.variant == 5 || g.variant == 4)) return hipErrorInvalidValue;
+    if (lc.ctl && g.variant == 4) return hipErrorInvalidValue;
     if (g.variant == 5) {  // (geometry chose the single-buffer wide-panel kernel: nb = 12 or 16, LDS-DMA staging)
         if (!dma) return hipErrorInvalidValue;
         auto go = [&](auto kern) -> hipError_t {
@@ -3468,8 +3944,12 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
                 if (e != hipSuccess) return e;
             }
             const int64_t ntiles = (N + TS - 1) / TS;
-            hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0, l1,
-                               dn, pp, op);
+            if (lc.ev_start && lc.ev_stop)
+                hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, u, ld, N,
+                                      ntiles, aden, cw, l0, l1, dn, pp, op, lc.ctl, lc.slot_stride);
+            else
+                hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0, l1,
+                                   dn, pp, op, lc.ctl, lc.slot_stride);
             return hipGetLastError();
         };
         if (nb == 12) return nf == 1 ? go(k_lse_wide<12, 1>) : go(k_lse_wide<12, 2>);
@@ -3582,6 +4062,49 @@ hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g
 #undef MBAR_CASE
         default: return hipErrorInvalidValue;
     }
+}
+
+LaunchGeom gram_quad_geometry(int nbt, int num_cu, int64_t ntiles, int64_t grid_override) {
+    LaunchGeom g;
+    g.waves = 4;
+    g.variant = 6;
+    g.lds_bytes = (size_t)EXP_TABLE_BYTES + (size_t)2 * ((size_t)nbt * 16 * TS * 8 + 4 * 1024);
+    int64_t cap = grid_override > 0 ? grid_override : num_cu;
+    int64_t want = ntiles < 1 ? 1 : ntiles;
+    g.blocks = (int)(want < cap ? want : cap);
+    g.nwaves = g.blocks;  // one partial record per workgroup
+    g.psum_records = g.nwaves;
+    return g;
+}
+template <int NBT, bool PMODE>
+static hipError_t launch_gram_quad_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                     const double* anum, const double* logden, double* gp, const LoopCtl& lc) {
+    auto launch = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        if (lc.ev_start && lc.ev_stop)
+            hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, u, ld, N, ntiles, anum,
+                                  logden, gp, lc.ctl, lc.slot_stride, lc.cond_needgram ? 1 : 0);
+        else
+            hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, u, ld, N, ntiles, anum, logden, gp, lc.ctl,
+                               lc.slot_stride, lc.cond_needgram ? 1 : 0);
+        return hipGetLastError();
+    };
+    return stage_offsets_wide(ld) ? launch(k_gram_quad<NBT, true, PMODE>) : launch(k_gram_quad<NBT, false, PMODE>);
+}
+hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                            const double* anum, const double* logden, double* gram_part, const LoopCtl& lc) {
+    if (nbt == 12)
+        return lc.pmode ? launch_gram_quad_t<12, true>(s, g, u, ld, N, anum, logden, gram_part, lc)
+                        : launch_gram_quad_t<12, false>(s, g, u, ld, N, anum, logden, gram_part, lc);
+    if (nbt == 16)
+        return lc.pmode ? launch_gram_quad_t<16, true>(s, g, u, ld, N, anum, logden, gram_part, lc)
+                        : launch_gram_quad_t<16, false>(s, g, u, ld, N, anum, logden, gram_part, lc);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_gram_off(hipStream_t s, int nbj, bool dma, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
@@ -3841,6 +4364,24 @@ hipError_t launch_newton(hipStream_t s, const AdaptArgs& a) {
 hipError_t launch_loop_reduce(hipStream_t s, const LoopSrc& src, int64_t count, int op, double* out) {
     if (count < 1 || src.n < 1 || src.n > 8) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_loop_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src, count, op, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_newton_chol(hipStream_t s, const AdaptArgs& a, double* work) {
+    const int M = a.m - 1;
+    if (M < 0 || M > CHOL_NP - 1 || a.Kp > 256) return hipErrorInvalidValue;
+    double* Aw = work;
+    double* thr = work + (size_t)CHOL_NP * CHOL_NP;
+    hipLaunchKernelGGL(k_chol_setup, dim3(CHOL_NP / 16, CHOL_NP / 16), dim3(256), 0, s, a, Aw, thr);
+    for (int j0 = 0; j0 < M; j0 += CB) {
+        hipLaunchKernelGGL(k_chol_panel, dim3(1), dim3(256), 0, s, a, Aw, (const double*)thr, j0);
+        const int rows_below = M + 1 - (j0 + CB);  // incl. the right-hand-side row
+        if (rows_below > 0) {
+            const int nt = (rows_below + CB - 1) / CB;
+            hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, s, a, Aw, j0);
+        }
+    }
+    hipLaunchKernelGGL(k_chol_finish, dim3(1), dim3(256), 0, s, a, (const double*)Aw);
     return hipGetLastError();
 }
 

@@ -300,7 +300,8 @@ def test_full_panel_gram_with_and_without_the_exponential_clamp(DM):
             assert np.linalg.norm(g) < 1e-6 * N
 
 
-@pytest.mark.parametrize("K,N,unsampled", [(5, 3000, ()), (40, 20000, (7, 23)), (64, 9000, ()), (128, 30011, (5,))])
+@pytest.mark.parametrize("K,N,unsampled", [(5, 3000, ()), (40, 20000, (7, 23)), (64, 9000, ()), (128, 30011, (5,)),
+                                           (200, 12000, (11,)), (256, 10000, ())])
 def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
     """The adaptive iteration in its four forms -- host-driven loop, device-resident loop with per-sweep exponentials,
     with the resident probability matrix (two sweeps), and with the fused sweep (speculated Gram matrix of the Newton
@@ -308,6 +309,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
     self-consistent candidate is forced for the first iterations (every speculation of those iterations is rejected),
     with per-sample multiplicities, with a damped Newton step, and for a fixed number of iterations past convergence."""
     u_kn, N_k, f = random_problem(K, N, seed=K + 1, unsampled=unsampled)
+    tol = 1e-12 if K <= 128 else 1e-10  # (~50 samples per state above 128 states: 1e-12 is the round-off floor of f there)
     sws = np.where(N_k > 0)[0]
     modes = {"host": dict(device_loop=0), "classic": dict(device_loop=1, pmode=0, fused=0),
              "pmode": dict(device_loop=1, pmode=1, fused=0), "fused": dict(device_loop=1, pmode=1, fused=1),
@@ -332,7 +334,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                     dm.set_option(k, v)
                 dm.set_sample_weights(c_n if case.get("weights") else None)
                 try:
-                    fa, ra = dm.solve_adaptive(np.zeros(K), tol=1e-12, maxiter=case.get("fixed", 200), min_sc_iter=case["min_sc_iter"],
+                    fa, ra = dm.solve_adaptive(np.zeros(K), tol=tol, maxiter=case.get("fixed", 200), min_sc_iter=case["min_sc_iter"],
                                                gamma=case.get("gamma", 1.0), check_convergence="fixed" not in case, history_rows=200)
                 finally:
                     dm.set_sample_weights(None)
@@ -345,7 +347,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                 assert ra["success"] == r_ref["success"]
                 big = r_ref["history"][:, 1:3] > 1e-6
                 np.testing.assert_allclose(ra["history"][:, 1:3][big], r_ref["history"][:, 1:3][big], rtol=1e-6, err_msg=f"{case} {name}")
-                if name.startswith("fused"):
+                if name.startswith("fused") and K <= 128:  # (above 128 states the device loop runs the two-sweep form)
                     # a separate Gram sweep runs only when the accepted candidate is not the speculated one: the fused sweep
                     # speculates on the self-consistent candidate while those steps are forced (sci_iter < min_sc_iter), on the
                     # Newton-Raphson one otherwise -- so only a self-consistent step that WON on its gradient norm costs a sweep
@@ -353,7 +355,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                     lost = int(np.sum((ra["history"][:, 0] == 0) & ~forced))
                     assert ra["gram_sweeps"] <= lost, (case, name, ra["gram_sweeps"], lost)
             if not case.get("weights") and "fixed" not in case:
-                f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=1e-12, min_sc_iter=case["min_sc_iter"])
+                f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=tol, min_sc_iter=case["min_sc_iter"])
                 if case.get("gamma", 1.0) == 1.0:
                     np.testing.assert_allclose(out["fused"][0][sws], (f_or - f_or[sws[0]])[sws], rtol=1e-9, atol=1e-10)
         for k, v in dict(device_loop=1, pmode=1, fused=1, graph=1).items():
