@@ -2711,6 +2711,11 @@ __host__ __device__ constexpr int fused_steps_done(int I) {
     const int rows = NB - 2 - r1;     // rows r1 + 1 .. NB - 2 share the second batch
     return NB + (NB * (I - r1) + rows - 1) / rows;
 }
+#ifndef MBAR_FUSED_PSUM1_FROM_GRAM
+#define MBAR_FUSED_PSUM1_FROM_GRAM 1
+#endif
+// from this many blocks of 16 states on, the fused sweep leaves the second candidate's per-state sums to k_select (see k_fused)
+constexpr int FUSED_PSUM1_FROM_GRAM_NB = MBAR_FUSED_PSUM1_FROM_GRAM ? 8 : 99;
 template <int NB, bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cmul,
@@ -2730,6 +2735,10 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
     constexpr int TILE_BYTES = U_BYTES + 1024;    // (the weights' piece is a full-wave LDS-DMA too: no exec-masked branch)
     constexpr int NBLK = NB * (NB + 1) / 2;
     constexpr bool PINNED = NBLK > GRAM_AGPR_BLOCKS;
+    // Full panel: the per-state sums of the SECOND candidate are not accumulated here -- the rows of p sum to one, so they are
+    // sum_j c_j G'_kj of the Gram matrix this sweep accumulates for that very candidate, and k_select takes them from the
+    // reduced blocks (FUSED_PSUM1_FROM_GRAM_NB): 8 NB fp64 instructions less per tile on a pipe the matrix instructions share.
+    constexpr bool ACC1 = NB < FUSED_PSUM1_FROM_GRAM_NB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
@@ -2890,11 +2899,11 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
 #pragma unroll
             for (int I = 0; I < NB; ++I) {
                 acc[0][I] = fma(uv[gc][I], q0, acc[0][I]);
-                acc[1][I] = fma(uv[gc][I], q1, acc[1][I]);
+                if constexpr (ACC1) acc[1][I] = fma(uv[gc][I], q1, acc[1][I]);
                 // (pinned here: left alone, the compiler sinks all 8 NB updates to the end of the iteration and keeps
                 // the operands of all four groups alive for them)
                 settle(acc[0][I]);
-                settle(acc[1][I]);
+                if constexpr (ACC1) settle(acc[1][I]);
             }
             // (a padded sample needs no mask: its multiplicity and the root of it are stored as zeros)
             const double rin = r1 * sw[gc];  // operand of the Newton-Raphson candidate's Gram matrix
@@ -3631,8 +3640,22 @@ k_select(AdaptArgs q) {
     const int o_sci = swap ? Kp : 0, o_nr = swap ? 0 : Kp;
     const double m0 = (in && q.pmode) ? q.aden[o_sci + tid] : 1.0;
     const double m1 = in ? (q.pmode ? q.aden[o_nr + tid] : q.ratio[tid]) : 0.0;
-    const double ps0 = in ? q.lse_red[o_sci + tid] * m0 : 0.0;
-    const double ps1 = in ? q.lse_red[o_nr + tid] * m1 : 0.0;
+    double raw0 = in ? q.lse_red[o_sci + tid] : 0.0, raw1 = in ? q.lse_red[o_nr + tid] : 0.0;
+    if (q.fused && Kp / 16 >= FUSED_PSUM1_FROM_GRAM_NB) {
+        // the fused sweep of a full panel left the unscaled sums of its SECOND multiplier row c to be taken from the Gram matrix
+        // it accumulated for that candidate: sum_n w_n P_kn / s_n = sum_j c_j G'_kj (rows of p sum to one)
+        __shared__ double s_c[128];
+        if (tid < Kp) s_c[tid] = q.aden[Kp + tid];
+        __syncthreads();
+        double acc = 0.0;
+        if (in) {
+            const int nb = Kp / 16;
+            for (int j = 0; j < Kp; ++j) acc = fma(s_c[j], gram_elem(q.gram_red, nb, tid, j), acc);
+        }
+        if (swap) raw0 = acc; else raw1 = acc;
+    }
+    const double ps0 = raw0 * m0;
+    const double ps1 = raw1 * m1;
     const double fo = in ? q.f[tid] : 0.0, fs = in ? q.cand[tid] : 0.0, fn = in ? q.cand[Kp + tid] : 0.0;
     const double lnk = in ? q.lnNk[tid] : 0.0;
     const double ga = sampled ? ps0 - nk : 0.0, gb = sampled ? ps1 - nk : 0.0;
