@@ -92,6 +92,9 @@ int mbar_device_synchronize(int device);
  *                    stream and split the panel's 78 / 136 blocks (default); 0 = 128-state panels + 64 x 128 rectangles (2.5 reads)
  *   "device_loop_wide" 1 = the device-resident loop also serves 129 <= K <= 256 (Newton system by a blocked Cholesky
  *                    factorisation in device memory; default); 0 = host-driven loop there
+ *   "pcache"         1 = the resident probability matrix outlives the solve that built it: a later adaptive solve on the same
+ *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
+ *                    one fused sweep instead of the build sweep (default); 0 = every solve builds
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
  *   "timing"         HIP-event timers (mbar_ctx_timing): 0 = off (default: an event pair per sweep costs ~10 us, a fifth of an
  *                    iteration at the problem sizes pymbar is mostly used on), 1 = event records around a launch, 2 = events
@@ -197,6 +200,8 @@ typedef struct mbar_solve_result {
     double max_delta;   /* last relative change                                  */
     double gnorm;       /* |g| at the returned f                                 */
     double wall_ms;     /* host wall time of the loop                            */
+    int32_t warm_starts; /* device-resident loop entries that re-used the resident probability matrix of an earlier solve */
+    int32_t builds;      /* ... that built it (build sweep)                       */
 } mbar_solve_result;
 
 /* Adaptive NR/SCI on the states with N_k > 0 (others are left untouched).  f_inout[K].

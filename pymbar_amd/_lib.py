@@ -38,6 +38,8 @@ class SolveResult(C.Structure):
         ("max_delta", C.c_double),
         ("gnorm", C.c_double),
         ("wall_ms", C.c_double),
+        ("warm_starts", C.c_int32),
+        ("builds", C.c_int32),
     ]
 
 

@@ -257,10 +257,14 @@ struct mbar_ctx {
     size_t part_g_doubles = 0;
     double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
     double* chol = nullptr;         // workspace of the blocked Cholesky Newton solve (129 .. 256 states)
+    // P outlives the solve that built it: a later solve on the same matrix whose start lies within the window of the anchor
+    // (bootstrap replicates, protocol stages, continuation) starts with ONE fused sweep instead of the build sweep
+    bool P_valid = false;
+    std::vector<double> P_a0;       // anchor of the resident probability matrix: aden at the build point (Kp entries)
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -1312,13 +1316,57 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         c->error = local_err;
     }
     int rc = MBAR_OK;
+    LoopCtl lc_slot, lc_flat;
+    lc_slot.ctl = lc_flat.ctl = c->ad_ints;
+    lc_slot.slot_stride = c->ld;
+    lc_slot.unclamped = lc_flat.unclamped = c->u_checked && !c->u_posinf;
+    lc_slot.pmode = lc_flat.pmode = pmode;
+    // Warm start: the resident probability matrix of an earlier solve on this matrix is still there and the start point lies
+    // inside the window of its anchor -- the per-state sums, the reciprocals and the Gram matrix at f come from ONE fused sweep
+    // (both multiplier rows = exp(aden(f) - a0)) instead of the build sweep (16 K N bytes of traffic and K N exponentials).
+    std::vector<double> an0((size_t)Kp), cm0((size_t)Kp, 0.0);
+    build_aden(c, f.data(), an0.data(), Kp);
+    bool warm = fused && c->opt_pcache && c->P_valid && (int64_t)c->P_a0.size() == Kp;
+    for (int64_t k = 0; warm && k < Kp; ++k) {
+        const bool live = !std::isinf(an0[k]), was = !std::isinf(c->P_a0[k]);
+        if (live != was) warm = false;
+        else if (live) {
+            const double d = an0[k] - c->P_a0[k];
+            if (!(std::fabs(d) < 200.0)) warm = false;
+            cm0[k] = std::exp(d);
+        }
+    }
+    rc = agree_all_ok(c, warm);
+    if (rc) return rc;
     // initial gradient (mbar_solvers.py:570).  Classic: the evaluation sweep, logden(f) stays in slot 0.  P mode: the
     // same sweep also writes P = exp(a0 - u - logden(a0)) with a0 = aden(f) and leaves 1 / s = 1 in slot 0; in the fused
     // loop it accumulates the first Hessian's Gram matrix as well (its reduced blocks wait in `red` for k_newton).
     if (!pmode) {
         rc = eval_core(c, f.data(), 1, 0, c->logden[0], nullptr, psum.data(), nullptr, nullptr);
         if (rc) return rc;
+    } else if (warm) {
+        std::vector<int> z((size_t)CTL_WORDS, 0);  // slot 0, running: the sweep leaves the reciprocals of its first row in slot 1
+        HIPCHK(c, hipMemcpyAsync(c->ad_ints, z.data(), z.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        std::copy(cm0.begin(), cm0.end(), c->hstage);
+        std::copy(cm0.begin(), cm0.end(), c->hstage + Kp);
+        HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, (size_t)2 * Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->red, 0, off_gram * sizeof(double), c->stream));
+        {
+            ScopedTimer t(c, MBAR_TIMER_OTHER);
+            HIPCHK(c, launch_fused(c->stream, nb, gl, c->P, c->ld, c->N, d_aden(c), c->cw, c->weighted ? c->cwsq : c->cw, c->logden[0],
+                                   c->part_g, c->part, lc_slot));
+        }
+        HIPCHK(c, launch_reduce2(c->stream, c->part, (int64_t)rec_l, c->part_g, (int64_t)rec_g, gl.nwaves, c->scratch, c->red,
+                                 c->red + off_gram));
+        rc = allreduce_dev(c, c->red, (int64_t)(off_gram + rec_g), 0);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->hred, c->red, (size_t)Kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        rc = sync_stream(c);
+        if (rc) return rc;
+        for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k] * cm0[k];  // (the sweep returns the sums without the multipliers)
+        res.warm_starts += 1;
     } else {
+        c->P_valid = false;
         build_aden(c, f.data(), c->hstage, Kp);
         HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, (size_t)Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->red, 0, off_gram * sizeof(double), c->stream));
@@ -1343,6 +1391,9 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         rc = sync_stream(c);
         if (rc) return rc;
         for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k];
+        c->P_a0 = an0;
+        c->P_valid = true;
+        res.builds += 1;
     }
     double* gram_part = fused ? c->part_g : c->part;
 
@@ -1364,6 +1415,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         hi[CTL_NEEDGRAM] = fused ? 0 : 1;
         hi[CTL_GRAMSWEEPS] = 0;
         hi[CTL_SPEC] = 1;
+        hi[CTL_SLOT] = warm ? 1 : 0;
         hi[CTL_ITER] = (int)res.iterations;
         hi[CTL_SCI] = (int)res.sci_iter;
         hi[CTL_NR] = (int)res.nr_iter;
@@ -1373,11 +1425,13 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         HIPCHK(c, hipMemcpyAsync(c->ad, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->ad_ints, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_anum(c), an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if (pmode) {  // anchor point a0 = aden(f), multipliers of the current f = 1 (P itself was written by the build sweep)
+        if (pmode) {  // anchor point a0 (= aden(f) after a build), multipliers of the current f relative to it (1 after a build)
             std::vector<double> pv((size_t)3 * Kp, 1.0);
-            std::copy(an.begin(), an.end(), pv.begin());
-            for (int64_t k = 0; k < Kp; ++k)
+            std::copy(c->P_a0.begin(), c->P_a0.end(), pv.begin());
+            for (int64_t k = 0; k < Kp; ++k) {
+                if (warm) pv[(size_t)Kp + k] = pv[(size_t)2 * Kp + k] = cm0[k];
                 if (!(k < K && c->Nk[k] > 0.0)) pv[(size_t)Kp + k] = pv[(size_t)2 * Kp + k] = 0.0;
+            }
             HIPCHK(c, hipMemcpyAsync(c->pm_vec, pv.data(), pv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1407,11 +1461,6 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     q.ccur = pmode ? c->pm_vec + Kp : nullptr;
     q.fused = fused ? 1 : 0;
     q.cgram = fused ? c->pm_vec + 2 * Kp : nullptr;
-    LoopCtl lc_slot, lc_flat;
-    lc_slot.ctl = lc_flat.ctl = c->ad_ints;
-    lc_slot.slot_stride = c->ld;
-    lc_slot.unclamped = lc_flat.unclamped = c->u_checked && !c->u_posinf;
-    lc_slot.pmode = lc_flat.pmode = pmode;
 
     // Gram sweep at the current f with the known logden (the slot of the accepted candidate; P mode: the slots hold the
     // reciprocals 1 / s_n instead), reduced and all-reduced into the blocks k_newton reads.  Two-sweep loops: once per
@@ -1607,6 +1656,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     res.nr_iter = c->h_ctl[CTL_NR];
     res.gram_sweeps += fused ? gram_sweeps : (int32_t)(it - it_start);
     if (handed_back) {
+        c->P_valid = false;  // (the continuation re-anchors: a state whose weights underflow at this anchor has a zero row in P)
         static const char* why[] = {"", "the Newton system is not positive definite", "a candidate is too far from the point the sweeps are anchored at",
                                     "a candidate is not finite"};
         const int r = c->h_ctl[CTL_REASON];
@@ -1622,7 +1672,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
 // =================================================================================================
 extern "C" {
 
-int mbar_version(void) { return 100; }
+int mbar_version(void) { return 101; }
 
 const char* mbar_last_error(const mbar_ctx* ctx) { return ctx ? ctx->error.c_str() : g_last_error.c_str(); }
 
@@ -1808,6 +1858,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "fused") c->opt_fused = value;
     else if (k == "gram_quad") c->opt_quad = value;
     else if (k == "device_loop_wide") c->opt_device_loop_wide = value;
+    else if (k == "pcache") c->opt_pcache = value;
     else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;
@@ -1824,6 +1875,7 @@ int mbar_ctx_upload_u(mbar_ctx* c, const double* u_host, int64_t ld_host, int64_
                                (size_t)ld_host * sizeof(double), (size_t)ncols * sizeof(double), (size_t)c->K,
                                hipMemcpyHostToDevice, c->stream));
     c->u_checked = false;
+    c->P_valid = false;
     return sync_stream(c);
 }
 
@@ -1836,6 +1888,7 @@ int mbar_ctx_upload_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const double*
                                (size_t)ld_host * sizeof(double), (size_t)c->N * sizeof(double), (size_t)nrows,
                                hipMemcpyHostToDevice, c->stream));
     c->u_checked = false;
+    c->P_valid = false;
     return sync_stream(c);
 }
 
@@ -1855,6 +1908,7 @@ int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t s
                                      (size_t)src->ld * sizeof(double), (size_t)dst->N * sizeof(double), (size_t)nrows,
                                      hipMemcpyDeviceToDevice, dst->stream));
     dst->u_checked = false;
+    dst->P_valid = false;
     return sync_stream(dst);
 }
 
@@ -1869,6 +1923,7 @@ int mbar_ctx_row_sub(mbar_ctx* c, int64_t row, const double* v_host) {
         HIPCHK(c, hipMemcpyAsync(tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_row_sub(c->stream, c->u + row * c->ld, tmp, c->N));
     c->u_checked = false;
+    c->P_valid = false;
     return sync_stream(c);
 }
 
@@ -1886,6 +1941,7 @@ int mbar_ctx_rows_sub(mbar_ctx* c, int64_t dst_row0, int64_t src_row0, int64_t n
         HIPCHK(c, hipMemcpyAsync(c->vec_tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_rows_sub(c->stream, c->u + dst_row0 * c->ld, c->u + src_row0 * c->ld, c->ld, nrows, c->vec_tmp, c->N));
     c->u_checked = false;
+    c->P_valid = false;
     return sync_stream(c);
 }
 
@@ -1898,6 +1954,7 @@ int mbar_ctx_rows_rsub(mbar_ctx* c, int64_t dst_row0, int64_t src_row0, int64_t 
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, launch_rows_rsub(c->stream, c->u + dst_row0 * c->ld, c->u + src_row0 * c->ld, c->ld, nrows, c->N));
     c->u_checked = false;
+    c->P_valid = false;
     return sync_stream(c);
 }
 
@@ -1916,6 +1973,7 @@ int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const do
     (void)cache_free(dlabel);
     if (e != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("mbar_ctx_fill_masked_rows: ") + hipGetErrorString(e));
     c->u_checked = false;
+    c->P_valid = false;
     flush_timers(c);
     return MBAR_OK;
 }
@@ -1946,6 +2004,7 @@ int mbar_ctx_generate_harmonic(mbar_ctx* c, uint64_t seed, const double* O_k, co
         HIPCHK(c, launch_generate_harmonic(c->stream, c->u, c->ld, c->N, c->K, seed, dO, dK, dC, n_global0));
     }
     c->u_checked = false;
+    c->P_valid = false;
     return sync_stream(c);
 }
 
@@ -1971,6 +2030,7 @@ int mbar_ctx_set_Nk(mbar_ctx* c, const double* N_k) {
     }
     HIPCHK(c, hipMemcpyAsync(d_Nk(c), h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->P_valid = false;  // (the rows of P of states without samples are zero: the set may have changed)
     c->have_Nk = true;
     return MBAR_OK;
 }

@@ -702,9 +702,19 @@ def test_reduced_outputs_are_bit_reproducible(DM, K, N):
             cur = (psum.tobytes(), sld.tobytes(), G.tobytes(), dm.lognum(f).tobytes())
             first = first or cur
             assert cur == first
+        # solves: the first one builds the resident probability matrix, the later ones start warm on it (one fused sweep instead
+        # of the build: other bits than a cold start, the same bits among themselves); with the cache off every solve is cold
         a, ra = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
         b, rb = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
-        assert np.array_equal(a, b) and ra["iterations"] == rb["iterations"]
+        c, rc = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+        assert np.array_equal(b, c) and ra["iterations"] == rb["iterations"] == rc["iterations"]
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+        dm.set_option("pcache", 0)
+        d, rd = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+        e, re_ = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+        assert np.array_equal(a, d) and np.array_equal(d, e)
+        if K <= 128:  # (above 128 states the loop has no resident probability matrix)
+            assert rd["builds"] == 1 == re_["builds"] and rb["warm_starts"] == 1
 
 
 def test_rccl_communicator_single_rank(DM):
@@ -747,3 +757,53 @@ def test_mfma_peak_probe_is_sane(DM):
     with DM.from_host(np.zeros((4, 64))) as dm:
         t = dm.mfma_f64_peak()
     assert 60.0 < t < 90.0, t  # 64 cycles per instruction per SIMD at ~2.4 GHz = 78.6 TFLOP/s
+
+
+def test_resident_probability_matrix_is_reused_across_solves(DM):
+    """The resident probability matrix outlives the solve that built it: a second solve on the same matrix from a start within
+    the window of its anchor begins with ONE fused sweep (no build) -- a bootstrap replicate, the next protocol stage, a
+    restart -- and gives the result of a cold solve; anything that changes the matrix or the sampled-state set, and a start
+    outside the window, build again."""
+    K, N = 48, 30000
+    u_kn, N_k, f = random_problem(K, N, seed=77, unsampled=(9,))
+    sws = np.where(N_k > 0)[0]
+    rng = np.random.default_rng(3)
+    c_n = np.zeros(N)
+    start = 0
+    for n_k in N_k:
+        if n_k > 0:
+            c_n[start:start + n_k] = np.bincount(rng.integers(0, n_k, size=n_k), minlength=n_k)
+        start += n_k
+    with DM.from_host(u_kn) as dm, DM.from_host(u_kn) as cold:
+        cold.set_option("pcache", 0)
+        for d in (dm, cold):
+            d.set_Nk(N_k)
+        f1, r1 = dm.solve_adaptive(np.zeros(K), min_sc_iter=0)
+        assert r1["builds"] == 1 and r1["warm_starts"] == 0
+        f_start = f1 + 0.3 * np.cos(np.arange(K))
+        f_start[sws[0]] = 0.0
+        for fs, weights, msc in ((np.zeros(K), None, 0), (f_start, None, 2), (f1, c_n, 0), (f_start, c_n, 0)):
+            for d in (dm, cold):
+                d.set_sample_weights(weights)
+            fa, ra = dm.solve_adaptive(fs, min_sc_iter=msc, history_rows=50)
+            fb, rb = cold.solve_adaptive(fs, min_sc_iter=msc, history_rows=50)
+            assert ra["warm_starts"] == 1 and ra["builds"] == 0 and rb["builds"] == 1 and rb["warm_starts"] == 0
+            assert ra["success"] and ra["iterations"] == rb["iterations"]
+            np.testing.assert_allclose(fa[sws], fb[sws], rtol=1e-11, atol=1e-11)
+            np.testing.assert_allclose(ra["history"][:, 1:3], rb["history"][:, 1:3], rtol=1e-7, atol=1e-9)
+        for d in (dm, cold):
+            d.set_sample_weights(None)
+        # a start 300 kT away from the anchor: rebuilt there
+        far = f1.copy()
+        far[sws[1:]] += 300.0
+        _, rf = dm.solve_adaptive(far, min_sc_iter=0, maxiter=3, check_convergence=False)
+        assert rf["builds"] >= 1 and rf["warm_starts"] == 0
+        # a changed matrix, and a changed set of sampled states, invalidate it
+        dm.upload_rows(3, u_kn[3] + 0.5)
+        _, rm = dm.solve_adaptive(f1, min_sc_iter=0)
+        assert rm["builds"] == 1 and rm["warm_starts"] == 0
+        N2 = N_k.copy()
+        N2[9], N2[0] = 7, N2[0] - 7
+        dm.set_Nk(N2)
+        _, rn = dm.solve_adaptive(np.zeros(K), min_sc_iter=0, maxiter=4, check_convergence=False)
+        assert rn["builds"] == 1 and rn["warm_starts"] == 0

@@ -45,11 +45,16 @@ for K, N in ((128, 1_000_003), (128, 10_000_000), (256, 400_000), (192, 300_000)
                     c_n[start:start + n_k] = np.bincount(rng.integers(0, n_k, size=n_k), minlength=n_k)
                     start += n_k
                 dm.set_sample_weights(c_n)
-            fs, res = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
-            for r in range(sreps):
-                fs2, res2 = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
-                assert np.array_equal(fs, fs2) and res["iterations"] == res2["iterations"], f"K={K} weighted={weighted}: solve {r} differs"
-                assert np.array_equal(np.asarray(res.get("history", 0)), np.asarray(res2.get("history", 0)))
+            # cold solves (the build sweep every time) and warm ones (the resident probability matrix of the previous solve
+            # re-used: other bits than a cold start, the same bits among themselves)
+            for pcache in (0, 1):
+                dm.set_option("pcache", pcache)
+                dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)  # (pcache = 1: the solve that leaves the matrix behind)
+                fs, res = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+                for r in range(sreps // 2):
+                    fs2, res2 = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+                    assert np.array_equal(fs, fs2) and res["iterations"] == res2["iterations"], f"K={K} weighted={weighted} pcache={pcache}: solve {r} differs"
+                    assert np.array_equal(np.asarray(res.get("history", 0)), np.asarray(res2.get("history", 0)))
         dm.set_sample_weights(None)
         print(f"K={K:4d} N={N:8d}: {reps} evaluations bit-identical ({ref[:12]}), 2 x {sreps} solves reproducible ({res['iterations']} iterations weighted)")
 print("OK")
