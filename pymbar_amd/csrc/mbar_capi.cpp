@@ -554,6 +554,11 @@ void build_aden(const mbar_ctx* c, const double* f, double* out, int64_t rows) {
     for (int64_t k = 0; k < rows; ++k) out[k] = (k < c->K && c->Nk[k] > 0.0) ? f[k] + c->lnNk[k] : ninf;
 }
 
+// 257 .. 512 states: the one-read evaluation kernel whose eight waves split the rows of a tile
+bool split_sweep_ok(const mbar_ctx* c, int64_t rows) {
+    return !use_fast(c) && !c->opt_force_generic && c->opt_staging == 0 && !wide_pitch(c) && rows <= 512 && rows % 64 == 0 && c->opt_wide;
+}
+
 // Evaluation pass for nf vectors whose aden already sits in d_aden (device, row pitch `rows`).
 // Results: red[0 .. nf*rows) = psum, red[nf*rows .. nf*rows+nf) = sum logden.  Not all-reduced.
 int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool use_offset) {
@@ -581,26 +586,24 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
         }
         return MBAR_OK;
     }
-    // 257 .. 512 states: the rows of a tile split over the eight waves of a workgroup -- ONE read of the matrix per candidate
-    // (the layout-agnostic kernels below read it twice: log-sum-exp pass + column-sum pass)
-    if (!c->opt_force_generic && c->opt_staging == 0 && !wide_pitch(c) && rows <= 512 && rows % 64 == 0 && c->opt_wide) {
-        for (int i = 0; i < nf; ++i) {
-            int blocks = 0;
-            int rc = ensure(c, &c->part, &c->part_doubles, (size_t)c->num_cu * (rows + 1));
-            if (rc) return rc;
-            rc = ensure(c, &c->scratch, &c->scratch_doubles, (size_t)(c->num_cu / 32 + 2) * (rows + 1));
-            if (rc) return rc;
-            double* ldst = i == 0 ? ld0 : ld1;
-            double* obj_part = c->part + (size_t)c->num_cu * rows;
-            {
-                ScopedTimer t(c, MBAR_TIMER_LSE);
-                HIPCHK(c, launch_lse_split(c->stream, c->num_cu, c->u, c->ld, c->N, rows, d_aden(c) + i * rows, c->cw, ldst, dn,
-                                           c->part, obj_part, &blocks));
-            }
-            ScopedTimer t(c, MBAR_TIMER_REDUCE);
-            HIPCHK(c, launch_reduce(c->stream, c->part, blocks, rows, c->scratch, c->red + i * rows));
-            HIPCHK(c, launch_reduce(c->stream, obj_part, blocks, 1, c->scratch, c->red + nf * rows + i));
+    // 257 .. 512 states: the rows of a tile split over the eight waves of a workgroup -- ONE read of the matrix for one or
+    // two candidates (the second through its ratio row, like the narrower kernels; the layout-agnostic kernels below read the
+    // matrix twice per candidate: log-sum-exp pass + column-sum pass)
+    if (split_sweep_ok(c, rows)) {
+        int blocks = 0;
+        int rc = ensure(c, &c->part, &c->part_doubles, (size_t)c->num_cu * nf * (rows + 1));
+        if (rc) return rc;
+        rc = ensure(c, &c->scratch, &c->scratch_doubles, (size_t)(c->num_cu / 32 + 2) * nf * (rows + 1));
+        if (rc) return rc;
+        double* obj_part = c->part + (size_t)c->num_cu * nf * rows;
+        {
+            ScopedTimer t(c, MBAR_TIMER_LSE);
+            HIPCHK(c, launch_lse_split(c->stream, c->num_cu, nf, c->u, c->ld, c->N, rows, d_aden(c), c->cw, ld0, nf == 2 ? ld1 : nullptr, dn,
+                                       c->part, obj_part, &blocks));
         }
+        ScopedTimer t(c, MBAR_TIMER_REDUCE);
+        HIPCHK(c, launch_reduce(c->stream, c->part, blocks, (int64_t)nf * rows, c->scratch, c->red));
+        HIPCHK(c, launch_reduce(c->stream, obj_part, blocks, nf, c->scratch, c->red + (size_t)nf * rows));
         return MBAR_OK;
     }
     // generic: one f at a time
@@ -840,7 +843,7 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
     for (int i = 0; i < nf; ++i) build_aden(c, f + (size_t)i * c->K, h.data() + (size_t)i * rows, rows);
     bool split = false;
     std::vector<double> ratio;  // c_k of the fused two-candidate sweep; applied to its second psum row below
-    if (nf == 2 && use_fast(c)) {
+    if (nf == 2 && (use_fast(c) || split_sweep_ok(c, rows))) {
         double dmax = 0.0;
         for (int64_t k = 0; k < rows; ++k) {
             const double a0 = h[k], a1 = h[rows + k];

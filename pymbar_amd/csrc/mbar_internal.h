@@ -107,8 +107,11 @@ hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const d
                             const double* anum, const double* logden, double* gram_part, const LoopCtl& lc = LoopCtl());
 
 // ---- layout-agnostic fallbacks (any K) ---------------------------------------------------------
-hipError_t launch_lse_split(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
-                            const double* cw, double* logden, const double* dn, double* psum_part, double* obj_part, int* blocks_out);
+// 257 .. 512 states in one read: nf = 2 evaluates a second candidate through the ratio row aden[rows + k] = exp(a'_k - a_k)
+// (per-state sums without that factor); psum_part [blocks][nf][rows], obj_part [blocks][nf]
+hipError_t launch_lse_split(hipStream_t s, int num_cu, int nf, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
+                            const double* cw, double* logden, double* logden1, const double* dn, double* psum_part, double* obj_part,
+                            int* blocks_out);
 hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
                               const double* aden, const double* cw, double* logden, const double* dn,
                               double* obj_part /*[blocks]*/, int* blocks_out);

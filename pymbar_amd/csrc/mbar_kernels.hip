@@ -1093,11 +1093,12 @@ k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // is ONE exponential per element) and the per-sample sums.  Rows past the allocated pitch are never requested (their LDS rows
 // stay zero and their a_k is -inf).  Partial records: one per workgroup, `rows` entries + one objective term.
 // ---------------------------------------------------------------------------------------------
-template <int NBW>
+template <int NBW, int NF>
 __global__ void __launch_bounds__(512, 1)
 k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, int64_t rows,
             const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden,
-            const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+            double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
+            double* __restrict__ obj_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RW = NBW * 16;                  // rows per wave
     constexpr int NP = RW / 8;                    // LDS-DMA pieces per wave and tile
@@ -1109,8 +1110,8 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const int ks = lane & 15, ns = lane >> 4;
     exp_table_init(smem);
     double* xmax = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);  // [NW][TS]
-    double* xsum = xmax + NW * TS;                                     // [NW][TS]
-    char* buf = smem + EXP_TABLE_BYTES + 2 * NW * TS * 8 + wave * (2 * TILE_BYTES);
+    double* xsum = xmax + NW * TS;                                     // [NF][NW][TS]
+    char* buf = smem + EXP_TABLE_BYTES + (1 + NF) * NW * TS * 8 + wave * (2 * TILE_BYTES);
     const int64_t r0 = (int64_t)wave * RW;
     const StageOffsets so = make_stage_offsets(ld, lane);
     // rows this wave never requests: zero once, in both buffers
@@ -1119,15 +1120,24 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             for (int bsel = 0; bsel < 2; ++bsel) *reinterpret_cast<double2*>(buf + bsel * TILE_BYTES + j * 1024 + lane * 16) = double2{0.0, 0.0};
         }
     __syncthreads();
-    double a[NBW], acc[NBW], objl = 0.0;
+    // second candidate (NF == 2): aden[rows + k] holds the ratio c_k = exp(a'_k - a_k); its exponentials are the first one's
+    // times c_k (one exponential per element for both), its per-state sums are accumulated without c_k (applied by the caller)
+    double a[NBW], c[NBW], acc[NF][NBW], objl[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) objl[f] = 0.0;
 #pragma unroll
     for (int I = 0; I < NBW; ++I) {
         const int64_t r = r0 + 16 * I + ks;
         a[I] = r < rows ? aden[r] : -INFINITY;
-        acc[I] = 0.0;
+        c[I] = (NF == 2 && r < rows) ? aden[rows + r] : 0.0;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[f][I] = 0.0;
     }
 #pragma unroll
-    for (int I = 0; I < NBW; ++I) settle(a[I]);
+    for (int I = 0; I < NBW; ++I) {
+        settle(a[I]);
+        if (NF == 2) settle(c[I]);
+    }
     const int rd_base = ks * (TS * 8);
     int pos[GROUPS];
 #pragma unroll
@@ -1162,7 +1172,7 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             if (ks == 0) xmax[wave * TS + 4 * g + ns] = mloc[g];
         }
         __syncthreads();
-        double m2[GROUPS], sloc[GROUPS];
+        double m2[GROUPS];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             double m = xmax[4 * g + ns];
@@ -1172,40 +1182,59 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 #pragma unroll
             for (int I = 0; I < NBW; ++I) x[g][I] = fma(x[g][I], LOG2E_S, -m2[g]);
             exp2s_batch<NBW>(x[g]);
-            sloc[g] = row16_sum(tree_sum<NBW>(x[g]));
-            if (ks == 0) xsum[wave * TS + 4 * g + ns] = sloc[g];
+            double s0 = tree_sum<NBW>(x[g]), s1 = NF == 2 ? dot_sum<NBW>(x[g], c) : 0.0;
+            if constexpr (NF == 2) row16_sum2(s0, s1); else s0 = row16_sum(s0);
+            if (ks == 0) {
+                xsum[wave * TS + 4 * g + ns] = s0;
+                if constexpr (NF == 2) xsum[NW * TS + wave * TS + 4 * g + ns] = s1;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            double ssum = xsum[4 * g + ns];
+            double ssum[NF];
 #pragma unroll
-            for (int wv = 1; wv < NW; ++wv) ssum += xsum[wv * TS + 4 * g + ns];  // (fixed order: every wave gets the same bits)
-            const double r = w[g] * recip_fast(ssum);
+            for (int f = 0; f < NF; ++f) {
+                ssum[f] = xsum[f * NW * TS + 4 * g + ns];
 #pragma unroll
-            for (int I = 0; I < NBW; ++I) acc[I] = fma(x[g][I], r, acc[I]);
-            if (wave == 0 && ks == 0) {  // logden_n = shift + log(sum), one lane per sample
+                for (int wv = 1; wv < NW; ++wv) ssum[f] += xsum[f * NW * TS + wv * TS + 4 * g + ns];  // (fixed order: every wave gets the same bits)
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const double r = w[g] * recip_fast(ssum[f]);
+#pragma unroll
+                for (int I = 0; I < NBW; ++I) acc[f][I] = fma(x[g][I], r, acc[f][I]);
+            }
+            if (wave == 0 && ks < NF) {  // logden_n = shift + log(sum), one lane per sample and candidate
                 const int64_t n = t * TS + 4 * g + ns;
                 if (n < N) {
-                    const double ldv = fma(m2[g], LN2_OVER_S, log_pos(ssum));
-                    if (logden) logden[n] = ldv;
-                    objl = fma(w[g], dn ? (ldv - dn[n]) : ldv, objl);
+                    const double sv = ks == 0 ? ssum[0] : ssum[NF - 1];
+                    const double ldv = fma(m2[g], LN2_OVER_S, log_pos(sv));
+                    double* out = ks == 0 ? logden : logden1;
+                    if (out) out[n] = ldv;
+                    const double term = w[g] * (dn ? (ldv - dn[n]) : ldv);
+                    if (ks == 0) objl[0] += term; else objl[NF - 1] += term;
                 }
             }
         }
         cur ^= 1;
     }
 #pragma unroll
-    for (int I = 0; I < NBW; ++I) {
-        double v = acc[I];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        const int64_t r = r0 + 16 * I + lane;
-        if (lane < 16 && r < rows) psum_part[(int64_t)blockIdx.x * rows + r] = v;
-    }
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int I = 0; I < NBW; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int64_t r = r0 + 16 * I + lane;
+            if (lane < 16 && r < rows) psum_part[((int64_t)blockIdx.x * NF + f) * rows + r] = v;
+        }
     if (wave == 0) {
-        const double o = wave_sum(objl);
-        if (lane == 0) obj_part[blockIdx.x] = o;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const double o = wave_sum(objl[f]);
+            if (lane == 0) obj_part[(int64_t)blockIdx.x * NF + f] = o;
+        }
     }
 }
 
@@ -4148,13 +4177,14 @@ static int stream_blocks(int num_cu, int64_t N) {
 }
 
 // 257 .. 512 states in one read: rows = allocated row count (a multiple of 64); returns the number of partial records.
-hipError_t launch_lse_split(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
-                            const double* cw, double* logden, const double* dn, double* psum_part, double* obj_part, int* blocks_out) {
+hipError_t launch_lse_split(hipStream_t s, int num_cu, int nf, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
+                            const double* cw, double* logden, double* logden1, const double* dn, double* psum_part, double* obj_part,
+                            int* blocks_out) {
     const int nbw = (int)((rows + 127) / 128);
-    if (nbw < 1 || nbw > 4) return hipErrorInvalidValue;
+    if (nbw < 1 || nbw > 4 || nf < 1 || nf > 2) return hipErrorInvalidValue;
     const int64_t ntiles = (N + TS - 1) / TS;
     const size_t tile = (size_t)nbw * 16 * TS * 8 + TS * 8;
-    const size_t lds = EXP_TABLE_BYTES + (size_t)2 * 8 * TS * 8 + (size_t)8 * 2 * tile;
+    const size_t lds = EXP_TABLE_BYTES + (size_t)(1 + nf) * 8 * TS * 8 + (size_t)8 * 2 * tile;
     const int blocks = (int)(ntiles < num_cu ? (ntiles < 1 ? 1 : ntiles) : num_cu);
     *blocks_out = blocks;
     auto go = [&](auto kern) -> hipError_t {
@@ -4162,14 +4192,23 @@ hipError_t launch_lse_split(hipStream_t s, int num_cu, const double* u, int64_t 
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, u, ld, N, ntiles, rows, aden, cw, logden, dn, psum_part, obj_part);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, u, ld, N, ntiles, rows, aden, cw, logden, logden1, dn, psum_part,
+                           obj_part);
         return hipGetLastError();
     };
+    if (nf == 1) {
+        switch (nbw) {
+            case 1: return go(k_lse_split<1, 1>);
+            case 2: return go(k_lse_split<2, 1>);
+            case 3: return go(k_lse_split<3, 1>);
+            default: return go(k_lse_split<4, 1>);
+        }
+    }
     switch (nbw) {
-        case 1: return go(k_lse_split<1>);
-        case 2: return go(k_lse_split<2>);
-        case 3: return go(k_lse_split<3>);
-        default: return go(k_lse_split<4>);
+        case 1: return go(k_lse_split<1, 2>);
+        case 2: return go(k_lse_split<2, 2>);
+        case 3: return go(k_lse_split<3, 2>);
+        default: return go(k_lse_split<4, 2>);
     }
 }
 
