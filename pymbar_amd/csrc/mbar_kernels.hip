@@ -3673,14 +3673,17 @@ k_select(AdaptArgs q) {
     if (q.fused && Kp / 16 >= FUSED_PSUM1_FROM_GRAM_NB) {
         // the fused sweep of a full panel left the unscaled sums of its SECOND multiplier row c to be taken from the Gram matrix
         // it accumulated for that candidate: sum_n w_n P_kn / s_n = sum_j c_j G'_kj (rows of p sum to one)
-        __shared__ double s_c[128];
+        __shared__ double s_c[128], s_half[128];
         if (tid < Kp) s_c[tid] = q.aden[Kp + tid];
         __syncthreads();
+        // (two threads per state, half of the columns each: the loads are what this costs)
+        const int k = tid & 127, h = tid >> 7, nb = Kp / 16;
         double acc = 0.0;
-        if (in) {
-            const int nb = Kp / 16;
-            for (int j = 0; j < Kp; ++j) acc = fma(s_c[j], gram_elem(q.gram_red, nb, tid, j), acc);
-        }
+#pragma unroll 8
+        for (int j = h * 64; j < h * 64 + 64; ++j) acc = fma(s_c[j], gram_elem(q.gram_red, nb, k, j), acc);
+        if (h == 1) s_half[k] = acc;
+        __syncthreads();
+        if (h == 0) acc += s_half[k];
         if (swap) raw0 = acc; else raw1 = acc;
     }
     const double ps0 = raw0 * m0;

@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""State counts beyond one Gram panel (K > 128): what the sweeps and the adaptive iteration cost there.
+
+  gram    W^T W Gram sweep (mbar_gram_w) at K = 160 ... 256: 128-state panels + 64 x 128 rectangles (2.5 reads of the matrix)
+          against the one-read kernel whose four waves share a tile stream (k_gram_quad), in ms and as a fraction of the fp64
+          matrix peak on N K (K + 1) flop;
+  loop    one adaptive iteration at K = 192 / 256: host-driven loop (panels / one-read Gram) against the device-resident loop
+          (one-read Gram, four-waves-per-CU evaluation sweep, blocked Cholesky Newton solve in device memory);
+  split   evaluation sweep at 257 ... 512 states: one and two candidates, row-split kernel against the layout-agnostic path.
+
+Usage: python tools/bench_wide.py [gram] [loop] [split]   (default: all)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pymbar_amd import testsystems as ts  # noqa: E402
+from pymbar_amd.device import DeviceMatrix  # noqa: E402
+
+PEAK = 78.6
+
+
+def ladder(K, N):
+    O_k, K_k, N_k = ts.config3_params(K=K, N=N)
+    N_k[-1] += N - N_k.sum()
+    return O_k, K_k, N_k
+
+
+def gram():
+    for K, N in ((160, 2_000_000), (192, 2_000_000), (256, 2_000_000), (256, 4_000_000)):
+        O_k, K_k, N_k = ladder(K, N)
+        with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
+            dm.set_Nk(N_k)
+            dm.set_option("timing", 1)
+            f = ts.harmonic_free_energies(K_k)
+            res = {}
+            for q in (0, 1):
+                dm.set_option("gram_quad", q)
+                G, _ = dm.gram_w(f)
+                dm.timing_reset()
+                for _ in range(6):
+                    dm.gram_w(f)
+                res[q] = (G, dm.timing()["gram"][0] / 6)
+            flop = N * K * (K + 1.0)
+            d = np.max(np.abs(res[0][0] - res[1][0])) / np.max(np.abs(res[0][0]))
+            print(f"gram_w K={K} N={N}: panels {res[0][1]:.3f} ms = {flop / res[0][1] * 1e-9 / PEAK:.3f} of the fp64 matrix peak | one read "
+                  f"{res[1][1]:.3f} ms = {flop / res[1][1] * 1e-9 / PEAK:.3f} | largest relative difference {d:.1e}", flush=True)
+
+
+def loop():
+    for K, N in ((256, 4_000_000), (192, 4_000_000)):
+        O_k, K_k, N_k = ladder(K, N)
+        with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
+            dm.set_Nk(N_k)
+            for name, opts in (("host-driven loop, panel Gram", dict(device_loop=0, gram_quad=0)),
+                               ("host-driven loop, one-read Gram", dict(device_loop=0, gram_quad=1)),
+                               ("device-resident loop", dict(device_loop=1, gram_quad=1))):
+                for k, v in opts.items():
+                    dm.set_option(k, v)
+                dm.solve_adaptive(np.zeros(K), maxiter=3, min_sc_iter=0, check_convergence=False)
+                dm.synchronize()
+                t0 = time.perf_counter()
+                dm.solve_adaptive(np.zeros(K), maxiter=12, min_sc_iter=0, check_convergence=False)
+                dt = (time.perf_counter() - t0) / 12
+                t1 = time.perf_counter()
+                fc, rc = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+                dtc = time.perf_counter() - t1
+                print(f"adaptive K={K} N={N} {name:32s}: {1e3 * dt:7.3f} ms per iteration; solve from f=0: {rc['iterations']} iterations "
+                      f"{1e3 * dtc:7.2f} ms, success={rc['success']}", flush=True)
+
+
+def split():
+    for K, N in ((257, 2_000_000), (300, 1_000_000), (384, 1_000_000), (512, 1_000_000), (512, 4_000_000)):
+        O_k, K_k, N_k = ladder(K, N)
+        with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
+            dm.set_Nk(N_k)
+            f = ts.harmonic_free_energies(K_k)
+            f2 = np.stack([f, f * 0.99])
+            gb = 8.0 * K * N * 1e-9
+            out = []
+            for force in (1, 0):
+                dm.set_option("force_generic", force)
+                for name, fn in (("1 candidate", lambda: dm.eval(f)), ("2 candidates", lambda: dm.eval(f2))):
+                    fn()
+                    dm.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        fn()
+                    dt = (time.perf_counter() - t0) / 10
+                    out.append(f"{'layout-agnostic' if force else 'row-split'} {name} {1e3 * dt:7.3f} ms ({gb / dt * 1e-3:4.2f} TB/s of one read)")
+            print(f"eval K={K} N={N}: " + " | ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or ["gram", "loop", "split"]
+    for w in want:
+        {"gram": gram, "loop": loop, "split": split}[w]()
