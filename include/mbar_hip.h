@@ -95,6 +95,9 @@ int mbar_device_synchronize(int device);
  *   "pcache"         1 = the resident probability matrix outlives the solve that built it: a later adaptive solve on the same
  *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
  *                    one fused sweep instead of the build sweep (default); 0 = every solve builds
+ *   "persistent"     1 = small problems (up to 80 states, up to ~1e6 samples, one rank): the whole device-resident loop runs in
+ *                    ONE launch of a persistent grid with grid barriers between its phases (parity-tested; measured slower than
+ *                    the five launches per iteration it replaces: 77 against 51 us at K=40, N=95000); 0 = default
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
  *   "timing"         HIP-event timers (mbar_ctx_timing): 0 = off (default: an event pair per sweep costs ~10 us, a fifth of an
  *                    iteration at the problem sizes pymbar is mostly used on), 1 = event records around a launch, 2 = events

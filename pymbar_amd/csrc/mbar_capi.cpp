@@ -257,6 +257,9 @@ struct mbar_ctx {
     size_t part_g_doubles = 0;
     double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
     double* chol = nullptr;         // workspace of the blocked Cholesky Newton solve (129 .. 256 states)
+    double* sm_buf = nullptr;       // persistent small-problem loop: per-workgroup records [2][grid][E] | reduced [2][E]
+    size_t sm_doubles = 0;
+    unsigned* sm_bar = nullptr;     // ... its grid-barrier counter and timeout flag
     // P outlives the solve that built it: a later solve on the same matrix whose start lies within the window of the anchor
     // (bootstrap replicates, protocol stages, continuation) starts with ONE fused sweep instead of the build sweep
     bool P_valid = false;
@@ -264,7 +267,7 @@ struct mbar_ctx {
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_persistent = 0;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -1309,6 +1312,17 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
                      std::max(((size_t)std::max(gg.nwaves, gl.nwaves) / 32 + 1) * (rec_g + rec_l + 2), ((size_t)gb.nwaves / 32 + 1) * (Kp + rec_g)));
     if (!arc && c->weighted && !c->lden_eff) arc = fail(c, MBAR_ERR_STATE, "weighted context without its logden buffer");
     if (!arc && fused) arc = ensure(c, &c->part_g, &c->part_g_doubles, (size_t)gl.nwaves * rec_g);
+    // Small problems on one rank, OPTIONAL ("persistent", off): the whole loop in ONE launch (persistent grid, k_solve_small) -- up
+    // to 80 states, matrices of up to ~1e6 samples.  Measured SLOWER than five launches per iteration (config 5: 77 against 51 us
+    // per iteration): a phase change through a grid barrier and device-scope visibility costs 10-20 us, a kernel boundary ~5
+    const bool small = fused && !wide && nb <= 5 && c->nranks <= 1 && !stream_transport(c) && c->opt_persistent && ntiles <= 65536 &&
+                       m - 1 <= (nb <= 4 ? 63 : 127);
+    const int sm_grid = small ? solve_small_grid(c->num_cu, ntiles, c->opt_grid) : 0;
+    const size_t sm_E = small ? solve_small_record_doubles(nb) : 0;
+    if (!arc && small) arc = ensure(c, &c->sm_buf, &c->sm_doubles, (size_t)2 * sm_grid * sm_E + 2 * sm_E);
+    if (!arc && small) arc = ensure(c, &c->part, &c->part_doubles, (size_t)psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid).nwaves * Kp);
+    if (!arc && small && !c->sm_bar && cache_malloc((void**)&c->sm_bar, 64) != hipSuccess)
+        arc = fail(c, MBAR_ERR_HIP, "allocation of the grid-barrier words failed");
     {
         bool ok = arc == MBAR_OK;
         const std::string local_err = c->error;
@@ -1602,8 +1616,31 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         const int64_t want = std::min(ramp, nbatch < 3 ? std::min(batch, first_batches[nbatch]) : batch);
         ++nbatch;
         ramp = std::min(batch, ramp * 2);
-        const int64_t nbat = std::min(want, maxiter - it);
-        if (use_graph && nbat == batch) {
+        int64_t nbat = std::min(want, maxiter - it);
+        if (small) {
+            // the persistent kernel runs until the loop stops by itself (converged, handed back, paused) or the budget ends
+            nbat = std::min<int64_t>(maxiter - it, 1 << 30);
+            SmallArgs sa;
+            sa.P = c->P;
+            sa.ld = c->ld;
+            sa.N = c->N;
+            sa.ntiles = ntiles;
+            sa.cw = c->cw;
+            sa.wsq = c->weighted ? c->cwsq : c->cw;
+            sa.rinv_base = c->logden[0];
+            sa.slot_stride = c->ld;
+            sa.rec = c->sm_buf;
+            sa.red = c->sm_buf + (size_t)2 * sm_grid * sm_E;
+            sa.bar = c->sm_bar;
+            sa.max_iters = (int)nbat;
+            sa.q = q;
+            HIPCHK(c, hipMemsetAsync(c->sm_bar, 0, 64, c->stream));
+            HIPCHK(c, launch_solve_small(c->stream, nb, sm_grid, sa));
+            unsigned hb[2] = {0, 0};
+            HIPCHK(c, hipMemcpyAsync(hb, c->sm_bar, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (hb[1] != 0) return fail(c, MBAR_ERR_STATE, "persistent solver kernel: a grid barrier was not met (workgroups not co-resident?)");
+        } else if (use_graph && nbat == batch) {
             rc = prepare_graph();
             if (rc) return rc;
             HIPCHK(c, hipGraphLaunch(c->ad_graph, c->stream));
@@ -1628,6 +1665,13 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             // Gram matrix has to be swept separately.  Every rank sees the same control words, so every rank comes by here.
             if (it_new <= it || it_new > it + nbat) return fail(c, MBAR_ERR_STATE, "device-resident adaptive loop lost count of its iterations");
             if (it_new < maxiter) {
+                if (small) {
+                    // the persistent kernel does not store the reciprocals 1 / s_n (nothing in its loop reads them): the Gram sweep of
+                    // the accepted candidate does, so they are recomputed here -- one single-candidate sweep with its multipliers
+                    const LaunchGeom gp = psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid);
+                    HIPCHK(c, launch_psweep(c->stream, nb, 1, gp, c->P, c->ld, c->N, c->pm_vec + Kp, c->cw,
+                                            c->logden[0] + (int64_t)c->h_ctl[CTL_SLOT] * c->ld, nullptr, c->part, LoopCtl()));
+                }
                 rc = enqueue_gram(c->opt_timing != 0);
                 if (rc) return rc;
                 ++gram_sweeps;
@@ -1797,6 +1841,8 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->part_g) (void)cache_free(c->part_g);
     if (c->cwsq) (void)cache_free(c->cwsq);
     if (c->chol) (void)cache_free(c->chol);
+    if (c->sm_buf) (void)cache_free(c->sm_buf);
+    if (c->sm_bar) (void)cache_free(c->sm_bar);
     if (c->ad_ints) (void)cache_free(c->ad_ints);
     if (c->h_ctl) (void)cache_host_free(c->h_ctl);
     if (c->ad_graph) (void)hipGraphExecDestroy(c->ad_graph);
@@ -1862,6 +1908,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "gram_quad") c->opt_quad = value;
     else if (k == "device_loop_wide") c->opt_device_loop_wide = value;
     else if (k == "pcache") c->opt_pcache = value;
+    else if (k == "persistent") c->opt_persistent = value;
     else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;

@@ -190,6 +190,27 @@ struct AdaptArgs {
     int fused;
     double* cgram;           // [Kp]
 };
+// ---- small problems: the whole device-resident loop in ONE launch (k_solve_small) ---------------------------------------
+// Up to 80 states (nb <= 5 blocks of 16) and a matrix of a few hundred MB at most, single rank, P mode: a persistent grid of
+// one workgroup per compute unit runs {Newton solve, fused sweep, fold, grid barrier, reduction, grid barrier, selection}
+// per iteration until the loop stops (converged / handed back / paused / iteration budget) -- no launches in between.
+struct SmallArgs {
+    const double* P;
+    int64_t ld, N, ntiles;
+    const double* cw;
+    const double* wsq;
+    double* rinv_base;      // three slot vectors, pitch slot_stride
+    int64_t slot_stride;
+    double* rec;            // [2][grid][E] per-workgroup records, E = 2 Kp + nblk 256 (double-buffered by iteration parity)
+    double* red;            // [2][E] reduced records
+    unsigned* bar;          // [0] arrivals at the grid barriers of this launch (zeroed by the host), [1] timeout flag
+    int max_iters;          // iterations this launch may run
+    AdaptArgs q;            // the solver state in device memory (read at entry, written back at exit)
+};
+size_t solve_small_record_doubles(int nb);                 // E
+int solve_small_grid(int num_cu, int64_t ntiles, int64_t grid_override);
+hipError_t launch_solve_small(hipStream_t s, int nb, int grid, const SmallArgs& a);
+
 // ---- P mode: resident probability matrix P = exp(a0 - u - logden(a0)) (see k_psweep) ----------------------------------
 LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
 // cmul: [nf][16 nb] multipliers exp(a - a0); rinv0 = base of the three slot vectors when lc.ctl is set

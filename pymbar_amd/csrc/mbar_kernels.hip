@@ -3252,8 +3252,7 @@ __device__ __forceinline__ void newton_tail(const AdaptArgs& q, const double* xs
 // non-finite candidate hand the solve back to the host loop (CTL_DONE = 2).
 // Outputs: cand = (f_sci, f_nr), ratio = exp(aden_nr - aden_sci), aden = (aden_sci, ratio) for the sweep.
 template <int T, int R>
-__global__ void __launch_bounds__(T * T)
-k_newton(AdaptArgs q) {
+__device__ __forceinline__ void newton_body(const AdaptArgs& q) {  // (T * T threads; the pointers of q may be LDS or global)
     constexpr int NC = R * T, NT = T * T;
     __shared__ double colbuf[2][2][NC];  // [parity of the step][column j, column j + 1]
     __shared__ double pv[NC], rh[NC], xs[NC + 1];
@@ -3408,6 +3407,11 @@ k_newton(AdaptArgs q) {
     __syncthreads();
 
     newton_tail<NT>(q, xs, bad, s_f, s_ps, s_nk, s_ln, s_a0, smp, pos, tid);
+}
+template <int T, int R>
+__global__ void __launch_bounds__(T * T)
+k_newton(AdaptArgs q) {
+    newton_body<T, R>(q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3649,8 +3653,7 @@ k_chol_finish(AdaptArgs q, const double* __restrict__ Aw) {
 // Choice between the candidates and convergence test, one workgroup of 256 threads (one state per thread).  The two
 // gradient norms are fixed-order tree sums (deterministic; the host loop adds the same terms serially, so a round-off
 // tie between the candidates may fall differently there), the convergence measures are maxima.
-__global__ void __launch_bounds__(256)
-k_select(AdaptArgs q) {
+__device__ __forceinline__ void select_body(const AdaptArgs& q) {  // (256 threads; the pointers of q may be LDS or global)
     __shared__ double red[4];
     int* ctl = q.ctl;
     if (ctl[CTL_DONE] != 0) return;
@@ -3742,6 +3745,10 @@ k_select(AdaptArgs q) {
             ctl[CTL_DONE] = 3;  // pause: the host enqueues the Gram sweep of the accepted candidate (same flags on every rank)
     }
 }
+__global__ void __launch_bounds__(256)
+k_select(AdaptArgs q) {
+    select_body(q);
+}
 
 __global__ void __launch_bounds__(256)
 k_loop_reduce(LoopSrc src, int64_t count, int op, double* __restrict__ out) {
@@ -3750,6 +3757,269 @@ k_loop_reduce(LoopSrc src, int64_t count, int op, double* __restrict__ out) {
     double v = src.p[0][i];
     for (int r = 1; r < src.n; ++r) v = op == 0 ? v + src.p[r][i] : fmax(v, src.p[r][i]);
     out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small problems: the whole device-resident loop in ONE launch.
+// At the sizes pymbar is mostly run at (tens of states, 1e4 - 1e6 samples: a sweep of 5-20 us) an iteration of five launches
+// is the fixed cost of its launches -- 3-4 us each before any work -- plus a thousand partial records written and re-read.
+// Here a persistent grid of ONE workgroup per compute unit (at most) loops over the iterations itself:
+//   [K x K Newton solve + candidates: every workgroup, redundantly, on its OWN copy of the solver state in LDS -- identical
+//    inputs, identical bits, no broadcast]  [fused sweep over the workgroup's tiles: both candidates' normalisers and per-state
+//    sums + the Gram matrix of the second one on the matrix cores]  [the four waves' records folded through LDS: ONE record per
+//    workgroup]  [grid barrier]  [the records reduced in a fixed order, four threads per entry spread over the grid]
+//   [grid barrier]  [selection + convergence test: every workgroup, redundantly]
+// Records and reduced values are double-buffered by the parity of the iteration, which is what lets two barriers per iteration
+// suffice.  The loop stops like the multi-launch one: converged, handed back, paused for a separate Gram sweep (the host takes
+// over from the state workgroup 0 writes back), or out of iterations.  A barrier that is not met within ~0.5 s raises a flag
+// and every workgroup leaves (the host then reports an error instead of hanging the device).
+// The sweep is the plain one (compiler-scheduled matrix instructions, NB <= 5: at most 15 blocks) -- at these sizes it is not
+// what the iteration costs.
+// ---------------------------------------------------------------------------------------------
+// Grid barrier of the persistent kernel.  What the workgroups exchange through device memory (records, reduced values) is
+// written with agent-scope stores (write-through: visible to the other XCDs' L2 without a cache write-back) and read after an
+// agent-scope acquire (an invalidate) -- a full __threadfence() here writes back the whole L2 per workgroup and cost 20 us.
+__device__ __forceinline__ void store_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target) {
+    __syncthreads();  // (every thread's stores have been waited for)
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 21) || __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (invalidate: what the other workgroups wrote is read from memory)
+    return __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+}
+
+__host__ __device__ constexpr int small_ring_depth(int nb) { return nb == 1 ? 8 : (nb == 2 ? 6 : (nb == 3 ? 5 : 3)); }
+template <int NB>
+__global__ void __launch_bounds__(256, 1)
+k_solve_small(SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16, NBLK = NB * (NB + 1) / 2;
+    constexpr int REC_L = 2 * ROWS, REC_G = NBLK * 256, E = REC_L + REC_G;
+    constexpr int NSTG = ROWS / 8 + 2;                // LDS-DMA instructions per tile: the rows + the multiplicities + their roots
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + 2 * TS * 8;  // + the tile's 16 multiplicities and their roots
+    constexpr int DEPTH = small_ring_depth(NB);
+    constexpr int R = NB <= 4 ? 4 : 8;                // register tile of the Newton solve (16 x 16 threads): 63 / 127 unknowns
+    __shared__ double s_f[ROWS], s_psum[ROWS], s_cand[2 * ROWS], s_ratio[ROWS], s_aden[2 * ROWS], s_anum[ROWS], s_ccur[ROWS],
+        s_cgram[ROWS], s_state[2];
+    __shared__ int s_ctl[CTL_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = lane & 15, ns = lane >> 4;
+    const int G = gridDim.x;
+    const AdaptArgs& qg = a.q;
+    for (int k = tid; k < ROWS; k += 256) {
+        s_f[k] = qg.f[k];
+        s_psum[k] = qg.psum[k];
+        s_anum[k] = qg.anum[k];
+        s_ccur[k] = qg.ccur[k];
+        s_cgram[k] = qg.cgram[k];
+        s_ratio[k] = 1.0;
+        s_cand[k] = s_cand[ROWS + k] = 0.0;
+        s_aden[k] = s_aden[ROWS + k] = 0.0;
+    }
+    if (tid < CTL_WORDS) s_ctl[tid] = qg.ctl[tid];
+    if (tid == 0) s_state[0] = qg.state[0];
+    __syncthreads();
+    AdaptArgs ql = a.q;  // this workgroup's view: the mutable state lives in its LDS
+    ql.f = s_f;
+    ql.psum = s_psum;
+    ql.cand = s_cand;
+    ql.ratio = s_ratio;
+    ql.aden = s_aden;
+    ql.anum = s_anum;
+    ql.ccur = s_ccur;
+    ql.cgram = s_cgram;
+    ql.ctl = s_ctl;
+    ql.state = s_state;
+    if (blockIdx.x != 0) ql.hist_cap = 0;  // (the history rows are written once, by workgroup 0)
+
+    char* buf = smem + wave * (DEPTH * TILE_BYTES);
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t W = (int64_t)G * 4;
+    const RowIdentity rows{0};
+    const StageOffsets so = make_stage_offsets(a.ld, lane);
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+    auto stage = [&](int64_t tile, char* dst) {
+        stage_tile<ROWS, true, 0, 1>(a.P, a.ld, tile * TS, dst, lane, so, rows);
+        stage_vec16<true>(a.cw, tile * TS, dst + U_BYTES, lane);
+        stage_vec16<true>(a.wsq, tile * TS, dst + U_BYTES + TS * 8, lane);
+    };
+
+    unsigned nbar = 0;
+    int par = 0;
+    bool ok = true;
+#ifdef MBAR_EXPERIMENT_SMALL_TIMING  // instrumented build: where an iteration of the persistent loop spends its time (workgroup 0)
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+    int nit = 0;
+#define SMALL_TICK(i) do { const long long tn_ = wall_clock64(); tph[i] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define SMALL_TICK(i) do { } while (0)
+#endif
+    for (int it = 0; it < a.max_iters && ok; ++it) {
+        if (s_ctl[CTL_DONE] != 0) break;
+        SMALL_TICK(5);
+        newton_body<16, R>(ql);
+        __syncthreads();
+        SMALL_TICK(0);
+        if (s_ctl[CTL_DONE] != 0) break;  // (handed back: Newton system not positive definite, candidate out of the window)
+        // ---- fused sweep over this wave's tiles
+        double c0[NB], c1[NB], acc0[NB], acc1[NB];
+        v4d Gm[NBLK];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            c0[I] = s_aden[16 * I + ks];
+            c1[I] = s_aden[ROWS + 16 * I + ks];
+            acc0[I] = acc1[I] = 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) Gm[b] = v4d{0.0, 0.0, 0.0, 0.0};
+        __syncthreads();  // (the fold region of the previous iteration is the tile buffers' memory)
+        // Ring of DEPTH tile buffers per wave: a wave has a handful of tiles (a few hundred KB of matrix per compute unit), so
+        // what a tile costs is the latency of its LDS-DMA -- all of a wave's first DEPTH tiles are requested at once.  No store in
+        // this loop (vmcnt counts the LDS-DMA pieces only, in order): the reciprocals 1 / s_n are not written -- only a separate
+        // Gram sweep after a pause reads them, and the host has them recomputed then.
+        const int64_t ntw = gw < a.ntiles ? (a.ntiles - gw + W - 1) / W : 0;  // tiles of this wave
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j)
+            if (j < ntw) stage(gw + j * W, buf + j * TILE_BYTES);
+        int cur = 0;
+        for (int64_t j = 0; j < ntw; ++j) {
+            char* cbuf = buf + cur * TILE_BYTES;
+            if (j + DEPTH - 1 < ntw)
+                wait_vm<(DEPTH - 1) * NSTG>();  // exactly DEPTH - 1 younger tiles are in flight
+            else
+                wait_vm<0>();
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                double x[NB];
+#pragma unroll
+                for (int I = 0; I < NB; ++I) x[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g]);
+                const double w = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+                const double sw = *reinterpret_cast<const double*>(cbuf + U_BYTES + TS * 8 + (4 * g + ns) * 8);
+                double d0 = dot_sum<NB>(x, c0), d1 = dot_sum<NB>(x, c1);
+                row16_sum2(d0, d1);
+                // (a padded sample has an all-zero column: keep its reciprocal finite, its multiplicity is 0)
+                const double r0 = recip_fast(fmax(d0, 1e-300)), r1 = recip_fast(fmax(d1, 1e-300));
+                const double q0 = w * r0, q1 = w * r1, rin = r1 * sw;
+                double p[NB];
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    acc0[I] = fma(x[I], q0, acc0[I]);
+                    acc1[I] = fma(x[I], q1, acc1[I]);
+                    p[I] = x[I] * rin;
+                }
+                int b = 0;
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+#pragma unroll
+                    for (int J = I; J < NB; ++J, ++b) Gm[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[I], p[J], Gm[b], 0, 0, 0);
+            }
+            // (every LDS read of this buffer has been consumed by the arithmetic above: it takes tile j + DEPTH)
+            if (j + DEPTH < ntw) stage(gw + (j + DEPTH) * W, cbuf);
+            cur = cur + 1 == DEPTH ? 0 : cur + 1;
+        }
+        // ---- fold the four waves' records through LDS: one record per workgroup
+        __syncthreads();  // (all tile buffers are dead)
+        SMALL_TICK(1);
+        double* frec = reinterpret_cast<double*>(smem) + (size_t)wave * E;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v0 = acc0[I], v1 = acc1[I];
+            v0 += __shfl_xor(v0, 16);
+            v0 += __shfl_xor(v0, 32);
+            v1 += __shfl_xor(v1, 16);
+            v1 += __shfl_xor(v1, 32);
+            if (lane < 16) {
+                frec[16 * I + lane] = v0;
+                frec[ROWS + 16 * I + lane] = v1;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) frec[REC_L + (b * 4 + r) * 64 + lane] = Gm[b][r];
+        __syncthreads();
+        {
+            const double* f0 = reinterpret_cast<const double*>(smem);
+            double* out = a.rec + ((size_t)par * G + blockIdx.x) * E;
+            for (int e = tid; e < E; e += 256) store_agent(out + e, (f0[e] + f0[E + e]) + (f0[2 * E + e] + f0[3 * E + e]));
+        }
+        nbar += 1;
+        ok = grid_barrier(a.bar, nbar * (unsigned)G);
+        SMALL_TICK(2);
+        if (!ok) break;
+        // ---- reduction over the workgroups, fixed order: sixteen threads per entry, each with its records' loads all in flight
+        {
+            const double* rb = a.rec + (size_t)par * G * E;
+            double* red = a.red + (size_t)par * E;
+            for (int64_t e16 = (int64_t)blockIdx.x * 256 + tid; e16 < (int64_t)16 * E; e16 += (int64_t)G * 256) {
+                const int e = (int)(e16 >> 4), part = (int)(e16 & 15);
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = part + 16 * i;
+                    v[i] = r < G ? rb[(size_t)r * E + e] : 0.0;
+                }
+                double sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                sum += ((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]));
+                sum += __shfl_xor(sum, 1);
+                sum += __shfl_xor(sum, 2);
+                sum += __shfl_xor(sum, 4);
+                sum += __shfl_xor(sum, 8);
+                if (part == 0) store_agent(red + e, sum);
+            }
+        }
+        nbar += 1;
+        ok = grid_barrier(a.bar, nbar * (unsigned)G);
+        SMALL_TICK(3);
+        if (!ok) break;
+        ql.lse_red = a.red + (size_t)par * E;
+        ql.gram_red = a.red + (size_t)par * E + REC_L;
+        select_body(ql);
+        __syncthreads();
+        SMALL_TICK(4);
+        par ^= 1;
+#ifdef MBAR_EXPERIMENT_SMALL_TIMING
+        ++nit;
+#endif
+    }
+#ifdef MBAR_EXPERIMENT_SMALL_TIMING
+    if (blockIdx.x == 0 && tid == 0 && nit > 0)
+        printf("DBG small: %d iterations; per iteration (x10 ns): newton %lld, sweep %lld, fold+barrier1 %lld, reduce+barrier2 %lld, select %lld, top %lld\n",
+               nit, tph[0] / nit, tph[1] / nit, tph[2] / nit, tph[3] / nit, tph[4] / nit, tph[5] / nit);
+#endif
+    // ---- the state back to device memory (workgroup 0; the others hold the same bits)
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int k = tid; k < ROWS; k += 256) {
+            qg.f[k] = s_f[k];
+            qg.psum[k] = s_psum[k];
+            qg.cand[k] = s_cand[k];
+            qg.cand[ROWS + k] = s_cand[ROWS + k];
+            qg.ratio[k] = s_ratio[k];
+            qg.aden[k] = s_aden[k];
+            qg.aden[ROWS + k] = s_aden[ROWS + k];
+            qg.anum[k] = s_anum[k];
+            qg.ccur[k] = s_ccur[k];
+            qg.cgram[k] = s_cgram[k];
+        }
+        if (tid < CTL_WORDS) qg.ctl[tid] = s_ctl[tid];
+        if (tid == 0) qg.state[0] = s_state[0];
+    }
 }
 
 // Fused loop, resumed after a pause (CTL_DONE = 3): the host enqueues this in front of the accepted candidate's Gram sweep.
@@ -4448,6 +4718,39 @@ hipError_t launch_newton_chol(hipStream_t s, const AdaptArgs& a, double* work) {
     }
     hipLaunchKernelGGL(k_chol_finish, dim3(1), dim3(256), 0, s, a, (const double*)Aw);
     return hipGetLastError();
+}
+
+size_t solve_small_record_doubles(int nb) { return (size_t)2 * nb * 16 + (size_t)nb * (nb + 1) / 2 * 256; }
+int solve_small_grid(int num_cu, int64_t ntiles, int64_t grid_override) {
+    int64_t g = (ntiles + 3) / 4;  // at least one tile per wave
+    if (g > num_cu) g = num_cu;    // one workgroup per compute unit: the grid barriers need every workgroup resident
+    if (g > 256) g = 256;          // (the in-kernel reduction sums at most 16 x 16 records per entry)
+    if (grid_override > 0 && grid_override < g) g = grid_override;
+    return (int)(g < 1 ? 1 : g);
+}
+template <int NB>
+static hipError_t launch_solve_small_nb(hipStream_t s, int grid, const SmallArgs& a) {
+    const size_t tile = (size_t)NB * 16 * TS * 8 + 2 * TS * 8;
+    size_t lds = (size_t)4 * small_ring_depth(NB) * tile;
+    const size_t fold = (size_t)4 * solve_small_record_doubles(NB) * sizeof(double);
+    if (fold > lds) lds = fold;
+    auto kern = k_solve_small<NB>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_solve_small(hipStream_t s, int nb, int grid, const SmallArgs& a) {
+    switch (nb) {
+        case 1: return launch_solve_small_nb<1>(s, grid, a);
+        case 2: return launch_solve_small_nb<2>(s, grid, a);
+        case 3: return launch_solve_small_nb<3>(s, grid, a);
+        case 4: return launch_solve_small_nb<4>(s, grid, a);
+        case 5: return launch_solve_small_nb<5>(s, grid, a);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_ctl_resume(hipStream_t s, int* ctl) {

@@ -311,8 +311,10 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
     u_kn, N_k, f = random_problem(K, N, seed=K + 1, unsampled=unsampled)
     tol = 1e-12 if K <= 128 else 1e-10  # (~50 samples per state above 128 states: 1e-12 is the round-off floor of f there)
     sws = np.where(N_k > 0)[0]
+    # ("fused persistent": up to 80 states the whole loop in ONE launch of a persistent grid -- optional, slower than the launches)
     modes = {"host": dict(device_loop=0), "classic": dict(device_loop=1, pmode=0, fused=0),
              "pmode": dict(device_loop=1, pmode=1, fused=0), "fused": dict(device_loop=1, pmode=1, fused=1),
+             "fused persistent": dict(device_loop=1, pmode=1, fused=1, persistent=1),
              "fused eager": dict(device_loop=1, pmode=1, fused=1, graph=0)}
     rng = np.random.default_rng(K)
     # a bootstrap replicate: draw counts of a resampling WITHIN each state (sum_n c_n over a state's samples = N_k, or the
@@ -330,7 +332,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                      dict(min_sc_iter=0, fixed=30)):  # (30: batches of 6, 2, 4, 8, 8, 2 -- the full ones replay the captured hipGraph)
             out = {}
             for name, opts in modes.items():
-                for k, v in {"graph": 1, **opts}.items():
+                for k, v in {"graph": 1, "persistent": 0, **opts}.items():
                     dm.set_option(k, v)
                 dm.set_sample_weights(c_n if case.get("weights") else None)
                 try:
@@ -358,7 +360,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                 f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=tol, min_sc_iter=case["min_sc_iter"])
                 if case.get("gamma", 1.0) == 1.0:
                     np.testing.assert_allclose(out["fused"][0][sws], (f_or - f_or[sws[0]])[sws], rtol=1e-9, atol=1e-10)
-        for k, v in dict(device_loop=1, pmode=1, fused=1, graph=1).items():
+        for k, v in dict(device_loop=1, pmode=1, fused=1, graph=1, persistent=0).items():
             dm.set_option(k, v)
 
 
