@@ -267,7 +267,7 @@ struct mbar_ctx {
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_persistent = 0;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_persistent = 0, opt_merge_select = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -1520,6 +1520,10 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // One iteration.  Fused loop: {k_newton, fused sweep, ONE reduction of its per-state sums and Gram records, ONE all-reduce
     // of both, k_select} -- the Gram matrix the next k_newton needs comes out of the same sweep as the gradients.  Two-sweep
     // loops: the Gram sweep first.
+    // (fused loop: the Newton solve of an iteration rides in the launch of the previous iteration's selection -- k_select_newton --
+    // so the loop proper is four launches per iteration; a solve of its own is needed at the start and after a pause)
+    const bool merged = fused && !wide && c->opt_merge_select;
+    bool need_newton = true;
     auto enqueue_iteration = [&](bool timed) -> int {
         if (!fused) {
             int r2 = enqueue_gram(timed);
@@ -1527,8 +1531,9 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         }
         if (wide)
             HIPCHK(c, launch_newton_chol(c->stream, q, c->chol));
-        else
+        else if (!merged || need_newton)
             HIPCHK(c, launch_newton(c->stream, q));
+        need_newton = false;
         double* psum_part = c->part;
         double* obj_part = c->part + (size_t)gl.nwaves * rec_l;
         {
@@ -1564,7 +1569,10 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             int r2 = allreduce_dev(c, c->red, ar_count, 0);
             if (r2) return r2;
         }
-        HIPCHK(c, launch_select(c->stream, q));
+        if (merged)
+            HIPCHK(c, launch_select_newton(c->stream, q));
+        else
+            HIPCHK(c, launch_select(c->stream, q));
         return MBAR_OK;
     };
 
@@ -1578,8 +1586,12 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const bool use_graph = c->opt_graph && !stream_transport(c);
     auto prepare_graph = [&]() -> int {
         const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 12) ^ (pmode ? 128 : 0) ^ (fused ? 256 : 0) ^
-                            (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (lc_slot.unclamped ? 512 : 0) ^ (int64_t)nb;
+                            (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (lc_slot.unclamped ? 512 : 0) ^ (merged ? 1024 : 0) ^ (int64_t)nb;
         if (!c->ad_graph || c->ad_graph_batch != batch || c->ad_graph_sig != sig) {
+            // (the captured iterations are the steady-state ones: no Newton solve of their own when it rides with the selection)
+            const bool need_saved = need_newton;
+            need_newton = false;
+            struct Restore { bool& r; bool v; ~Restore() { r = v; } } restore{need_newton, need_saved};
             if (c->ad_graph) HIPCHK(c, hipGraphExecDestroy(c->ad_graph));
             c->ad_graph = nullptr;
             // eager warm-up with the stop flag raised: every kernel is launched once outside the capture (function
@@ -1643,6 +1655,10 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         } else if (use_graph && nbat == batch) {
             rc = prepare_graph();
             if (rc) return rc;
+            if (merged && need_newton) {  // (start of the solve / after a pause: the replayed iterations have no solve of their own)
+                HIPCHK(c, launch_newton(c->stream, q));
+                need_newton = false;
+            }
             HIPCHK(c, hipGraphLaunch(c->ad_graph, c->stream));
         } else {
             for (int64_t b = 0; b < nbat; ++b) {
@@ -1676,6 +1692,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
                 if (rc) return rc;
                 ++gram_sweeps;
                 ramp = 1;
+                need_newton = true;  // (the solve that rode with the selection returned on the pause flag)
             }
         } else if (it_new != it + nbat) {
             return fail(c, MBAR_ERR_STATE, "device-resident adaptive loop lost count of its iterations");
@@ -1909,6 +1926,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "device_loop_wide") c->opt_device_loop_wide = value;
     else if (k == "pcache") c->opt_pcache = value;
     else if (k == "persistent") c->opt_persistent = value;
+    else if (k == "merge_select") c->opt_merge_select = value;
     else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;

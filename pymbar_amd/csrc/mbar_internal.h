@@ -242,6 +242,8 @@ constexpr size_t NEWTON_CHOL_WORK = (size_t)256 * 256 + 8;
 hipError_t launch_newton_chol(hipStream_t s, const AdaptArgs& a, double* work);
 // gradient norms of both candidates, choice (mbar_solvers.py:607), convergence test (:627-640), next Gram operand
 hipError_t launch_select(hipStream_t s, const AdaptArgs& a);
+// selection of one iteration + Newton solve of the next in one launch (fused loop, up to 127 unknowns)
+hipError_t launch_select_newton(hipStream_t s, const AdaptArgs& a);
 // fused loop paused by k_select (CTL_DONE = 3): clear the pause and the Gram request (in front of the Gram sweep)
 hipError_t launch_ctl_resume(hipStream_t s, int* ctl);
 

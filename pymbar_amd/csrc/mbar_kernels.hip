@@ -3749,6 +3749,16 @@ __global__ void __launch_bounds__(256)
 k_select(AdaptArgs q) {
     select_body(q);
 }
+// Fused loop: the selection of iteration i and the Newton solve of iteration i + 1 in ONE launch (a kernel boundary costs ~5 us;
+// at the sizes pymbar is mostly used at that is a tenth of an iteration).  A stop or pause flag raised by the selection makes the
+// solve return at once.
+template <int R>
+__global__ void __launch_bounds__(256)
+k_select_newton(AdaptArgs q) {
+    select_body(q);
+    __syncthreads();
+    newton_body<16, R>(q);
+}
 
 __global__ void __launch_bounds__(256)
 k_loop_reduce(LoopSrc src, int64_t count, int op, double* __restrict__ out) {
@@ -4755,6 +4765,16 @@ hipError_t launch_solve_small(hipStream_t s, int nb, int grid, const SmallArgs& 
 
 hipError_t launch_ctl_resume(hipStream_t s, int* ctl) {
     hipLaunchKernelGGL(k_ctl_resume, dim3(1), dim3(64), 0, s, ctl);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_newton(hipStream_t s, const AdaptArgs& a) {
+    const int M = a.m - 1;
+    if (M > 127 || a.Kp > 128) return hipErrorInvalidValue;
+    if (M <= 63)
+        hipLaunchKernelGGL((k_select_newton<4>), dim3(1), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_select_newton<8>), dim3(1), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -315,7 +315,9 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
     modes = {"host": dict(device_loop=0), "classic": dict(device_loop=1, pmode=0, fused=0),
              "pmode": dict(device_loop=1, pmode=1, fused=0), "fused": dict(device_loop=1, pmode=1, fused=1),
              "fused persistent": dict(device_loop=1, pmode=1, fused=1, persistent=1),
-             "fused eager": dict(device_loop=1, pmode=1, fused=1, graph=0)}
+             "fused eager": dict(device_loop=1, pmode=1, fused=1, graph=0),
+             "fused graphs of 2": dict(device_loop=1, pmode=1, fused=1, adapt_batch=2),   # (every batch a replay, also the first)
+             "fused, own Newton launch": dict(device_loop=1, pmode=1, fused=1, merge_select=0)}
     rng = np.random.default_rng(K)
     # a bootstrap replicate: draw counts of a resampling WITHIN each state (sum_n c_n over a state's samples = N_k, or the
     # weighted equations have no solution)
@@ -332,7 +334,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                      dict(min_sc_iter=0, fixed=30)):  # (30: batches of 6, 2, 4, 8, 8, 2 -- the full ones replay the captured hipGraph)
             out = {}
             for name, opts in modes.items():
-                for k, v in {"graph": 1, "persistent": 0, **opts}.items():
+                for k, v in {"graph": 1, "persistent": 0, "adapt_batch": 8, "merge_select": 1, **opts}.items():
                     dm.set_option(k, v)
                 dm.set_sample_weights(c_n if case.get("weights") else None)
                 try:
@@ -360,7 +362,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                 f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=tol, min_sc_iter=case["min_sc_iter"])
                 if case.get("gamma", 1.0) == 1.0:
                     np.testing.assert_allclose(out["fused"][0][sws], (f_or - f_or[sws[0]])[sws], rtol=1e-9, atol=1e-10)
-        for k, v in dict(device_loop=1, pmode=1, fused=1, graph=1, persistent=0).items():
+        for k, v in dict(device_loop=1, pmode=1, fused=1, graph=1, persistent=0, adapt_batch=8, merge_select=1).items():
             dm.set_option(k, v)
 
 
