@@ -583,9 +583,10 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
                                  ld1, dn, psum_part, obj_part));
         }
         {
+            // (per-state sums and objective terms in ONE pair of launches: at small sizes an evaluation is its launches -- the
+            // scipy-driven protocol stages call this thirty times per solve)
             ScopedTimer t(c, MBAR_TIMER_REDUCE);
-            HIPCHK(c, launch_reduce(c->stream, psum_part, g.nwaves, (int64_t)rec, c->scratch, c->red));
-            HIPCHK(c, launch_reduce(c->stream, obj_part, g.nwaves, nf, c->scratch, c->red + rec));
+            HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec, obj_part, nf, g.nwaves, c->scratch, c->red, c->red + rec));
         }
         return MBAR_OK;
     }

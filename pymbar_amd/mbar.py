@@ -101,13 +101,15 @@ class MBAR:
         # host copy is read again by initialize="BAR" in the bootstrap loop, by "mean-reduced-potential" and as the default
         # ``u_kn`` / ``A_n`` of the expectation family).  ``copy=False`` (extension; for matrices of many GB, where a second host
         # copy is 10 GB and seconds) REFERENCES a float64 C-contiguous input instead, through a read-only view.
-        if copy:
-            self.u_kn = np.array(u_kn, dtype=np.float64)
+        src = np.ascontiguousarray(u_kn, dtype=np.float64)   # (a conversion already yields a private array)
+        shared = src is u_kn or src.base is not None
+        if copy and shared:
+            self.u_kn = np.array(src, dtype=np.float64)
+        elif shared:
+            self.u_kn = src.view()
+            self.u_kn.setflags(write=False)
         else:
-            self.u_kn = np.ascontiguousarray(u_kn, dtype=np.float64)
-            if self.u_kn is u_kn or self.u_kn.base is not None:
-                self.u_kn = self.u_kn.view()
-                self.u_kn.setflags(write=False)
+            self.u_kn = src
         if self.u_kn.ndim != 2:
             raise ParameterError("u_kn must be a K x N (or K x L x N_max) array.")
         K, N = self.u_kn.shape

@@ -31,7 +31,7 @@ class OracleMatrix:
         u_kn = np.asarray(u_kn, dtype=np.float64)
         if columns is not None:
             u_kn = u_kn[:, columns[0] : columns[1]]
-        return cls(u_kn)
+        return cls(np.array(u_kn))  # (an upload is a copy: the device matrix must not follow the host array afterwards)
 
     def __enter__(self):
         return self
