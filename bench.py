@@ -9,8 +9,10 @@ Workload (BASELINE.json metric "MBAR solver iterations/sec + wallclock-to-conver
 synthetic harmonic ladder O_k = linspace(0,4,K), K_k = linspace(1,3,K), equal N_k, K = 128, fp64, generated directly
 in HBM from a counter RNG keyed by (seed, global sample index), so every sharding sees the same data.
 
-    --gpus 1, 2, 4 : config 3, N = 1e7 samples in TOTAL, column-sharded over the GPUs (strong scaling)
-    --gpus 8       : config 4, N = 1e8 samples in TOTAL = 1.25e7 per GPU
+    --gpus 1, 2, 4, 8 : config 3 -- the configuration the metric is quoted on -- N = 1e7 samples in TOTAL, column-sharded over the
+                        GPUs (strong scaling: `value` at N GPUs against N x `value` at one is the scaling efficiency)
+    --gpus 8          : ALSO measures config 4 (N = 1e8 in total = 1.25e7 per GPU) after the headline run and reports it as the
+                        `config4` object of the same JSON line (`--config4 0` skips it, `--config4 1` forces it at any count)
 
 A step is ONE adaptive iteration (pymbar/mbar_solvers.py:575-640): the K x K Newton solve from the Hessian at the current f,
 ONE fused sweep over the resident probability matrix that evaluates the gradients of both candidates (f_sci, f_nr) AND
@@ -237,6 +239,9 @@ def main():
                     help="1 = ONE sweep per iteration in P mode: the candidate sweep also accumulates the Gram matrix of the "
                          "Newton-Raphson candidate (the separate Gram sweep runs only when that candidate is rejected); 0 = two sweeps (A/B)")
     ap.add_argument("--allow-host-allreduce", action="store_true", help="debugging only: do not fail when RCCL is unavailable")
+    ap.add_argument("--config4", type=int, default=-1,
+                    help="also measure config 4 (K=128, N=1e8 in total, sharded) after the headline run: -1 = only with 8 or more "
+                         "GPUs (default), 0 = never, 1 = always (needs 205 GB on a single GPU)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -255,7 +260,7 @@ def main():
     group = HostGroup.from_env() if world > 1 else None
 
     K = args.K
-    N_total = args.n_total if args.n_total > 0 else (100_000_000 if world >= 8 else 10_000_000)
+    N_total = args.n_total if args.n_total > 0 else 10_000_000  # the metric's workload at EVERY GPU count (strong scaling)
     config_name = "config4" if N_total == 100_000_000 else ("config3" if N_total == 10_000_000 else "custom")
     n0, n1 = shard_bounds(N_total, rank, world)
     n_loc = n1 - n0
@@ -336,6 +341,58 @@ def main():
     err_analytic = float(np.max(np.abs(f_conv - ts.harmonic_free_energies(K_k))))
 
     mfma_peak = dm.mfma_f64_peak() if rank == 0 else None
+
+    # ---- config 4 (K = 128, N = 1e8 in total, sharded): BASELINE.json's eight-GPU configuration, next to the headline run ----
+    config4 = None
+    if (args.config4 == 1 or (args.config4 < 0 and world >= 8)) and N_total != 100_000_000:
+        N4 = 100_000_000
+        a0, a1 = shard_bounds(N4, rank, world)
+        O4, K4, Nk4 = ts.config3_params(K=K, N=N4)
+        Nk4 = Nk4.copy()
+        Nk4[-1] += N4 - int(Nk4.sum())
+        d4 = DeviceMatrix.harmonic(O4, K4, Nk4, seed=args.seed, n_global0=a0, N_local=a1 - a0, device=dev)
+        for key, val in (("staging", args.staging), ("device_loop", args.device_loop), ("pmode", args.pmode), ("fused", args.fused),
+                         ("pcache", 0), ("timing", 1), ("graph", 0)):
+            d4.set_option(key, val)
+        d4.set_Nk(Nk4)
+        kind4 = attach_allreduce(d4, group) if world > 1 else "none"
+        if kind4 in ("none", "rccl") or args.allow_host_allreduce:
+            steps4 = max(3, min(args.steps, 8))
+            d4.solve_adaptive(f0, tol=1e-12, maxiter=1, min_sc_iter=0, check_convergence=False)
+            d4.timing_reset()
+            if group is not None:
+                group.barrier()
+            d4.device_synchronize()
+            t0 = time.perf_counter()
+            _, r4 = d4.solve_adaptive(f0, tol=1e-12, maxiter=steps4, min_sc_iter=0, check_convergence=False)
+            if group is not None:
+                group.barrier()
+            d4.device_synchronize()
+            e4 = time.perf_counter() - t0
+            tm4 = d4.timing()
+            t1 = time.perf_counter()
+            f4, c4 = d4.solve_adaptive(f0, tol=1e-12, maxiter=10000, min_sc_iter=0, check_convergence=True)
+            d4.device_synchronize()
+            tc4 = time.perf_counter() - t1
+            if group is not None:
+                tt = np.array([e4, tc4])
+                group.allreduce(tt, "max")
+                e4, tc4 = float(tt[0]), float(tt[1])
+            fus4 = tm4.get("fused", (0.0, 0))
+            flop4 = float(a1 - a0) * K * (K + 1)
+            config4 = {
+                "workload": f"config4: harmonic ladder K={K}, N_total={N4} ({a1 - a0} per GPU), same adaptive iteration, {steps4} steps "
+                            "in one cold solver call",
+                "scaling_note": "ten times the samples of the headline workload: compare per GPU, not with `value`",
+                "iterations_per_s": steps4 / e4, "ms_per_step": 1e3 * e4 / steps4, "allreduce": kind4,
+                "fused_sweep_ms": fus4[0] / fus4[1] if fus4[1] else None,
+                "fused_sweep_frac_of_matrix_peak": (flop4 / (fus4[0] / fus4[1] * 1e-3) * 1e-12 / FP64_MFMA_PEAK_TFLOPS) if fus4[1] else None,
+                "iterations_to_converge": int(c4["iterations"]), "converged": bool(c4["success"]), "wallclock_to_converge_s": tc4,
+                "max_abs_error_vs_analytic_f": float(np.max(np.abs(f4 - ts.harmonic_free_energies(K4)))),
+            }
+        else:
+            config4 = {"skipped": f"RCCL unavailable for the second communicator (transport would be '{kind4}')"}
+        d4.close()
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
@@ -439,7 +496,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "strong" if N_total == 10_000_000 or world == 1 else "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -475,6 +532,7 @@ def main():
             "max_abs_error_vs_analytic_f": err_analytic,
             "gnorm_at_solution": float(conv["gnorm"]),
             "api_end_to_end": e2e,
+            "config4": config4,
         }
         out.update(extra)
         if cpu is not None:
