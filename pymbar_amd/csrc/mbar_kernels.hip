@@ -1551,7 +1551,9 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + one copy of the tile's 16 logden values per wave (a 1 KB LDS-DMA piece each)
     constexpr int NBLK = NBT * (NBT + 1) / 2, NMINE = quad_blocks_of(NBT, WV);
-    constexpr bool PINNED = NMINE > GRAM_AGPR_BLOCKS;
+    // (hand-placed asm matrix instructions also for the 192-state panel, whose 19 / 20 blocks per wave the compiler could manage:
+    // left to it, K = 192 ran at 0.565 of the matrix peak against 0.600 this way)
+    constexpr bool PINNED = true;
     const int ks = lane & 15, ns = lane >> 4;
     char* buf = smem + EXP_TABLE_BYTES;  // two tile buffers shared by the four waves
     const RowIdentity rows{0};
@@ -1623,7 +1625,6 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
     };
     int64_t t = blockIdx.x;
     int cur = 0;
-    // (the 78-block panel's waves hold 19 / 20 compiler-managed accumulators: there the early request measured slower)
     constexpr bool PREFETCH = PINNED;
     if (t < ntiles) {
         stage(t, buf);
