@@ -98,6 +98,8 @@ int mbar_device_synchronize(int device);
  *   "persistent"     1 = small problems (up to 80 states, up to ~1e6 samples, one rank): the whole device-resident loop runs in
  *                    ONE launch of a persistent grid with grid barriers between its phases (parity-tested; measured slower than
  *                    the five launches per iteration it replaces: 77 against 51 us at K=40, N=95000); 0 = default
+ *   "wide_pmode"     1 = 129 <= K <= 256 also keep a resident probability matrix and run ONE fused sweep per iteration
+ *                    (k_fused_quad; default); 0 = two sweeps on u there (one-read Gram + evaluation sweep)
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
  *   "timing"         HIP-event timers (mbar_ctx_timing): 0 = off (default: an event pair per sweep costs ~10 us, a fifth of an
  *                    iteration at the problem sizes pymbar is mostly used on), 1 = event records around a launch, 2 = events
@@ -210,7 +212,7 @@ typedef struct mbar_solve_result {
 /* Adaptive NR/SCI on the states with N_k > 0 (others are left untouched).  f_inout[K].
  * history (may be NULL): rows of 4 doubles {choice(0 sci,1 nr), |g_sci|, |g_nr|, max_delta}.
  * check_convergence = 0 runs exactly maxiter iterations (benchmarking).
- * Up to 256 states the whole iteration is device-resident (129 .. 256: classic two-sweep form, blocked Cholesky solve).
+ * Up to 256 states the whole iteration is device-resident (129 .. 256: blocked Cholesky solve in device memory).
  * Up to 128 states the whole iteration is device-resident (K x K Newton solve in one workgroup, candidate construction,
  * ONE fused sweep for both candidates' gradients and the next Hessian's Gram matrix, choice and convergence test; the host
  * reads a few control words per batch of iterations, replayed from a hipGraph on a single rank, with ONE ncclAllReduce on

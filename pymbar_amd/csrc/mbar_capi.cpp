@@ -267,7 +267,7 @@ struct mbar_ctx {
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_persistent = 0, opt_merge_select = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_persistent = 0, opt_merge_select = 1, opt_wide_pmode = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -1257,8 +1257,9 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // sequence of collectives than its peers.
     // P mode: the sweeps run on the resident probability matrix (one more K x N array); if it does not fit ON ANY RANK, or with
     // register staging, every rank runs the classic sweeps on u.
-    const bool wide = Kp > 128;  // 129 .. 256 states: one-read Gram kernel, classic sweeps (no resident probability matrix yet)
-    bool pmode = c->opt_pmode && dma && !c->P_failed && !wide;
+    const bool wide = Kp > 128;  // 129 .. 256 states: the one-read kernels whose four waves share a tile stream
+    // (129 .. 256 states: P mode exists in its fused form only)
+    bool pmode = c->opt_pmode && dma && !c->P_failed && (!wide || (c->opt_wide_pmode && c->opt_fused));
     int arc = ensure_ad(c, history ? history_rows : 0);
     if (!arc && wide && !c->chol && cache_malloc((void**)&c->chol, NEWTON_CHOL_WORK * sizeof(double)) != hipSuccess)
         arc = fail(c, MBAR_ERR_HIP, "allocation of the Newton workspace failed");
@@ -1383,6 +1384,47 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         if (rc) return rc;
         for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k] * cm0[k];  // (the sweep returns the sums without the multipliers)
         res.warm_starts += 1;
+    } else if (wide) {
+        // 129 .. 256 states: the probability matrix from three plain sweeps -- evaluation at the anchor (log-denominators into slot
+        // 1, per-state sums), P = exp(a0 - u - logden), and (fused loop) the Gram matrix at the anchor from P with unit reciprocals
+        c->P_valid = false;
+        rc = eval_core(c, f.data(), 1, 0, c->logden[1], nullptr, psum.data(), nullptr, nullptr);
+        if (rc) return rc;
+        if (fused && !c->weighted) {
+            // unweighted: the Gram sweep at the anchor forms exactly P as its operands -- it writes them out on the way (one sweep
+            // instead of make-P + Gram-from-P: 8 K N bytes read + 8 K N written once)
+            ScopedTimer t(c, MBAR_TIMER_OTHER);
+            HIPCHK(c, launch_gram_quad(c->stream, nb, gg, c->u, c->ld, c->N, d_aden(c), c->logden[1], c->part_g, LoopCtl(), c->P));
+            HIPCHK(c, launch_reduce(c->stream, c->part_g, gg.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
+            rc = allreduce_dev(c, c->red + off_gram, (int64_t)rec_g, 0);
+            if (rc) return rc;
+            HIPCHK(c, launch_fill(c->stream, c->logden[0], 1.0, c->ld));
+        } else {
+            ScopedTimer t(c, MBAR_TIMER_OTHER);
+            HIPCHK(c, launch_make_p(c->stream, c->num_cu, c->u, c->ld, c->N, Kp, d_aden(c), c->logden[1], c->P));
+            HIPCHK(c, launch_fill(c->stream, c->logden[0], 1.0, c->ld));
+        }
+        if (fused && c->weighted) {
+            const double* lden = c->logden[0];
+            if (c->weighted) {
+                HIPCHK(c, launch_rinv_weighted(c->stream, c->logden[0], c->cw, c->N, c->lden_eff));
+                lden = c->lden_eff;
+            }
+            LoopCtl lp;
+            lp.pmode = true;
+            {
+                ScopedTimer t(c, MBAR_TIMER_GRAM);
+                HIPCHK(c, launch_gram_quad(c->stream, nb, gg, c->P, c->ld, c->N, d_anum(c), lden, c->part_g, lp));
+            }
+            HIPCHK(c, launch_reduce(c->stream, c->part_g, gg.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
+            rc = allreduce_dev(c, c->red + off_gram, (int64_t)rec_g, 0);
+            if (rc) return rc;
+        }
+        rc = sync_stream(c);
+        if (rc) return rc;
+        c->P_a0 = an0;
+        c->P_valid = true;
+        res.builds += 1;
     } else {
         c->P_valid = false;
         build_aden(c, f.data(), c->hstage, Kp);
@@ -1504,7 +1546,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             if (ext) { lca.ev_start = tp.a; lca.ev_stop = tp.b; }
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
             if (wide)
-                HIPCHK(c, launch_gram_quad(c->stream, nb, gg, c->u, c->ld, c->N, d_anum(c), lden, gram_part, lca));
+                HIPCHK(c, launch_gram_quad(c->stream, nb, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, gram_part, lca));
             else
                 HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, gram_part,
                                            nullptr, lca));
@@ -1928,6 +1970,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "pcache") c->opt_pcache = value;
     else if (k == "persistent") c->opt_persistent = value;
     else if (k == "merge_select") c->opt_merge_select = value;
+    else if (k == "wide_pmode") c->opt_wide_pmode = value;
     else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;

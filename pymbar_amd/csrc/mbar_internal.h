@@ -103,8 +103,10 @@ hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, bool dma, const La
 // the nbt (nbt + 1) / 2 upper-triangular blocks; gram_part: [blocks][nblk][256], block b = (I, J), I <= J, row-major.
 // LDS-DMA staging only.  lc.pmode: `u` is the resident probability matrix, `logden` the reciprocals 1 / s_n.
 LaunchGeom gram_quad_geometry(int nbt, int num_cu, int64_t ntiles, int64_t grid_override);
+// Pout (classic operands only): the operand tiles exp(anum - u - logden) are also written out there (the probability matrix)
 hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
-                            const double* anum, const double* logden, double* gram_part, const LoopCtl& lc = LoopCtl());
+                            const double* anum, const double* logden, double* gram_part, const LoopCtl& lc = LoopCtl(),
+                            double* Pout = nullptr);
 
 // ---- layout-agnostic fallbacks (any K) ---------------------------------------------------------
 // 257 .. 512 states in one read: nf = 2 evaluates a second candidate through the ratio row aden[rows + k] = exp(a'_k - a_k)
@@ -232,6 +234,10 @@ LaunchGeom build_gram_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_
 hipError_t launch_build_gram(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                              const double* aden, const double* cw, const double* wsq, double* P, double* rinv_slot,
                              double* psum_part, double* gram_part);
+// 129 .. 256 states: P = exp(aden_k - u_kn - logden_n) (rows = padded state count; padding and sub-normal entries: 0)
+hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
+                         const double* logden, double* P);
+hipError_t launch_fill(hipStream_t s, double* v, double value, int64_t n);
 hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,
                                 const LoopCtl& lc = LoopCtl());
 // K x K Newton system (gauge-fixed, Gauss-Jordan in registers, one workgroup) + both candidates + sweep inputs

@@ -1543,10 +1543,14 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // single-panel kernel, so the reduction, the K x K solve and the host-side unpacking are the ones of K <= 128).
 // ---------------------------------------------------------------------------------------------
 constexpr int quad_blocks_of(int nbt, int w) { return (nbt * (nbt + 1) / 2 - w + 3) / 4; }
-template <int NBT, int WV, bool WIDE, bool PMODE>
+// STOREP (classic operands only): the operand tile IS the normalised probability matrix exp(a - u - logden) when `logden` are the
+// log-denominators at `a` -- each wave also writes its quarter of it out (coalesced 16-byte stores that mirror the LDS-DMA
+// pattern, behind the blocks of group 1): the build of the resident probability matrix for 129 .. 256 states rides on the Gram
+// sweep at the anchor.
+template <int NBT, int WV, bool WIDE, bool PMODE, bool STOREP = false>
 __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                                                const double* __restrict__ anum, const double* __restrict__ logden,
-                                               double* __restrict__ gram_part, char* smem, int lane) {
+                                               double* __restrict__ gram_part, char* smem, int lane, double* __restrict__ Pout = nullptr) {
     constexpr int ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + one copy of the tile's 16 logden values per wave (a 1 KB LDS-DMA piece each)
@@ -1657,6 +1661,10 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
                 }
             }
             if constexpr (!PMODE) exp2s_batch<GROUPS * NQ>(x);
+            if constexpr (STOREP) {  // (what is kept as P: entries below the normal range are flushed to zero)
+#pragma unroll
+                for (int e = 0; e < GROUPS * NQ; ++e) x[e] = x[e] >= 2.3e-308 ? x[e] : 0.0;
+            }
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g)
 #pragma unroll
@@ -1694,6 +1702,13 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
                                 stage_l(tnext, nbuf);
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                         }
+                        if (STOREP && g == 1 && mine >= 1 && mine <= QDMA) {  // this wave's quarter of the operand tile out as P
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                            const int j = WV * QDMA + mine - 1;
+                            const double2 pv = *reinterpret_cast<const double2*>(cbuf + j * 1024 + lane * 16);
+                            *reinterpret_cast<double2*>(reinterpret_cast<char*>(Pout + rows(8 * j) * ld + t * TS) + so.off[j & 1]) = pv;
+                            if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
+                        }
                         if (PREFETCH && g == GROUPS - 1 && mine == 1) {  // the next tile was requested three groups ago: its rows into registers
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                             wait_vm<0>();
@@ -1725,11 +1740,11 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
     }
 }
 
-template <int NBT, bool WIDE, bool PMODE>
+template <int NBT, bool WIDE, bool PMODE, bool STOREP = false>
 __global__ void __launch_bounds__(256, 1)
 k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ anum,
             const double* __restrict__ logden, double* __restrict__ gram_part, const int* __restrict__ ctl,
-            int64_t slot_stride, int cond_needgram) {
+            int64_t slot_stride, int cond_needgram, double* __restrict__ Pout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (ctl) {  // device-resident solver loop: stop flag + the logden / reciprocal slot of the current f
         if (ctl[CTL_DONE] != 0) return;
@@ -1743,11 +1758,251 @@ k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         __syncthreads();
     }
     switch (wave) {
-        case 0: gram_quad_body<NBT, 0, WIDE, PMODE>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane); break;
-        case 1: gram_quad_body<NBT, 1, WIDE, PMODE>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane); break;
-        case 2: gram_quad_body<NBT, 2, WIDE, PMODE>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane); break;
-        default: gram_quad_body<NBT, 3, WIDE, PMODE>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane); break;
+        case 0: gram_quad_body<NBT, 0, WIDE, PMODE, STOREP>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
+        case 1: gram_quad_body<NBT, 1, WIDE, PMODE, STOREP>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
+        case 2: gram_quad_body<NBT, 2, WIDE, PMODE, STOREP>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
+        default: gram_quad_body<NBT, 3, WIDE, PMODE, STOREP>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused sweep for 129 .. 256 states (P mode): k_gram_quad's tile stream -- four waves, one shared tile, each wave its quarter of
+// the rows and every fourth block -- carrying what k_fused carries for one panel: the normalisers 1 / s_n of both candidates
+// (each wave's partial dot products over ITS rows meet in a 1 KB LDS table: one more barrier per tile), the per-state sums of
+// both (each wave for its rows: the four waves' records are disjoint, nothing to fold), the reciprocals into the slot vectors
+// (wave w stores group w), and the Gram matrix of the second multiplier row on the matrix cores.
+//   [own rows in registers (requested behind the last blocks of the previous tile)] [partial normalisers -> LDS] [barrier]
+//   [normalisers, reciprocals, per-state sums; operands P / s written in place] [barrier] [own blocks; next tile's LDS-DMA
+//   behind the first of them]
+// ---------------------------------------------------------------------------------------------
+template <int NBT, int WV, bool WIDE>
+__device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles,
+                                                const double* __restrict__ cmul, const double* __restrict__ cw,
+                                                const double* __restrict__ wsq, double* __restrict__ rinv0,
+                                                double* __restrict__ rinv1, double* __restrict__ gram_part,
+                                                double* __restrict__ psum_part, char* smem, int lane) {
+    constexpr int ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + per wave: the tile's 16 multiplicities and their 16 roots (a 1 KB LDS-DMA piece)
+    constexpr int NBLK = NBT * (NBT + 1) / 2, NMINE = quad_blocks_of(NBT, WV);
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem;  // two tile buffers shared by the four waves; behind them the table of partial normalisers
+    double* xs = reinterpret_cast<double*>(smem + 2 * TILE_BYTES);  // [wave][candidate][16 samples]
+    const RowIdentity rows{0};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+    const int64_t G = gridDim.x;
+
+    double c0[NQ], c1[NQ], acc0[NQ], acc1[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        c0[i] = cmul[16 * (WV * NQ + i) + ks];
+        c1[i] = cmul[ROWS + 16 * (WV * NQ + i) + ks];
+        acc0[i] = acc1[i] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        settle(c0[i]);
+        settle(c1[i]);
+    }
+    v4d acc[NMINE];
+#pragma unroll
+    for (int b = 0; b < NMINE; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    auto stage_piece_j = [&](int64_t tile, char* dst, int j) {
+        stage_piece<true>(P + rows(8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
+    };
+    // multiplicities and their roots behind the tile, one full-wave piece per wave: even 128-byte rows of it take cw, odd rows wsq
+    const char* wsrc = reinterpret_cast<const char*>(((lane >> 3) & 1) ? wsq : cw) + (lane & 7) * 16;
+    auto stage_w = [&](int64_t tile, char* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + tile * (TS * 8)),
+                                         (__attribute__((address_space(3))) void*)(dst + U_BYTES + WV * 1024), 16, 0, 0);
+    };
+    auto stage = [&](int64_t tile, char* dst) {
+#pragma unroll
+        for (int j = WV * QDMA; j < (WV + 1) * QDMA; ++j) stage_piece_j(tile, dst, j);
+        stage_w(tile, dst);
+    };
+    auto read_group = [&](const char* tb, int g, double (&x)[NBT]) {
+#pragma unroll
+        for (int I = 0; I < NBT; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
+    };
+    auto mfma = [&](int b, double x, double y) {
+        if (b < GRAM_AGPR_BLOCKS)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(x), "v"(y));
+        else
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(x), "v"(y));
+    };
+    double x[GROUPS * NQ], w[GROUPS], sw[GROUPS];
+    auto read_own = [&](const char* tb) {
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            w[g] = *reinterpret_cast<const double*>(tb + U_BYTES + WV * 1024 + (4 * g + ns) * 8);
+            sw[g] = *reinterpret_cast<const double*>(tb + U_BYTES + WV * 1024 + TS * 8 + (4 * g + ns) * 8);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                x[g * NQ + i] = *reinterpret_cast<const double*>(tb + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]);
+        }
+    };
+    int64_t t = blockIdx.x;
+    int cur = 0;
+    if (t < ntiles) {
+        stage(t, buf);
+        wait_vm<0>();
+        read_own(buf);
+    }
+    for (; t < ntiles; t += G) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+        const int64_t tnext = t + G < ntiles ? t + G : t;  // (past the end this tile is requested again and never looked at)
+        // ---- this wave's share of the normalisers s_n = sum_k P_kn c_k of both candidates
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                d0 = fma(x[g * NQ + i], c0[i], d0);
+                d1 = fma(x[g * NQ + i], c1[i], d1);
+            }
+            row16_sum2(d0, d1);
+            if (ks < 2) xs[(WV * 2 + ks) * TS + 4 * g + ns] = ks == 0 ? d0 : d1;
+        }
+        __syncthreads();  // (the four partial sums of every sample are in the table; every wave is done with the other buffer)
+        // ---- reciprocals, per-state sums, operands in place
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const int sidx = 4 * g + ns;
+            const double s0 = (xs[(0 * 2 + 0) * TS + sidx] + xs[(1 * 2 + 0) * TS + sidx]) + (xs[(2 * 2 + 0) * TS + sidx] + xs[(3 * 2 + 0) * TS + sidx]);
+            const double s1 = (xs[(0 * 2 + 1) * TS + sidx] + xs[(1 * 2 + 1) * TS + sidx]) + (xs[(2 * 2 + 1) * TS + sidx] + xs[(3 * 2 + 1) * TS + sidx]);
+            // (a padded sample has an all-zero column: keep its reciprocal finite, its multiplicity and the root of it are 0)
+            const double r0 = recip_fast(fmax(s0, 1e-300)), r1 = recip_fast(fmax(s1, 1e-300));
+            const double q0 = w[g] * r0, q1 = w[g] * r1, rin = r1 * sw[g];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                acc0[i] = fma(x[g * NQ + i], q0, acc0[i]);
+                acc1[i] = fma(x[g * NQ + i], q1, acc1[i]);
+                *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i] * rin;
+            }
+            if (g == WV) {  // this wave stores the reciprocals of group WV (one store instruction per wave and tile)
+                const int64_t n = t * TS + sidx;
+                if (n < N && ks < 2) (ks == 0 ? rinv0 : rinv1)[n] = ks == 0 ? r0 : r1;
+            }
+        }
+        __syncthreads();  // every row of tile t holds operands
+        // ---- this wave's blocks (see k_gram_quad)
+        double p[2][NBT];
+        read_group(cbuf, 0, p[0]);
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7");
+            int b = 0, mine = 0;
+#pragma unroll
+            for (int I = 0; I < NBT; ++I)
+#pragma unroll
+                for (int J = I; J < NBT; ++J) {
+                    if ((b & 3) == WV) {
+                        mfma(mine, p[g & 1][I], p[g & 1][J]);
+                        if (mine == 0 && g < GROUPS - 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            read_group(cbuf, g + 1, p[(g + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (g == 0 && mine >= 1 && mine <= QDMA + 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (mine <= QDMA)
+                                stage_piece_j(tnext, nbuf, WV * QDMA + mine - 1);
+                            else
+                                stage_w(tnext, nbuf);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (g == GROUPS - 1 && mine == 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            wait_vm<0>();
+                            read_own(nbuf);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ++mine;
+                    }
+                    ++b;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // matrix result -> VALU read distance
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        double v0 = acc0[i], v1 = acc1[i];
+        v0 += __shfl_xor(v0, 16);
+        v0 += __shfl_xor(v0, 32);
+        v1 += __shfl_xor(v1, 16);
+        v1 += __shfl_xor(v1, 32);
+        if (lane < 16) {
+            psum_part[((int64_t)blockIdx.x * 2 + 0) * ROWS + 16 * (WV * NQ + i) + lane] = v0;
+            psum_part[((int64_t)blockIdx.x * 2 + 1) * ROWS + 16 * (WV * NQ + i) + lane] = v1;
+        }
+    }
+    {
+        int b = 0, mine = 0;
+#pragma unroll
+        for (int I = 0; I < NBT; ++I)
+#pragma unroll
+            for (int J = I; J < NBT; ++J) {
+                if ((b & 3) == WV) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gram_part[(((int64_t)blockIdx.x * NBLK + b) * 4 + r) * 64 + lane] = acc[mine][r];
+                    ++mine;
+                }
+                ++b;
+            }
+    }
+}
+
+template <int NBT, bool WIDE>
+__global__ void __launch_bounds__(256, 1)
+k_fused_quad(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cmul,
+             const double* __restrict__ cw, const double* __restrict__ wsq, double* __restrict__ rinv0,
+             double* __restrict__ gram_part, double* __restrict__ psum_part, const int* __restrict__ ctl, int64_t slot_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl[CTL_DONE] != 0) return;
+    const int s = ctl[CTL_SLOT];
+    double* rinv1 = rinv0 + (int64_t)((s + 2) % 3) * slot_stride;
+    rinv0 = rinv0 + (int64_t)((s + 1) % 3) * slot_stride;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {
+        case 0: fused_quad_body<NBT, 0, WIDE>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
+        case 1: fused_quad_body<NBT, 1, WIDE>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
+        case 2: fused_quad_body<NBT, 2, WIDE>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
+        default: fused_quad_body<NBT, 3, WIDE>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
+    }
+}
+
+// P = exp(aden_k - u_kn - logden_n) for the rows / samples of a shard (padding: 0; entries below the normal range are flushed to
+// zero): the resident probability matrix of 129 .. 256 states, built from the log-denominators an evaluation sweep left behind.
+__global__ void __launch_bounds__(256)
+k_make_p(const double* __restrict__ u, int64_t ld, int64_t N, int64_t rows, const double* __restrict__ aden,
+         const double* __restrict__ logden, double* __restrict__ P) {
+    const int64_t per_row = ld / 2;  // two samples per thread
+    const int64_t total = rows * per_row;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = e / per_row, n = (e - k * per_row) * 2;
+        const double a = aden[k];
+        const double2 uv = *reinterpret_cast<const double2*>(u + k * ld + n);
+        double2 pv;
+        pv.x = (n < N) ? exp(a - uv.x - logden[n]) : 0.0;
+        pv.y = (n + 1 < N) ? exp(a - uv.y - logden[n + 1]) : 0.0;
+        if (!(pv.x >= 2.3e-308)) pv.x = 0.0;  // (also a = -inf: unsampled / padded state)
+        if (!(pv.y >= 2.3e-308)) pv.y = 0.0;
+        *reinterpret_cast<double2*>(P + k * ld + n) = pv;
+    }
+}
+__global__ void __launch_bounds__(256) k_fill(double* __restrict__ v, double value, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = value;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3674,7 +3929,7 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q) {  // (256 threa
     const double m0 = (in && q.pmode) ? q.aden[o_sci + tid] : 1.0;
     const double m1 = in ? (q.pmode ? q.aden[o_nr + tid] : q.ratio[tid]) : 0.0;
     double raw0 = in ? q.lse_red[o_sci + tid] : 0.0, raw1 = in ? q.lse_red[o_nr + tid] : 0.0;
-    if (q.fused && Kp / 16 >= FUSED_PSUM1_FROM_GRAM_NB) {
+    if (q.fused && Kp == 128 && FUSED_PSUM1_FROM_GRAM_NB <= 8) {  // (k_fused<8> only: narrower panels and k_fused_quad accumulate both rows)
         // the fused sweep of a full panel left the unscaled sums of its SECOND multiplier row c to be taken from the Gram matrix
         // it accumulated for that candidate: sum_n w_n P_kn / s_n = sum_j c_j G'_kj (rows of p sum to one)
         __shared__ double s_c[128], s_half[128];
@@ -4412,9 +4667,9 @@ LaunchGeom gram_quad_geometry(int nbt, int num_cu, int64_t ntiles, int64_t grid_
     g.psum_records = g.nwaves;
     return g;
 }
-template <int NBT, bool PMODE>
+template <int NBT, bool PMODE, bool STOREP = false>
 static hipError_t launch_gram_quad_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
-                                     const double* anum, const double* logden, double* gp, const LoopCtl& lc) {
+                                     const double* anum, const double* logden, double* gp, const LoopCtl& lc, double* Pout = nullptr) {
     auto launch = [&](auto kern) -> hipError_t {
         if (g.lds_bytes > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -4424,16 +4679,22 @@ static hipError_t launch_gram_quad_t(hipStream_t s, const LaunchGeom& g, const d
         const int64_t ntiles = (N + TS - 1) / TS;
         if (lc.ev_start && lc.ev_stop)
             hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, u, ld, N, ntiles, anum,
-                                  logden, gp, lc.ctl, lc.slot_stride, lc.cond_needgram ? 1 : 0);
+                                  logden, gp, lc.ctl, lc.slot_stride, lc.cond_needgram ? 1 : 0, Pout);
         else
             hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, u, ld, N, ntiles, anum, logden, gp, lc.ctl,
-                               lc.slot_stride, lc.cond_needgram ? 1 : 0);
+                               lc.slot_stride, lc.cond_needgram ? 1 : 0, Pout);
         return hipGetLastError();
     };
-    return stage_offsets_wide(ld) ? launch(k_gram_quad<NBT, true, PMODE>) : launch(k_gram_quad<NBT, false, PMODE>);
+    return stage_offsets_wide(ld) ? launch(k_gram_quad<NBT, true, PMODE, STOREP>) : launch(k_gram_quad<NBT, false, PMODE, STOREP>);
 }
 hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
-                            const double* anum, const double* logden, double* gram_part, const LoopCtl& lc) {
+                            const double* anum, const double* logden, double* gram_part, const LoopCtl& lc, double* Pout) {
+    if (Pout) {  // classic operands, also written out as the probability matrix
+        if (lc.pmode) return hipErrorInvalidValue;
+        if (nbt == 12) return launch_gram_quad_t<12, false, true>(s, g, u, ld, N, anum, logden, gram_part, lc, Pout);
+        if (nbt == 16) return launch_gram_quad_t<16, false, true>(s, g, u, ld, N, anum, logden, gram_part, lc, Pout);
+        return hipErrorInvalidValue;
+    }
     if (nbt == 12)
         return lc.pmode ? launch_gram_quad_t<12, true>(s, g, u, ld, N, anum, logden, gram_part, lc)
                         : launch_gram_quad_t<12, false>(s, g, u, ld, N, anum, logden, gram_part, lc);
@@ -4881,6 +5142,16 @@ LaunchGeom fused_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_overr
     LaunchGeom g;
     g.waves = 4;
     g.variant = 1;
+    if (nb > 8) {  // 129 .. 256 states: one tile stream per workgroup, one partial record per workgroup (k_fused_quad)
+        g.variant = 6;
+        g.lds_bytes = (size_t)2 * ((size_t)nb * 16 * TS * 8 + 4 * 1024) + 1024;
+        int64_t capq = grid_override > 0 ? grid_override : num_cu;
+        int64_t wantq = ntiles < 1 ? 1 : ntiles;
+        g.blocks = (int)(wantq < capq ? wantq : capq);
+        g.nwaves = g.blocks;
+        g.psum_records = g.nwaves;
+        return g;
+    }
     const size_t tile = (size_t)nb * 16 * TS * 8 + 1024;    // + one LDS-DMA piece for the two weight vectors
     g.lds_bytes = (size_t)4 * 2 * tile + (size_t)nb * 512;  // + the candidates' multipliers as a 4x4x4 MFMA operand
     int64_t want = (ntiles + 3) / 4;
@@ -4924,10 +5195,42 @@ static hipError_t launch_fused_nb(hipStream_t s, const LaunchGeom& g, const doub
     };
     return stage_offsets_wide(ld) ? go(k_fused<NB, true>) : go(k_fused<NB, false>);
 }
+template <int NBT>
+static hipError_t launch_fused_quad_t(hipStream_t s, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, const double* cmul,
+                                      const double* cw, const double* wsq, double* rinv0, double* gp, double* pp, const LoopCtl& lc) {
+    auto go = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        if (lc.ev_start && lc.ev_stop)
+            hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, P, ld, N, ntiles, cmul,
+                                  cw, wsq, rinv0, gp, pp, lc.ctl, lc.slot_stride);
+        else
+            hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, P, ld, N, ntiles, cmul, cw, wsq, rinv0, gp, pp, lc.ctl,
+                               lc.slot_stride);
+        return hipGetLastError();
+    };
+    return stage_offsets_wide(ld) ? go(k_fused_quad<NBT, true>) : go(k_fused_quad<NBT, false>);
+}
+hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
+                         const double* logden, double* P) {
+    hipLaunchKernelGGL(k_make_p, dim3((unsigned)(num_cu * 8)), dim3(256), 0, s, u, ld, N, rows, aden, logden, P);
+    return hipGetLastError();
+}
+hipError_t launch_fill(hipStream_t s, double* v, double value, int64_t n) {
+    int64_t bx = (n + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, v, value, n);
+    return hipGetLastError();
+}
 hipError_t launch_fused(hipStream_t s, int nb, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, const double* cmul,
                         const double* cw, const double* wsq, double* rinv_base, double* gram_part, double* psum_part,
                         const LoopCtl& lc) {
     if (!lc.ctl) return hipErrorInvalidValue;  // (the slot vectors are addressed through the control words)
+    if (nb == 12) return launch_fused_quad_t<12>(s, g, P, ld, N, cmul, cw, wsq, rinv_base, gram_part, psum_part, lc);
+    if (nb == 16) return launch_fused_quad_t<16>(s, g, P, ld, N, cmul, cw, wsq, rinv_base, gram_part, psum_part, lc);
     switch (nb) {
 #define MBAR_CASE(NB_) \
     case NB_: return launch_fused_nb<NB_>(s, g, P, ld, N, cmul, cw, wsq, rinv_base, gram_part, psum_part, lc);

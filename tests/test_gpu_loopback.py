@@ -58,12 +58,12 @@ CASES = (dict(min_sc_iter=0), dict(min_sc_iter=2), dict(min_sc_iter=0, weights=T
          dict(min_sc_iter=3, gamma=0.7))
 
 
-def solve_cases(dm, K, c_n):
+def solve_cases(dm, K, c_n, tol=1e-12):
     out = []
     for case in CASES:
         dm.set_sample_weights(c_n if case.get("weights") else None)
         try:
-            fa, ra = dm.solve_adaptive(np.zeros(K), tol=1e-12, maxiter=case.get("fixed", 200), min_sc_iter=case["min_sc_iter"],
+            fa, ra = dm.solve_adaptive(np.zeros(K), tol=tol, maxiter=case.get("fixed", 200), min_sc_iter=case["min_sc_iter"],
                                        gamma=case.get("gamma", 1.0), check_convergence="fixed" not in case, history_rows=200)
         finally:
             dm.set_sample_weights(None)
@@ -71,16 +71,18 @@ def solve_cases(dm, K, c_n):
     return out
 
 
-@pytest.mark.parametrize("K,N,unsampled,nranks", [(40, 20000, (7, 23), 2), (128, 30011, (5,), 2), (64, 9000, (), 3), (5, 3000, (), 2)])
+@pytest.mark.parametrize("K,N,unsampled,nranks", [(40, 20000, (7, 23), 2), (128, 30011, (5,), 2), (64, 9000, (), 3), (5, 3000, (), 2),
+                                                  (200, 16000, (11,), 2)])
 def test_device_resident_loop_across_logical_ranks(K, N, unsampled, nranks):
     from pymbar_amd.device import DeviceMatrix, LoopbackGroup
 
     u_kn, N_k, f = random_problem(K, N, seed=K + 3, unsampled=unsampled)
     sws = np.where(N_k > 0)[0]
     c_n = bootstrap_counts(N_k, K)
+    tol = 1e-12 if K <= 128 else 1e-10  # (few samples per state above 128 states: 1e-12 is the round-off floor of f there)
     with DeviceMatrix.from_host(u_kn) as one:
         one.set_Nk(N_k)
-        ref = solve_cases(one, K, c_n)
+        ref = solve_cases(one, K, c_n, tol)
         ref_eval = one.eval(f, gram=True)
         ref_lognum = one.lognum(f)
         ref_gw = one.gram_w(f)
@@ -91,7 +93,7 @@ def test_device_resident_loop_across_logical_ranks(K, N, unsampled, nranks):
                 dm.set_loopback(grp, r)
                 assert dm.allreduce_kind == "loopback"
                 dm.set_Nk(N_k)
-                res = dict(solves=solve_cases(dm, K, c_n[n0:n1]), eval=dm.eval(f, gram=True), lognum=dm.lognum(f), gw=dm.gram_w(f),
+                res = dict(solves=solve_cases(dm, K, c_n[n0:n1], tol), eval=dm.eval(f, gram=True), lognum=dm.lognum(f), gw=dm.gram_w(f),
                            sci=dm.solve_sci(np.zeros(K), tol=1e-10, maxiter=3000))
                 dm.comm_destroy()
                 return res
@@ -119,8 +121,8 @@ def test_device_resident_loop_across_logical_ranks(K, N, unsampled, nranks):
         big = rr["history"][:, 1:3] > 1e-6
         np.testing.assert_allclose(ra["history"][:, 1:3][big], rr["history"][:, 1:3][big], rtol=1e-6, err_msg=str(case))
         assert ra["gram_sweeps"] == rr["gram_sweeps"]
-    f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=1e-12, min_sc_iter=0)
-    np.testing.assert_allclose(r0["solves"][0][0][sws], (f_or - f_or[sws[0]])[sws], rtol=1e-9, atol=1e-10)
+    f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=tol, min_sc_iter=0)
+    np.testing.assert_allclose(r0["solves"][0][0][sws], (f_or - f_or[sws[0]])[sws], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(r0["sci"][0][sws], r0["solves"][0][0][sws], atol=1e-7)
 
 
