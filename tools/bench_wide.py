@@ -5,7 +5,8 @@
           against the one-read kernel whose four waves share a tile stream (k_gram_quad), in ms and as a fraction of the fp64
           matrix peak on N K (K + 1) flop;
   loop    one adaptive iteration at K = 192 / 256: host-driven loop (panels / one-read Gram) against the device-resident loop
-          (one-read Gram, four-waves-per-CU evaluation sweep, blocked Cholesky Newton solve in device memory);
+          (blocked Cholesky Newton solve in device memory) in its two forms: two sweeps on u (one-read Gram + four-waves-per-CU
+          evaluation sweep), and ONE fused sweep on the resident probability matrix (k_fused_quad); cold and warm solves;
   split   evaluation sweep at 257 ... 512 states: one and two candidates, row-split kernel against the layout-agnostic path.
 
 Usage: python tools/bench_wide.py [gram] [loop] [split]   (default: all)"""
@@ -56,19 +57,26 @@ def loop():
             dm.set_Nk(N_k)
             for name, opts in (("host-driven loop, panel Gram", dict(device_loop=0, gram_quad=0)),
                                ("host-driven loop, one-read Gram", dict(device_loop=0, gram_quad=1)),
-                               ("device-resident loop", dict(device_loop=1, gram_quad=1))):
-                for k, v in opts.items():
+                               ("device-resident, two sweeps on u", dict(device_loop=1, gram_quad=1, wide_pmode=0)),
+                               ("device-resident, fused on P", dict(device_loop=1, gram_quad=1, wide_pmode=1))):
+                for k, v in {"pcache": 0, **opts}.items():
                     dm.set_option(k, v)
                 dm.solve_adaptive(np.zeros(K), maxiter=3, min_sc_iter=0, check_convergence=False)
                 dm.synchronize()
                 t0 = time.perf_counter()
-                dm.solve_adaptive(np.zeros(K), maxiter=12, min_sc_iter=0, check_convergence=False)
-                dt = (time.perf_counter() - t0) / 12
+                dm.solve_adaptive(np.zeros(K), maxiter=20, min_sc_iter=0, check_convergence=False)
+                dt = (time.perf_counter() - t0) / 20
                 t1 = time.perf_counter()
                 fc, rc = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
                 dtc = time.perf_counter() - t1
-                print(f"adaptive K={K} N={N} {name:32s}: {1e3 * dt:7.3f} ms per iteration; solve from f=0: {rc['iterations']} iterations "
-                      f"{1e3 * dtc:7.2f} ms, success={rc['success']}", flush=True)
+                dm.set_option("pcache", 1)
+                dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+                t2 = time.perf_counter()
+                fw, rw = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+                dtw = time.perf_counter() - t2
+                print(f"adaptive K={K} N={N} {name:34s}: {1e3 * dt:7.3f} ms per iteration (20 in one cold solver call); solve from f=0: "
+                      f"{rc['iterations']} iterations {1e3 * dtc:7.2f} ms cold, {1e3 * dtw:7.2f} ms warm ({rw['warm_starts']} warm start), "
+                      f"success={rc['success']}", flush=True)
 
 
 def split():
