@@ -223,6 +223,11 @@ typedef struct mbar_solve_result {
 int mbar_solve_adaptive(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxiter,
                         int64_t min_sc_iter, double gamma, int check_convergence,
                         double* history, int64_t history_rows, mbar_solve_result* result);
+/* psum[k] = sum_n p_nk at the f the last mbar_solve_adaptive on this context returned (its gradient is psum - N_k, the
+ * all-state self-consistent update of sampled states f - log(psum / N_k)): what mbar_solvers.py:939 and :1012 recompute
+ * with one more sweep each after a solve.  MBAR_ERR_STATE when there is none (no solve yet, or the matrix / N_k / the sample
+ * weights changed since). */
+int mbar_ctx_last_solve_psum(mbar_ctx* ctx, double* psum);
 /* Pure self-consistent iteration, device-resident (f update and convergence measure on the
  * device; the host looks every `check_every` iterations). */
 int mbar_solve_sci(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxiter, int check_convergence,

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mbar_gram_w": (C.c_int, [_ctx, _dp, _dp, _dp]),
     "mbar_solve_adaptive": (C.c_int, [_ctx, _dp, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_int,
                                       _dp, C.c_int64, C.POINTER(SolveResult)]),
+    "mbar_ctx_last_solve_psum": (C.c_int, [_ctx, _dp]),
     "mbar_solve_sci": (C.c_int, [_ctx, _dp, C.c_double, C.c_int64, C.c_int, C.POINTER(SolveResult)]),
     "mbar_ctx_timing": (C.c_int, [_ctx, C.c_int, _dp, _ip]),
     "mbar_ctx_timing_reset": (C.c_int, [_ctx]),

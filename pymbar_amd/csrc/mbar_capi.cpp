@@ -262,6 +262,7 @@ struct mbar_ctx {
     unsigned* sm_bar = nullptr;     // ... its grid-barrier counter and timeout flag
     // P outlives the solve that built it: a later solve on the same matrix whose start lies within the window of the anchor
     // (bootstrap replicates, protocol stages, continuation) starts with ONE fused sweep instead of the build sweep
+    std::vector<double> last_psum;  // per-state sums at the f the last adaptive solve returned (empty: none)
     bool P_valid = false;
     std::vector<double> P_a0;       // anchor of the resident probability matrix: aden at the build point (Kp entries)
     // options
@@ -1988,6 +1989,7 @@ int mbar_ctx_upload_u(mbar_ctx* c, const double* u_host, int64_t ld_host, int64_
                                hipMemcpyHostToDevice, c->stream));
     c->u_checked = false;
     c->P_valid = false;
+    c->last_psum.clear();
     return sync_stream(c);
 }
 
@@ -2001,6 +2003,7 @@ int mbar_ctx_upload_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const double*
                                hipMemcpyHostToDevice, c->stream));
     c->u_checked = false;
     c->P_valid = false;
+    c->last_psum.clear();
     return sync_stream(c);
 }
 
@@ -2021,6 +2024,7 @@ int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t s
                                      hipMemcpyDeviceToDevice, dst->stream));
     dst->u_checked = false;
     dst->P_valid = false;
+    dst->last_psum.clear();
     return sync_stream(dst);
 }
 
@@ -2036,6 +2040,7 @@ int mbar_ctx_row_sub(mbar_ctx* c, int64_t row, const double* v_host) {
     HIPCHK(c, launch_row_sub(c->stream, c->u + row * c->ld, tmp, c->N));
     c->u_checked = false;
     c->P_valid = false;
+    c->last_psum.clear();
     return sync_stream(c);
 }
 
@@ -2054,6 +2059,7 @@ int mbar_ctx_rows_sub(mbar_ctx* c, int64_t dst_row0, int64_t src_row0, int64_t n
     HIPCHK(c, launch_rows_sub(c->stream, c->u + dst_row0 * c->ld, c->u + src_row0 * c->ld, c->ld, nrows, c->vec_tmp, c->N));
     c->u_checked = false;
     c->P_valid = false;
+    c->last_psum.clear();
     return sync_stream(c);
 }
 
@@ -2067,6 +2073,7 @@ int mbar_ctx_rows_rsub(mbar_ctx* c, int64_t dst_row0, int64_t src_row0, int64_t 
     HIPCHK(c, launch_rows_rsub(c->stream, c->u + dst_row0 * c->ld, c->u + src_row0 * c->ld, c->ld, nrows, c->N));
     c->u_checked = false;
     c->P_valid = false;
+    c->last_psum.clear();
     return sync_stream(c);
 }
 
@@ -2086,6 +2093,7 @@ int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const do
     if (e != hipSuccess) return fail(c, MBAR_ERR_HIP, std::string("mbar_ctx_fill_masked_rows: ") + hipGetErrorString(e));
     c->u_checked = false;
     c->P_valid = false;
+    c->last_psum.clear();
     flush_timers(c);
     return MBAR_OK;
 }
@@ -2117,6 +2125,7 @@ int mbar_ctx_generate_harmonic(mbar_ctx* c, uint64_t seed, const double* O_k, co
     }
     c->u_checked = false;
     c->P_valid = false;
+    c->last_psum.clear();
     return sync_stream(c);
 }
 
@@ -2143,6 +2152,7 @@ int mbar_ctx_set_Nk(mbar_ctx* c, const double* N_k) {
     HIPCHK(c, hipMemcpyAsync(d_Nk(c), h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->P_valid = false;  // (the rows of P of states without samples are zero: the set may have changed)
+    c->last_psum.clear();
     c->have_Nk = true;
     return MBAR_OK;
 }
@@ -2174,6 +2184,7 @@ int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->weighted = weighted;
+    c->last_psum.clear();
     return MBAR_OK;
 }
 
@@ -2496,11 +2507,12 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     }
     const int m = (int)c->sampled.size();
     double gn = 0.0;
-    for (int i = 0; i < m; ++i) {
+    for (int i = 0; i < m && (int64_t)psum.size() == K; ++i) {
         const int k = c->sampled[i];
         gn += (psum[k] - c->Nk[k]) * (psum[k] - c->Nk[k]);
     }
     res.gnorm = std::sqrt(gn);
+    c->last_psum = (int64_t)psum.size() == K ? psum : std::vector<double>();
     res.max_delta = max_delta;
     res.wall_ms = now_ms() - t0;
     if (std::getenv("MBAR_DEBUG_TIMING") && res.iterations > 0)
@@ -2508,6 +2520,13 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
                      res.wall_ms / res.iterations, on_device ? "device-resident" : "host-driven");
     std::copy(f.begin(), f.end(), f_inout);
     if (result) *result = res;
+    return MBAR_OK;
+}
+
+int mbar_ctx_last_solve_psum(mbar_ctx* c, double* psum_out) {
+    if (!c || !psum_out) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if ((int64_t)c->last_psum.size() != c->K) return fail(c, MBAR_ERR_STATE, "no adaptive solve has left its per-state sums on this context");
+    std::copy(c->last_psum.begin(), c->last_psum.end(), psum_out);
     return MBAR_OK;
 }
 

@@ -286,6 +286,9 @@ class DeviceMatrix:
         out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_}
         out["success"] = bool(res.success)
         out["history"] = hist[: min(history_rows, res.iterations)]
+        # per-state sums at the returned f (the solver has them anyway): gradient norm and all-state update without another sweep
+        psum = np.empty(self.K, dtype=np.float64)
+        out["psum"] = psum if self._lib.mbar_ctx_last_solve_psum(self._ctx, _dptr(psum)) == _lib.MBAR_OK else None
         return f, out
 
     def solve_sci(self, f, tol=1e-12, maxiter=10000, check_convergence=True):

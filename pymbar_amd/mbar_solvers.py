@@ -321,6 +321,8 @@ def adaptive(u_kn, N_k, f_k, tol=1.0e-8, options=None):
                            f"iterations completed = {res['iterations']:d}")
     results = dict(success=res["success"], message=message, x=x, nr_iter=res["nr_iter"], sci_iter=res["sci_iter"],
                    iterations=res["iterations"], wall_ms=res["wall_ms"])
+    if res.get("psum") is not None and np.all(np.isfinite(res["psum"])):
+        results["psum"] = res["psum"]  # (extension: sum_n N_k W_nk at x, from the solver's last sweep)
     return results
 
 
@@ -456,7 +458,10 @@ def _solve_protocol_resident(h, N_k, f_k, sampled, solver_protocol):
         f_stage = f_cur - f_cur[sampled[0]]
         f_result, results = _solve_once_resident(h, N_k, f_stage, sampled, method, tol, options)
         all_fks.append(f_result)
-        all_gnorms.append(_gnorm(h, N_k, f_result, sampled))
+        # gradient norm at the stage's result (mbar_solvers.py:939): the adaptive loop hands its per-state sums back, any other
+        # method costs one evaluation sweep
+        ps = results.get("psum") if isinstance(results, dict) else None
+        all_gnorms.append(float(np.linalg.norm((ps - N_k)[sampled])) if ps is not None else _gnorm(h, N_k, f_result, sampled))
         all_results.append(results)
         if results["success"]:
             logger.info(f"Reached a solution to within tolerance with {method}")
@@ -477,7 +482,10 @@ def _solve_protocol_resident(h, N_k, f_k, sampled, solver_protocol):
                        f"{solver_protocol[i_best]['method']}")
         logger.warning("Please exercise caution with this solution and consider alternative methods or a different tolerance.")
     logger.info(f"Final gradient norm: {best_gnorm:.3g}")
-    return best, all_results
+    best_psum = None
+    if results["success"] and isinstance(all_results[-1], dict):
+        best_psum = all_results[-1].get("psum")
+    return best, all_results, best_psum
 
 
 def solve_mbar(u_kn_nonzero, N_k_nonzero, f_k_nonzero, solver_protocol=None):
@@ -486,7 +494,7 @@ def solve_mbar(u_kn_nonzero, N_k_nonzero, f_k_nonzero, solver_protocol=None):
     N_k_f = 1.0 * N_k_f
     with _Resident(u_kn_nonzero) as h:
         sampled = np.arange(h.shape[0])
-        return _solve_protocol_resident(h, N_k_f, f_k_nonzero - f_k_nonzero[0], sampled, solver_protocol)
+        return _solve_protocol_resident(h, N_k_f, f_k_nonzero - f_k_nonzero[0], sampled, solver_protocol)[:2]
 
 
 def solve_mbar_for_all_states(u_kn, N_k, f_k, states_with_samples, solver_protocol):
@@ -505,15 +513,21 @@ def solve_mbar_for_all_states(u_kn, N_k, f_k, states_with_samples, solver_protoc
         else:
             f_start = f_k.copy()
             f_start[states_with_samples] -= f_start[states_with_samples[0]]
-            f_solved, _ = _solve_protocol_resident(h, Nf, f_start, states_with_samples,
-                                                   copy.deepcopy(solver_protocol) if solver_protocol is not None else None)
+        psum_solved = None
+        if len(states_with_samples) != 1:
+            f_solved, _, psum_solved = _solve_protocol_resident(h, Nf, f_start, states_with_samples,
+                                                                copy.deepcopy(solver_protocol) if solver_protocol is not None else None)
             f_k[states_with_samples] = f_solved[states_with_samples]
         h.set_Nk(Nf)
         if np.all(Nf > 0):
-            # every state is sampled: the all-state update -lognum_k equals f_k - log(psum_k / N_k), i.e. one
-            # single-candidate sweep instead of the log-denominator sweep + the log-space reduction sweep
-            psum, _, _ = h.eval(f_k)
-            f_k = f_k - np.log(psum[0] / Nf)
+            # every state is sampled: the all-state update -lognum_k equals f_k - log(psum_k / N_k) -- with the per-state sums the
+            # adaptive loop hands back at its solution no sweep at all, otherwise one single-candidate sweep (instead of the
+            # log-denominator sweep + the log-space reduction sweep)
+            if psum_solved is not None and np.all(psum_solved > 0):
+                f_k = f_k - np.log(psum_solved / Nf)
+            else:
+                psum, _, _ = h.eval(f_k)
+                f_k = f_k - np.log(psum[0] / Nf)
         else:
             f_k = -1.0 * h.lognum(f_k)
     f_k -= f_k[0]

@@ -811,3 +811,32 @@ def test_resident_probability_matrix_is_reused_across_solves(DM):
         dm.set_Nk(N2)
         _, rn = dm.solve_adaptive(np.zeros(K), min_sc_iter=0, maxiter=4, check_convergence=False)
         assert rn["builds"] == 1 and rn["warm_starts"] == 0
+
+
+@pytest.mark.parametrize("K,N,unsampled", [(5, 3000, ()), (48, 20000, (9,)), (128, 30000, ()), (200, 16000, (11,)), (300, 12000, ())])
+def test_solve_hands_back_the_per_state_sums_at_its_result(DM, K, N, unsampled):
+    """mbar_ctx_last_solve_psum: the sums the adaptive loop ends with are those of the f it returns (every loop form: the fused
+    device-resident one, the split one above 128 states, the host-driven one above 256; cold, warm, weighted) -- what the host
+    side uses for the gradient norm (mbar_solvers.py:939) and the final all-state update (:1012) instead of another sweep."""
+    u_kn, N_k, _ = random_problem(K, N, seed=K + 1, unsampled=unsampled)
+    rng = np.random.default_rng(K)
+    c_n, first = np.zeros(N), 0
+    for n_k in N_k:  # draw counts of one bootstrap replicate (they sum to N_k within each state's block)
+        if n_k > 0:
+            c_n[first:first + n_k] = np.bincount(rng.integers(0, n_k, size=n_k), minlength=n_k)
+        first += n_k
+    with DM.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        for weights, start in ((None, None), (None, "warm"), (c_n, "warm")):
+            dm.set_sample_weights(weights)
+            f0 = np.zeros(K) if start is None else fa + 0.1 * np.sin(np.arange(K)) * (N_k > 0)  # noqa: F821
+            fa, ra = dm.solve_adaptive(f0, tol=1e-10, min_sc_iter=0)
+            assert ra["success"] and ra["psum"] is not None
+            psum = dm.eval(fa)[0][0]
+            np.testing.assert_allclose(ra["psum"], psum, rtol=1e-11, atol=1e-11 * float(N_k.max()))
+        dm.set_sample_weights(None)
+        # nothing stale: a change of the matrix withdraws them
+        dm.upload_rows(0, u_kn[0] + 0.25)
+        from pymbar_amd.device import _dptr
+
+        assert dm._lib.mbar_ctx_last_solve_psum(dm._ctx, _dptr(np.empty(K))) != 0
