@@ -1,0 +1,131 @@
+"""Randomised parity sweep of the gfx950 path against the CPU oracle: state counts on and around every kernel boundary
+(16-state blocks, the 128 / 256 / 512 panel limits), sample counts on and around the tile sizes, random sets of states
+without samples, random energy scales, bootstrap draw counts, and a random choice among the loop / sweep variants the
+library can run a problem through.  Deterministic (case i is seeded by i); ``MBAR_FUZZ_CASES`` sets how many cases run
+(default 48; the committed ``profiles/r3_fuzz_parity.txt`` is a run of 400)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mbar_oracle as oracle  # noqa: E402
+from pymbar_amd import testsystems as ts  # noqa: E402
+
+EDGE_K = (1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 40, 47, 48, 49, 63, 64, 65, 96, 111, 112, 113, 127, 128, 129, 130, 144, 159, 160, 161,
+          176, 191, 192, 193, 208, 240, 255, 256, 257, 258, 300, 383, 384, 385, 511, 512, 513, 600)
+EDGE_N = (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096,
+          4097, 8191, 8192, 8193)
+OPTIONS = (("pmode", (0, 1)), ("fused", (0, 1)), ("graph", (0, 1)), ("device_loop", (0, 1)), ("gram_quad", (0, 1)),
+           ("device_loop_wide", (0, 1)), ("wide_pmode", (0, 1)), ("merge_select", (0, 1)), ("staging", (0, 1)), ("pcache", (0, 1)),
+           ("lse_variant", (0, 1, 2, 3)), ("gram_variant", (0, 1, 2)), ("adapt_batch", (1, 2, 8)))
+
+
+def draw_case(i):
+    rng = np.random.default_rng(1000 + i)
+    K = int(rng.choice(EDGE_K)) if rng.random() < 0.7 else int(rng.integers(1, 601))
+    cap = max(64, min(60000, 3_000_000 // K))
+    N = int(rng.choice(EDGE_N)) if rng.random() < 0.4 else int(rng.integers(max(1, K // 8), cap))
+    N = max(1, min(N, cap))
+    # sample counts: multinomial, with a random set of states emptied into state `keep` (at least one state keeps samples)
+    N_k = rng.multinomial(N, np.ones(K) / K)
+    if K > 1 and rng.random() < 0.6:
+        empty = rng.choice(K, size=int(rng.integers(1, max(2, K // 3))), replace=False)
+        keep = int(rng.integers(0, K))
+        for k in empty:
+            if k != keep:
+                N_k[keep] += N_k[k]
+                N_k[k] = 0
+    spread = float(rng.choice([0.3, 1.0, 1.0, 2.5]))
+    O_k = np.linspace(0.0, 3.0, K) * spread + 0.1 * rng.standard_normal(K)
+    K_k = np.exp(rng.uniform(np.log(0.8), np.log(3.0), size=K))
+    _, u_kn, N_k, _ = ts.harmonic_u_kn(O_k, K_k, N_k, seed=i)
+    if rng.random() < 0.3:  # per-sample shifts of hundreds of kT leave every reduced quantity but the objective unchanged
+        u_kn = u_kn + 300.0 * rng.standard_normal(N)[None, :]
+    f = ts.harmonic_free_energies(K_k) + 0.2 * rng.standard_normal(K)
+    f -= f[0]
+    opts = {name: int(rng.choice(vals)) for name, vals in OPTIONS if rng.random() < 0.35}
+    c_n = None
+    if rng.random() < 0.35:
+        c_n, first = np.zeros(N), 0
+        for n_k in N_k:
+            if n_k > 0:
+                c_n[first:first + n_k] = np.bincount(rng.integers(0, n_k, size=n_k), minlength=n_k)
+            first += n_k
+    return dict(K=K, N=N, u_kn=np.ascontiguousarray(u_kn), N_k=N_k, f=f, opts=opts, c_n=c_n, min_sc_iter=int(rng.choice([0, 0, 2, 3])),
+                gamma=float(rng.choice([1.0, 1.0, 0.8])))
+
+
+def check_case(DM, case):
+    K, N, u_kn, N_k, f, c_n = case["K"], case["N"], case["u_kn"], case["N_k"], case["f"], case["c_n"]
+    Nf = N_k.astype(float)
+    scale = max(1.0, float(Nf.max()))
+    sws = np.where(N_k > 0)[0]
+    # the oracle sees draw counts as repeated columns
+    u_or = u_kn if c_n is None else np.ascontiguousarray(np.repeat(u_kn, c_n.astype(int), axis=1))
+    with DM.from_host(u_kn) as dm:
+        for name, value in case["opts"].items():
+            dm.set_option(name, value)
+        dm.set_Nk(N_k)
+        dm.set_sample_weights(c_n)
+        psum, sld, gram = dm.eval(f, gram=True)
+        part = oracle.shard_partials(u_or, N_k, f, want_gram=True)
+        np.testing.assert_allclose(psum[0], part["psum"], rtol=1e-10, atol=1e-11 * scale, err_msg="psum")
+        np.testing.assert_allclose(sld[0], part["sumlogden"], rtol=1e-11, atol=1e-8, err_msg="sumlogden")
+        np.testing.assert_allclose(gram, part["gram"], rtol=1e-9, atol=1e-12 * scale, err_msg="gram")
+        f2 = f + 0.05 * np.cos(np.arange(K))
+        ps2 = dm.eval(np.stack([f, f2]))[0]
+        np.testing.assert_allclose(ps2[1], oracle.shard_partials(u_or, N_k, f2)["psum"], rtol=1e-10, atol=1e-11 * scale, err_msg="psum 2")
+        np.testing.assert_allclose(ps2[0], psum[0], rtol=1e-12, atol=1e-12 * scale, err_msg="psum 1 of 2")
+        np.testing.assert_allclose(-dm.lognum(f), oracle.self_consistent_update(u_or, N_k, f), rtol=1e-11, atol=1e-10, err_msg="lognum")
+        if c_n is None:
+            np.testing.assert_allclose(dm.logden(f), oracle.log_denominator(u_kn, N_k, f), rtol=1e-12, atol=1e-11, err_msg="logden")
+            W = oracle.mbar_W_nk(u_kn, N_k, f)
+            G, wsum = dm.gram_w(f)
+            np.testing.assert_allclose(G, W.T @ W, rtol=1e-9, atol=1e-13, err_msg="gram_w")
+            np.testing.assert_allclose(wsum, W.sum(0), rtol=1e-10, atol=1e-13, err_msg="wsum")
+        if len(sws) < 2:
+            return "L1 only (one sampled state)"
+        # the adaptive solve: same iteration count as the oracle's loop unless a comparison sits at round-off level, and
+        # the gradient of the ORACLE at the returned f is as small as at the oracle's own answer
+        tol = 1e-10
+        f0 = np.zeros(K)
+        fa, ra = dm.solve_adaptive(f0, tol=tol, maxiter=500, min_sc_iter=case["min_sc_iter"], gamma=case["gamma"], history_rows=500)
+        hist = []
+        ro = oracle.adaptive(u_or[sws], Nf[sws], f0[sws], tol=tol, maxiter=500, min_sc_iter=case["min_sc_iter"], gamma=case["gamma"],
+                             history=hist)
+        assert ra["success"] == ro["success"], (ra, ro["iterations"])
+        g_dev = oracle.mbar_gradient(u_or[sws], Nf[sws], fa[sws] - fa[sws][0])
+        g_or = oracle.mbar_gradient(u_or[sws], Nf[sws], ro["x"])
+        assert np.abs(g_dev).max() <= 10.0 * np.abs(g_or).max() + 1e-8 * scale, (np.abs(g_dev).max(), np.abs(g_or).max())
+        if ra.get("psum") is not None:
+            np.testing.assert_allclose((ra["psum"] - Nf)[sws], -g_dev, rtol=0, atol=1e-9 * scale + 1e-6 * np.abs(g_dev).max(), err_msg="psum at the result")
+        close_call = any(abs(h["gnorm_sci"] - h["gnorm_nr"]) <= 1e-6 * max(h["gnorm_sci"], h["gnorm_nr"]) + 1e-9 * scale for h in hist)
+        near_tol = any(0.1 * tol < h["max_delta"] < 10 * tol for h in hist)
+        if not close_call and not near_tol:
+            assert ra["iterations"] == ro["iterations"], (ra["iterations"], ro["iterations"], ra["nr_iter"], ro["nr_iter"])
+            np.testing.assert_allclose(fa[sws] - fa[sws][0], ro["x"], rtol=1e-7, atol=1e-7, err_msg="f")
+        return f"{ra['iterations']} iterations ({ro['iterations']})"
+
+
+def test_randomised_problems_match_the_oracle():
+    from pymbar_amd.device import DeviceMatrix
+
+    n = int(os.environ.get("MBAR_FUZZ_CASES", "48"))
+    first = int(os.environ.get("MBAR_FUZZ_FIRST", "0"))
+    log = os.environ.get("MBAR_FUZZ_LOG")
+    lines, failures = [], []
+    for i in range(first, first + n):
+        case = draw_case(i)
+        tag = (f"case {i}: K={case['K']} N={case['N']} sampled={int((case['N_k'] > 0).sum())} weights={case['c_n'] is not None} "
+               f"min_sc_iter={case['min_sc_iter']} gamma={case['gamma']} options={case['opts']}")
+        try:
+            lines.append(tag + " -> " + check_case(DeviceMatrix, case))
+        except Exception as exc:  # noqa: BLE001  (a library error in one case must not hide the others)
+            failures.append(tag + "\n" + type(exc).__name__ + ": " + str(exc)[:1500])
+            lines.append(tag + " -> FAILED")
+    if log:
+        with open(log, "w") as fh:
+            fh.write("\n".join(lines) + f"\n{len(lines) - len(failures)} of {len(lines)} cases agree with the oracle\n")
+    assert not failures, "\n\n".join(failures[:5]) + f"\n({len(failures)} of {n} cases failed)"
