@@ -129,3 +129,87 @@ def test_randomised_problems_match_the_oracle():
         with open(log, "w") as fh:
             fh.write("\n".join(lines) + f"\n{len(lines) - len(failures)} of {len(lines)} cases agree with the oracle\n")
     assert not failures, "\n\n".join(failures[:5]) + f"\n({len(failures)} of {n} cases failed)"
+
+
+def check_case_across_ranks(case, i):
+    """The same problem on 2-3 logical ranks with RANDOM shard boundaries (in-process stream transport, as in
+    tests/test_gpu_loopback.py): ranks bit-identical to each other, and equal to the single-context run up to the
+    summation order."""
+    from pymbar_amd.device import DeviceMatrix, LoopbackGroup
+    from tests.test_gpu_loopback import run_ranks
+
+    K, N, u_kn, N_k, f, c_n = case["K"], case["N"], case["u_kn"], case["N_k"], case["f"], case["c_n"]
+    rng = np.random.default_rng(77 + i)
+    nranks = int(rng.integers(2, 4))
+    if N < nranks:
+        return "skipped (fewer samples than ranks)"
+    cuts = np.sort(rng.choice(np.arange(1, N), size=nranks - 1, replace=False)) if N > nranks else np.arange(1, nranks)
+    bounds = [0] + [int(c) for c in cuts] + [N]
+    sws = np.where(N_k > 0)[0]
+    scale = max(1.0, float(N_k.max()))
+    tol = 1e-10
+
+    def run(dm, c_local):
+        for name, value in case["opts"].items():
+            dm.set_option(name, value)
+        dm.set_Nk(N_k)
+        dm.set_sample_weights(c_local)
+        out = dict(eval=dm.eval(f, gram=True), lognum=dm.lognum(f))
+        if len(sws) >= 2:
+            out["solve"] = dm.solve_adaptive(np.zeros(K), tol=tol, maxiter=500, min_sc_iter=case["min_sc_iter"], gamma=case["gamma"],
+                                             history_rows=500)
+        return out
+
+    with DeviceMatrix.from_host(u_kn) as one:
+        ref = run(one, c_n)
+    with LoopbackGroup(nranks) as grp:
+        def worker(r):
+            n0, n1 = bounds[r], bounds[r + 1]
+            with DeviceMatrix.from_host(u_kn, columns=(n0, n1)) as dm:
+                dm.set_loopback(grp, r)
+                res = run(dm, None if c_n is None else c_n[n0:n1])
+                dm.comm_destroy()
+                return res
+
+        ranks = run_ranks(nranks, worker)
+    r0 = ranks[0]
+    for r in ranks[1:]:
+        for a, b in zip(r0["eval"], r["eval"]):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert np.array_equal(r0["lognum"], r["lognum"], equal_nan=True)
+        if "solve" in r0:
+            assert np.array_equal(r0["solve"][0], r["solve"][0], equal_nan=True) and r0["solve"][1]["iterations"] == r["solve"][1]["iterations"]
+    for a, b in zip(r0["eval"], ref["eval"]):
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-11 * scale)
+    np.testing.assert_allclose(r0["lognum"], ref["lognum"], rtol=1e-12, atol=1e-11)
+    if "solve" not in r0:
+        return f"{nranks} ranks {bounds}: L1 only"
+    (fa, ra), (fr, rr) = r0["solve"], ref["solve"]
+    assert ra["success"] == rr["success"]
+    h = rr["history"]
+    close_call = np.any(np.abs(h[:, 1] - h[:, 2]) <= 1e-6 * np.maximum(h[:, 1], h[:, 2]) + 1e-9 * scale)
+    near_tol = np.any((h[:, 3] > 0.1 * tol) & (h[:, 3] < 10 * tol)) if h.shape[1] > 3 else False
+    if not close_call and not near_tol:
+        assert ra["iterations"] == rr["iterations"], (ra["iterations"], rr["iterations"])
+        np.testing.assert_allclose(fa[sws], fr[sws], rtol=1e-8, atol=1e-8)
+    return f"{nranks} ranks {bounds}: {ra['iterations']} iterations ({rr['iterations']})"
+
+
+def test_randomised_problems_across_logical_ranks():
+    n = int(os.environ.get("MBAR_FUZZ_RANK_CASES", "16"))
+    first = int(os.environ.get("MBAR_FUZZ_FIRST", "0"))
+    log = os.environ.get("MBAR_FUZZ_RANK_LOG")
+    lines, failures = [], []
+    for i in range(first, first + n):
+        case = draw_case(5000 + i)
+        tag = (f"case {5000 + i}: K={case['K']} N={case['N']} sampled={int((case['N_k'] > 0).sum())} weights={case['c_n'] is not None} "
+               f"min_sc_iter={case['min_sc_iter']} gamma={case['gamma']} options={case['opts']}")
+        try:
+            lines.append(tag + " -> " + check_case_across_ranks(case, i))
+        except Exception as exc:  # noqa: BLE001
+            failures.append(tag + "\n" + type(exc).__name__ + ": " + str(exc)[:1500])
+            lines.append(tag + " -> FAILED")
+    if log:
+        with open(log, "w") as fh:
+            fh.write("\n".join(lines) + f"\n{len(lines) - len(failures)} of {len(lines)} cases: ranks bit-identical, equal to one context\n")
+    assert not failures, "\n\n".join(failures[:5]) + f"\n({len(failures)} of {n} cases failed)"
