@@ -100,6 +100,8 @@ int mbar_device_synchronize(int device);
  *                    the five launches per iteration it replaces: 77 against 51 us at K=40, N=95000); 0 = default
  *   "wide_pmode"     1 = 129 <= K <= 256 also keep a resident probability matrix and run ONE fused sweep per iteration
  *                    (k_fused_quad; default); 0 = two sweeps on u there (one-read Gram + evaluation sweep)
+ *   "quad_trim"      1 = 129 .. 160 and 193 .. 224 states: the one-read Gram / fused sweeps skip the two padding blocks of the
+ *                    192- / 256-row panel (default); 0 = the whole panel
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
  *   "timing"         HIP-event timers (mbar_ctx_timing): 0 = off (default: an event pair per sweep costs ~10 us, a fifth of an
  *                    iteration at the problem sizes pymbar is mostly used on), 1 = event records around a launch, 2 = events

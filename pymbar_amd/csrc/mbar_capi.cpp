@@ -268,7 +268,7 @@ struct mbar_ctx {
     // options
     int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_persistent = 0, opt_merge_select = 1, opt_wide_pmode = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_persistent = 0, opt_merge_select = 1, opt_wide_pmode = 1, opt_quad_trim = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -699,6 +699,9 @@ GramPlan gram_plan(int64_t Kp, bool quad = false) {
 // 129 .. 256 states: the one-read kernel (k_gram_quad) needs LDS-DMA staging
 bool use_quad(const mbar_ctx* c) { return c->opt_quad && c->opt_staging == 0 && use_fast(c) && c->Kp > 128 && c->Kp <= 256; }
 GramPlan plan_for(const mbar_ctx* c) { return gram_plan(c->Kp, use_quad(c)); }
+// blocks of 16 states of the 192- / 256-row panel that hold real states: up to 160 / 224 states the one-read kernels leave the
+// last two blocks (padding rows only) out of the staging, the operand step and the matrix instructions
+int quad_live_blocks(const mbar_ctx* c) { return c->opt_quad_trim ? (int)((c->K + 15) / 16) : 0; }
 
 // Gram pass with operand exp(anum_k - u_kn - logden_n); anum (device) has Kp entries.
 // Results: gram blocks at red + red_off (plan order).  The per-state operand sums are not accumulated on the
@@ -713,7 +716,8 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
     }
     for (const auto& it : plan.items) {
         if (it.diag && it.nbi > 8) {  // one read of the matrix: the four waves of a workgroup split the panel's blocks
-            const LaunchGeom g = gram_quad_geometry(it.nbi, c->num_cu, ntiles, c->opt_grid);
+            LaunchGeom g = gram_quad_geometry(it.nbi, c->num_cu, ntiles, c->opt_grid);
+            g.live_blocks = quad_live_blocks(c);
             const size_t rec = (size_t)it.nblk * 256;
             int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
             if (rc) return rc;
@@ -1292,9 +1296,10 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     LaunchGeom gg = wide ? gram_quad_geometry(nb, c->num_cu, ntiles, c->opt_grid)
                          : gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
-    const LaunchGeom gl = fused ? fused_geometry(nb, c->num_cu, ntiles, c->opt_grid)
-                          : pmode ? psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid)
-                                  : lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+    LaunchGeom gl = fused ? fused_geometry(nb, c->num_cu, ntiles, c->opt_grid)
+                    : pmode ? psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid)
+                            : lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+    if (wide) gg.live_blocks = gl.live_blocks = quad_live_blocks(c);
     if (fused) {  // the separate Gram sweep (when it runs) leaves its partial records where the fused sweep leaves them
         gg.blocks = gl.blocks;
         gg.nwaves = gl.nwaves;
@@ -1972,6 +1977,10 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "persistent") c->opt_persistent = value;
     else if (k == "merge_select") c->opt_merge_select = value;
     else if (k == "wide_pmode") c->opt_wide_pmode = value;
+    else if (k == "quad_trim") {
+        c->opt_quad_trim = value;
+        c->P_valid = false;  // (the trimmed build never writes the padding rows of P, the untrimmed sweeps read them)
+    }
     else if (k == "adapt_batch") c->opt_adapt_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(c, MBAR_ERR_ARG, "unknown option: " + k);
     return MBAR_OK;

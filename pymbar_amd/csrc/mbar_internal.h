@@ -66,6 +66,7 @@ struct LaunchGeom {
     int psum_records;  // number of partial records of the per-state sums (Gram kernels)
     int variant;       // kernel variant chosen (see lse_geometry / gram_geometry)
     size_t lds_bytes;
+    int live_blocks = 0;  // k_gram_quad / k_fused_quad: blocks of 16 states that hold real states (0: all of the panel's)
 };
 
 // ---- evaluation pass -------------------------------------------------------------------------

@@ -1543,18 +1543,48 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // single-panel kernel, so the reduction, the K x K solve and the host-side unpacking are the ones of K <= 128).
 // ---------------------------------------------------------------------------------------------
 constexpr int quad_blocks_of(int nbt, int w) { return (nbt * (nbt + 1) / 2 - w + 3) / 4; }
+// A wave's blocks into the workgroup's record (the NBT panel's layout: block (I, J), I <= J, row-major): live blocks -- every
+// fourth of the NBM triangle -- from the accumulators, the blocks of the padding rows (every fourth of those) as zeros.
+template <int NBT, int NBM, int WV, typename Acc>
+__device__ __forceinline__ void quad_store_blocks(double* __restrict__ rec, const Acc& acc, int lane) {
+    int b = 0, live = 0, dead = 0, mine = 0;
+#pragma unroll
+    for (int I = 0; I < NBT; ++I)
+#pragma unroll
+        for (int J = I; J < NBT; ++J) {
+            if (I < NBM && J < NBM) {
+                if ((live & 3) == WV) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rec[(b * 4 + r) * 64 + lane] = acc[mine][r];
+                    ++mine;
+                }
+                ++live;
+            } else {
+                if ((dead & 3) == WV) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rec[(b * 4 + r) * 64 + lane] = 0.0;
+                }
+                ++dead;
+            }
+            ++b;
+        }
+}
 // STOREP (classic operands only): the operand tile IS the normalised probability matrix exp(a - u - logden) when `logden` are the
 // log-denominators at `a` -- each wave also writes its quarter of it out (coalesced 16-byte stores that mirror the LDS-DMA
 // pattern, behind the blocks of group 1): the build of the resident probability matrix for 129 .. 256 states rides on the Gram
 // sweep at the anchor.
-template <int NBT, int WV, bool WIDE, bool PMODE, bool STOREP = false>
+// NBM <= NBT: blocks of 16 states that hold real states (a 160-state problem in the 192-row panel: 10 of 12).  The rows
+// beyond are padding: they are neither staged nor turned into operands, and their blocks are left out (55 matrix instructions
+// per k-step instead of 78) -- the record keeps the panel's layout, with zeros there.
+template <int NBT, int WV, bool WIDE, bool PMODE, bool STOREP = false, int NBM = NBT>
 __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                                                const double* __restrict__ anum, const double* __restrict__ logden,
                                                double* __restrict__ gram_part, char* smem, int lane, double* __restrict__ Pout = nullptr) {
     constexpr int ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + one copy of the tile's 16 logden values per wave (a 1 KB LDS-DMA piece each)
-    constexpr int NBLK = NBT * (NBT + 1) / 2, NMINE = quad_blocks_of(NBT, WV);
+    constexpr int NBLK = NBT * (NBT + 1) / 2, NMINE = quad_blocks_of(NBM, WV);
+    static_assert(NBM <= NBT && quad_blocks_of(NBM, 3) >= QDMA + 2, "every wave needs QDMA + 2 blocks to hang its LDS-DMA behind");
     // (hand-placed asm matrix instructions also for the 192-state panel, whose 19 / 20 blocks per wave the compiler could manage:
     // left to it, K = 192 ran at 0.565 of the matrix peak against 0.600 this way)
     constexpr bool PINNED = true;
@@ -1567,7 +1597,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
     double aS[NQ];  // exponent constants of the rows this wave turns into operands, in table units
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        double a = PMODE ? 0.0 : anum[16 * (WV * NQ + i) + ks];
+        double a = (PMODE || WV * NQ + i >= NBM) ? 0.0 : anum[16 * (WV * NQ + i) + ks];
         if constexpr (!PMODE) settle(a);
         aS[i] = a * LOG2E_S;
     }
@@ -1583,7 +1613,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
     // (behind the tile, one 128-byte slot per wave): everything a wave needs to turn its rows into operands it has staged
     // itself, so that step needs no barrier
     auto stage_piece_j = [&](int64_t tile, char* dst, int j) {
-        stage_piece<true>(u + rows(8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
+        if (j < 2 * NBM) stage_piece<true>(u + rows(8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);  // (j is a constant)
     };
     // (a full-wave LDS-DMA of 1 KB: lanes 0 .. 7 bring the 16 values, the others repeat them -- no exec-masked branch among the
     // matrix instructions: the register allocator handles the pinned accumulators only in straight-line code)
@@ -1599,7 +1629,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
     };
     auto read_group = [&](const char* tb, int g, double (&x)[NBT]) {
 #pragma unroll
-        for (int I = 0; I < NBT; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
+        for (int I = 0; I < NBM; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
     };
     auto mfma = [&](int b, double x, double y) {
         if constexpr (PINNED) {
@@ -1624,7 +1654,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
             ldc[g] = *reinterpret_cast<const double*>(tb + U_BYTES + WV * 1024 + (4 * g + ns) * 8);
 #pragma unroll
             for (int i = 0; i < NQ; ++i)
-                x[g * NQ + i] = *reinterpret_cast<const double*>(tb + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]);
+                x[g * NQ + i] = WV * NQ + i < NBM ? *reinterpret_cast<const double*>(tb + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) : 0.0;
         }
     };
     int64_t t = blockIdx.x;
@@ -1669,7 +1699,8 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
             for (int g = 0; g < GROUPS; ++g)
 #pragma unroll
                 for (int i = 0; i < NQ; ++i)
-                    *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i];
+                    if (WV * NQ + i < NBM)
+                        *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i];
         }
         __syncthreads();  // every row of tile t holds operands; every wave is done with the other buffer
         // ---- this wave's blocks, group by group; the operands of the next group are requested behind the first block, the
@@ -1682,11 +1713,11 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 7");
             }
-            int b = 0, mine = 0;
+            int b = 0, mine = 0;  // (b counts the blocks of the LIVE triangle here)
 #pragma unroll
-            for (int I = 0; I < NBT; ++I)
+            for (int I = 0; I < NBM; ++I)
 #pragma unroll
-                for (int J = I; J < NBT; ++J) {
+                for (int J = I; J < NBM; ++J) {
                     if ((b & 3) == WV) {
                         mfma(mine, p[g & 1][I], p[g & 1][J]);
                         if (mine == 0 && g < GROUPS - 1) {
@@ -1702,7 +1733,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
                                 stage_l(tnext, nbuf);
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (STOREP && g == 1 && mine >= 1 && mine <= QDMA) {  // this wave's quarter of the operand tile out as P
+                        if (STOREP && g == 1 && mine >= 1 && mine <= QDMA && WV * QDMA + mine - 1 < 2 * NBM) {  // this wave's quarter of the operand tile out as P
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                             const int j = WV * QDMA + mine - 1;
                             const double2 pv = *reinterpret_cast<const double2*>(cbuf + j * 1024 + lane * 16);
@@ -1724,23 +1755,10 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
         cur ^= 1;
     }
     if constexpr (PINNED) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // matrix result -> VALU read distance
-    {
-        int b = 0, mine = 0;
-#pragma unroll
-        for (int I = 0; I < NBT; ++I)
-#pragma unroll
-            for (int J = I; J < NBT; ++J) {
-                if ((b & 3) == WV) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gram_part[(((int64_t)blockIdx.x * NBLK + b) * 4 + r) * 64 + lane] = acc[mine][r];
-                    ++mine;
-                }
-                ++b;
-            }
-    }
+    quad_store_blocks<NBT, NBM, WV>(gram_part + (int64_t)blockIdx.x * NBLK * 256, acc, lane);
 }
 
-template <int NBT, bool WIDE, bool PMODE, bool STOREP = false>
+template <int NBT, bool WIDE, bool PMODE, bool STOREP = false, int NBM = NBT>
 __global__ void __launch_bounds__(256, 1)
 k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ anum,
             const double* __restrict__ logden, double* __restrict__ gram_part, const int* __restrict__ ctl,
@@ -1758,10 +1776,10 @@ k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         __syncthreads();
     }
     switch (wave) {
-        case 0: gram_quad_body<NBT, 0, WIDE, PMODE, STOREP>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
-        case 1: gram_quad_body<NBT, 1, WIDE, PMODE, STOREP>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
-        case 2: gram_quad_body<NBT, 2, WIDE, PMODE, STOREP>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
-        default: gram_quad_body<NBT, 3, WIDE, PMODE, STOREP>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
+        case 0: gram_quad_body<NBT, 0, WIDE, PMODE, STOREP, NBM>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
+        case 1: gram_quad_body<NBT, 1, WIDE, PMODE, STOREP, NBM>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
+        case 2: gram_quad_body<NBT, 2, WIDE, PMODE, STOREP, NBM>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
+        default: gram_quad_body<NBT, 3, WIDE, PMODE, STOREP, NBM>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
     }
 }
 
@@ -1775,7 +1793,7 @@ k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 //   [normalisers, reciprocals, per-state sums; operands P / s written in place] [barrier] [own blocks; next tile's LDS-DMA
 //   behind the first of them]
 // ---------------------------------------------------------------------------------------------
-template <int NBT, int WV, bool WIDE>
+template <int NBT, int WV, bool WIDE, int NBM = NBT>
 __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles,
                                                 const double* __restrict__ cmul, const double* __restrict__ cw,
                                                 const double* __restrict__ wsq, double* __restrict__ rinv0,
@@ -1784,7 +1802,8 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
     constexpr int ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + per wave: the tile's 16 multiplicities and their 16 roots (a 1 KB LDS-DMA piece)
-    constexpr int NBLK = NBT * (NBT + 1) / 2, NMINE = quad_blocks_of(NBT, WV);
+    constexpr int NBLK = NBT * (NBT + 1) / 2, NMINE = quad_blocks_of(NBM, WV);
+    static_assert(NBM <= NBT && quad_blocks_of(NBM, 3) >= QDMA + 2, "every wave needs QDMA + 2 blocks to hang its LDS-DMA behind");
     const int ks = lane & 15, ns = lane >> 4;
     char* buf = smem;  // two tile buffers shared by the four waves; behind them the table of partial normalisers
     double* xs = reinterpret_cast<double*>(smem + 2 * TILE_BYTES);  // [wave][candidate][16 samples]
@@ -1795,8 +1814,8 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
     double c0[NQ], c1[NQ], acc0[NQ], acc1[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        c0[i] = cmul[16 * (WV * NQ + i) + ks];
-        c1[i] = cmul[ROWS + 16 * (WV * NQ + i) + ks];
+        c0[i] = WV * NQ + i < NBM ? cmul[16 * (WV * NQ + i) + ks] : 0.0;
+        c1[i] = WV * NQ + i < NBM ? cmul[ROWS + 16 * (WV * NQ + i) + ks] : 0.0;
         acc0[i] = acc1[i] = 0.0;
     }
 #pragma unroll
@@ -1813,7 +1832,7 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
     for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
 
     auto stage_piece_j = [&](int64_t tile, char* dst, int j) {
-        stage_piece<true>(P + rows(8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
+        if (j < 2 * NBM) stage_piece<true>(P + rows(8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);  // (j is a constant)
     };
     // multiplicities and their roots behind the tile, one full-wave piece per wave: even 128-byte rows of it take cw, odd rows wsq
     const char* wsrc = reinterpret_cast<const char*>(((lane >> 3) & 1) ? wsq : cw) + (lane & 7) * 16;
@@ -1828,7 +1847,7 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
     };
     auto read_group = [&](const char* tb, int g, double (&x)[NBT]) {
 #pragma unroll
-        for (int I = 0; I < NBT; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
+        for (int I = 0; I < NBM; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
     };
     auto mfma = [&](int b, double x, double y) {
         if (b < GRAM_AGPR_BLOCKS)
@@ -1844,7 +1863,7 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
             sw[g] = *reinterpret_cast<const double*>(tb + U_BYTES + WV * 1024 + TS * 8 + (4 * g + ns) * 8);
 #pragma unroll
             for (int i = 0; i < NQ; ++i)
-                x[g * NQ + i] = *reinterpret_cast<const double*>(tb + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]);
+                x[g * NQ + i] = WV * NQ + i < NBM ? *reinterpret_cast<const double*>(tb + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) : 0.0;
         }
     };
     int64_t t = blockIdx.x;
@@ -1882,6 +1901,7 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
             const double q0 = w[g] * r0, q1 = w[g] * r1, rin = r1 * sw[g];
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
+                if (WV * NQ + i >= NBM) continue;  // (padding rows: never staged, never read)
                 acc0[i] = fma(x[g * NQ + i], q0, acc0[i]);
                 acc1[i] = fma(x[g * NQ + i], q1, acc1[i]);
                 *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i] * rin;
@@ -1899,11 +1919,11 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
         for (int g = 0; g < GROUPS; ++g) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop 7");
-            int b = 0, mine = 0;
+            int b = 0, mine = 0;  // (b counts the blocks of the LIVE triangle here)
 #pragma unroll
-            for (int I = 0; I < NBT; ++I)
+            for (int I = 0; I < NBM; ++I)
 #pragma unroll
-                for (int J = I; J < NBT; ++J) {
+                for (int J = I; J < NBM; ++J) {
                     if ((b & 3) == WV) {
                         mfma(mine, p[g & 1][I], p[g & 1][J]);
                         if (mine == 0 && g < GROUPS - 1) {
@@ -1946,23 +1966,10 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
             psum_part[((int64_t)blockIdx.x * 2 + 1) * ROWS + 16 * (WV * NQ + i) + lane] = v1;
         }
     }
-    {
-        int b = 0, mine = 0;
-#pragma unroll
-        for (int I = 0; I < NBT; ++I)
-#pragma unroll
-            for (int J = I; J < NBT; ++J) {
-                if ((b & 3) == WV) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gram_part[(((int64_t)blockIdx.x * NBLK + b) * 4 + r) * 64 + lane] = acc[mine][r];
-                    ++mine;
-                }
-                ++b;
-            }
-    }
+    quad_store_blocks<NBT, NBM, WV>(gram_part + (int64_t)blockIdx.x * NBLK * 256, acc, lane);
 }
 
-template <int NBT, bool WIDE>
+template <int NBT, bool WIDE, int NBM = NBT>
 __global__ void __launch_bounds__(256, 1)
 k_fused_quad(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cmul,
              const double* __restrict__ cw, const double* __restrict__ wsq, double* __restrict__ rinv0,
@@ -1975,10 +1982,10 @@ k_fused_quad(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {
-        case 0: fused_quad_body<NBT, 0, WIDE>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
-        case 1: fused_quad_body<NBT, 1, WIDE>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
-        case 2: fused_quad_body<NBT, 2, WIDE>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
-        default: fused_quad_body<NBT, 3, WIDE>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
+        case 0: fused_quad_body<NBT, 0, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
+        case 1: fused_quad_body<NBT, 1, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
+        case 2: fused_quad_body<NBT, 2, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
+        default: fused_quad_body<NBT, 3, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
     }
 }
 
@@ -4685,6 +4692,8 @@ static hipError_t launch_gram_quad_t(hipStream_t s, const LaunchGeom& g, const d
                                lc.slot_stride, lc.cond_needgram ? 1 : 0, Pout);
         return hipGetLastError();
     };
+    if (g.live_blocks > 0 && g.live_blocks <= NBT - 2)  // (the rows of the last two blocks are padding: the trimmed build)
+        return stage_offsets_wide(ld) ? launch(k_gram_quad<NBT, true, PMODE, STOREP, NBT - 2>) : launch(k_gram_quad<NBT, false, PMODE, STOREP, NBT - 2>);
     return stage_offsets_wide(ld) ? launch(k_gram_quad<NBT, true, PMODE, STOREP>) : launch(k_gram_quad<NBT, false, PMODE, STOREP>);
 }
 hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
@@ -5212,6 +5221,8 @@ static hipError_t launch_fused_quad_t(hipStream_t s, const LaunchGeom& g, const 
                                lc.slot_stride);
         return hipGetLastError();
     };
+    if (g.live_blocks > 0 && g.live_blocks <= NBT - 2)
+        return stage_offsets_wide(ld) ? go(k_fused_quad<NBT, true, NBT - 2>) : go(k_fused_quad<NBT, false, NBT - 2>);
     return stage_offsets_wide(ld) ? go(k_fused_quad<NBT, true>) : go(k_fused_quad<NBT, false>);
 }
 hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,

@@ -19,7 +19,7 @@ EDGE_N = (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 
           4097, 8191, 8192, 8193)
 OPTIONS = (("pmode", (0, 1)), ("fused", (0, 1)), ("graph", (0, 1)), ("device_loop", (0, 1)), ("gram_quad", (0, 1)),
            ("device_loop_wide", (0, 1)), ("wide_pmode", (0, 1)), ("merge_select", (0, 1)), ("staging", (0, 1)), ("pcache", (0, 1)),
-           ("lse_variant", (0, 1, 2, 3)), ("gram_variant", (0, 1, 2)), ("adapt_batch", (1, 2, 8)))
+           ("quad_trim", (0, 1)), ("lse_variant", (0, 1, 2, 3)), ("gram_variant", (0, 1, 2)), ("adapt_batch", (1, 2, 8)))
 
 
 def draw_case(i):

@@ -840,3 +840,30 @@ def test_solve_hands_back_the_per_state_sums_at_its_result(DM, K, N, unsampled):
         from pymbar_amd.device import _dptr
 
         assert dm._lib.mbar_ctx_last_solve_psum(dm._ctx, _dptr(np.empty(K))) != 0
+
+
+@pytest.mark.parametrize("K,N,unsampled", [(129, 3000, ()), (144, 5000, (3,)), (160, 7001, ()), (161, 2000, ()), (200, 6000, (11,)), (224, 9000, ()),
+                                           (225, 3000, ())])
+def test_padding_blocks_left_out_of_the_one_read_sweeps(DM, K, N, unsampled):
+    """Up to 160 (224) states the last two 16-state blocks of the 192- (256-) row panel are padding: k_gram_quad / k_fused_quad
+    neither stage nor multiply them ("quad_trim").  Every block is still accumulated by ONE wave over the same tile sequence,
+    so the Gram matrices agree bit for bit with the whole-panel kernels; so do the solves."""
+    u_kn, N_k, f = random_problem(K, N, seed=K, unsampled=unsampled)
+    sws = np.where(N_k > 0)[0]
+    out = []
+    for trim in (0, 1):
+        with DM.from_host(u_kn) as dm:
+            dm.set_option("quad_trim", trim)
+            dm.set_Nk(N_k)
+            check_l1(dm, u_kn, N_k, f, tag=f"K={K} trim={trim}")
+            ev = dm.eval(f, gram=True)
+            gw = dm.gram_w(f)
+            fa, ra = dm.solve_adaptive(np.zeros(K), tol=1e-10, min_sc_iter=0, history_rows=100)
+            f2, r2 = dm.solve_adaptive(fa + 0.05 * np.sin(np.arange(K)) * (N_k > 0), tol=1e-10, min_sc_iter=2)  # warm, on the resident P
+            out.append((ev, gw, fa, ra, f2, r2))
+    (e0, g0, f0, r0, w0, rw0), (e1, g1, f1, r1, w1, rw1) = out
+    assert np.array_equal(e0[2], e1[2]) and np.array_equal(e0[0], e1[0]) and np.array_equal(g0[0], g1[0])
+    assert r0["success"] and r1["success"] and r0["iterations"] == r1["iterations"] and rw0["iterations"] == rw1["iterations"]
+    assert np.array_equal(r0["history"], r1["history"]) and np.array_equal(f0, f1) and np.array_equal(w0, w1)
+    f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=1e-10, min_sc_iter=0)
+    np.testing.assert_allclose(f1[sws] - f1[sws[0]], (f_or - f_or[sws[0]])[sws], rtol=1e-8, atol=1e-8)

@@ -9,7 +9,9 @@
           evaluation sweep), and ONE fused sweep on the resident probability matrix (k_fused_quad); cold and warm solves;
   split   evaluation sweep at 257 ... 512 states: one and two candidates, row-split kernel against the layout-agnostic path.
 
-Usage: python tools/bench_wide.py [gram] [loop] [split]   (default: all)"""
+  trim    129 ... 160 / 193 ... 224 states: the one-read sweeps without the two padding blocks of their panel.
+
+Usage: python tools/bench_wide.py [gram] [loop] [split] [trim]   (default: the first three)"""
 import os
 import sys
 import time
@@ -79,6 +81,40 @@ def loop():
                       f"success={rc['success']}", flush=True)
 
 
+def trim():
+    """129 .. 160 and 193 .. 224 states: the one-read sweeps with and without the two padding blocks of the 192- / 256-row panel."""
+    for K, N in ((144, 4_000_000), (160, 4_000_000), (208, 4_000_000), (224, 4_000_000)):
+        O_k, K_k, N_k = ladder(K, N)
+        with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
+            dm.set_Nk(N_k)
+            f = ts.harmonic_free_energies(K_k)
+            out = []
+            for q in (0, 1):
+                dm.set_option("quad_trim", q)
+                dm.set_option("timing", 1)
+                G, _ = dm.gram_w(f)
+                dm.timing_reset()
+                for _ in range(6):
+                    dm.gram_w(f)
+                tg = dm.timing()["gram"][0] / 6
+                dm.set_option("timing", 0)
+                dm.set_option("pcache", 0)
+                dm.solve_adaptive(np.zeros(K), maxiter=3, min_sc_iter=0, check_convergence=False)
+                dm.synchronize()
+                t0 = time.perf_counter()
+                dm.solve_adaptive(np.zeros(K), maxiter=20, min_sc_iter=0, check_convergence=False)
+                dt = (time.perf_counter() - t0) / 20
+                t1 = time.perf_counter()
+                fc, rc = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+                dtc = time.perf_counter() - t1
+                flop = N * K * (K + 1.0)
+                out.append((G, fc, f"{'trimmed' if q else 'whole panel'}: gram_w {tg:.3f} ms = {flop / tg * 1e-9 / PEAK:.3f} of the fp64 matrix peak on "
+                            f"N K (K + 1) flop, iteration {1e3 * dt:.3f} ms, solve from f=0 {rc['iterations']} iterations {1e3 * dtc:.2f} ms"))
+            same = np.array_equal(out[0][0], out[1][0])
+            print(f"K={K} N={N}: " + " | ".join(o[2] for o in out) + f" | Gram bit-identical: {same}, largest |df| {np.max(np.abs(out[0][1] - out[1][1])):.1e}",
+                  flush=True)
+
+
 def split():
     for K, N in ((257, 2_000_000), (300, 1_000_000), (384, 1_000_000), (512, 1_000_000), (512, 4_000_000)):
         O_k, K_k, N_k = ladder(K, N)
@@ -104,4 +140,4 @@ def split():
 if __name__ == "__main__":
     want = sys.argv[1:] or ["gram", "loop", "split"]
     for w in want:
-        {"gram": gram, "loop": loop, "split": split}[w]()
+        {"gram": gram, "loop": loop, "split": split, "trim": trim}[w]()
