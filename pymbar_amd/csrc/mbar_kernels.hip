@@ -436,13 +436,18 @@ __device__ __forceinline__ StageOffsetsT<WIDE> make_stage_offsets(int64_t ld, in
     }
     return so;
 }
+// cache-policy bits of the tile loads (aux operand of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1): the default policy measured
+// best (profiles/r3_ab_streaming_hints.txt)
+#ifndef MBAR_DMA_AUX
+#define MBAR_DMA_AUX 0
+#endif
 template <bool DMA>
 __device__ __forceinline__ void stage_piece(const double* __restrict__ ubase /*wave-uniform*/, uint64_t voff,
                                             char* dst /*wave-uniform*/, int lane) {
     const char* src = reinterpret_cast<const char*>(ubase) + voff;
     if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, MBAR_DMA_AUX);
     } else {
         *reinterpret_cast<double2*>(dst + lane * 16) = *reinterpret_cast<const double2*>(src);
     }
@@ -461,7 +466,7 @@ __device__ __forceinline__ void stage_piece(const double* __restrict__ ubase /*w
     const char* src = reinterpret_cast<const char*>(ub) + voff;
     if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, MBAR_DMA_AUX);
     } else {
         *reinterpret_cast<double2*>(dst + lane * 16) = *reinterpret_cast<const double2*>(src);
     }
