@@ -477,7 +477,7 @@ __device__ __forceinline__ void stage_tile(const double* __restrict__ u, int64_t
     constexpr int NDMA = ROWS / 8;
 #pragma unroll
     for (int j = J0; j < NDMA; j += JSTEP)
-        stage_piece<DMA>(u + rowmap(8 * j) * ld + n0, so.off[j & 1], dst + j * 1024, lane);
+        stage_piece<DMA>(u + rowmap(8 * j) * ld + rowmap.cols(j, n0), so.off[j & 1], dst + j * 1024, lane);
 }
 
 // Stage the 16 per-sample values v[n0 .. n0+16) (128 bytes) behind a tile: lanes 0..7 move 16 bytes each.
@@ -497,17 +497,38 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// `live`: bit j set = the 8 rows of DMA piece j matter.  A piece whose rows all carry a per-state constant that makes their
+// terms exactly zero (exp(-inf - u): padding rows of the device matrix, states without samples) is requested from the FIRST tile's
+// columns instead of the current tile's: the same 1 KB every time (an L2 hit instead of HBM traffic), the same instruction
+// stream, the same LDS layout, and whatever lands there is multiplied by zero like the real rows would have been.
 struct RowIdentity {
     int64_t row0;
+    uint32_t live = 0xffffffffu;
     __device__ __forceinline__ int64_t operator()(int tr) const { return row0 + tr; }
+    __device__ __forceinline__ int64_t cols(int j, int64_t n0) const { return ((live >> j) & 1u) ? n0 : 0; }
 };
 struct RowTwoPanels {
     int64_t row_i0, row_j0;
     int split;
+    uint32_t live = 0xffffffffu;
     __device__ __forceinline__ int64_t operator()(int tr) const {
         return tr < split ? row_i0 + tr : row_j0 + (tr - split);
     }
+    __device__ __forceinline__ int64_t cols(int j, int64_t n0) const { return ((live >> j) & 1u) ? n0 : 0; }
 };
+// Live mask of a panel's DMA pieces from the per-state constants of its rows in the Gram / evaluation layout (lane & 15 = state
+// within block I): piece 2 I + h is dead when its 8 constants all equal `dead` (-inf exponent constants, zero multipliers).
+template <int NB>
+__device__ __forceinline__ uint32_t live_piece_mask(const double (&a)[NB], double dead) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const unsigned long long b = __ballot(a[I] != dead);
+        m |= ((b & 0xffull) ? 1u : 0u) << (2 * I);
+        m |= ((b & 0xff00ull) ? 1u : 0u) << (2 * I + 1);
+    }
+    return m;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Evaluation pass: per-sample log-sum-exp over states + per-state sums of p_nk, for NF candidates f.
@@ -547,7 +568,7 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
     // one global store per tile (lanes ks < 4 write logden0, 4 <= ks < 8 logden1) unless neither vector is wanted
     const bool has_store = logden0 != nullptr || logden1 != nullptr;
@@ -563,6 +584,7 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         settle(a[I]);
         if (NF == 2) settle(c[I]);
     }
+    rows.live = live_piece_mask<NB>(a, -INFINITY);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -668,7 +690,7 @@ k_lse_early(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     char* buf0 = smem + EXP_TABLE_BYTES + wave * (NBUF * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsets so = make_stage_offsets(ld, lane);
     const bool has_store = logden0 != nullptr || logden1 != nullptr;  // one store instruction per tile
 
@@ -683,6 +705,7 @@ k_lse_early(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         settle(a[I]);
         if (NF == 2) settle(c[I]);
     }
+    rows.live = live_piece_mask<NB>(a, -INFINITY);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -901,10 +924,16 @@ k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     }
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) settle(a[k]);
+    // pairs of rows whose exponent constants are both -inf (padding, states without samples): requested from the first tile's
+    // columns every time -- an L2 hit instead of HBM traffic (see RowIdentity::cols); 5 states in a 16-row matrix: half the bytes
+    uint32_t live = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS / 2; ++j) live |= (__ballot(a[2 * j] != -INFINITY || a[2 * j + 1] != -INFINITY) ? 1u : 0u) << j;
 
     auto stage = [&](int64_t tile) {
 #pragma unroll
-        for (int j = 0; j < ROWS / 2; ++j) stage_piece<true>(u + (int64_t)(2 * j) * ld + tile * TSS, voff, buf + j * 1024, lane);
+        for (int j = 0; j < ROWS / 2; ++j)
+            stage_piece<true>(u + (int64_t)(2 * j) * ld + (((live >> j) & 1u) ? tile * TSS : 0), voff, buf + j * 1024, lane);
         if (lane < 32) stage_piece<true>(cw + tile * TSS, (uint32_t)(lane * 16), buf + U_BYTES, lane);
     };
 
@@ -1003,7 +1032,7 @@ k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     const char* wslot = buf + U_BYTES;
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsets so = make_stage_offsets(ld, lane);
     const bool has_store = logden0 != nullptr || logden1 != nullptr;  // one store instruction per tile
 
@@ -1018,6 +1047,7 @@ k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         settle(a[I]);
         if (NF == 2) settle(c[I]);
     }
+    rows.live = live_piece_mask<NB>(a, -INFINITY);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -1265,7 +1295,7 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
     const int64_t S = (int64_t)gridDim.x * STREAMS;
     const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
     const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;  // block-uniform trip count
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsets so = make_stage_offsets(ld, lane);
 
     double a[NB], c[NB], acc[NF][NB], objl = 0.0;
@@ -1279,6 +1309,7 @@ __device__ __forceinline__ void lse_pair_body(const double* __restrict__ u, int6
         settle(a[I]);
         if (NF == 2) settle(c[I]);
     }
+    rows.live = live_piece_mask<NB>(a, -INFINITY);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -1401,7 +1432,7 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     char* buf = smem + EXP_TABLE_BYTES + wave * (NBUF * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
-    const RowTwoPanels rows{row_i0, row_j0, DIAG ? ROWS : NBI * 16};
+    RowTwoPanels rows{row_i0, row_j0, DIAG ? ROWS : NBI * 16};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
     double a[NBT];
@@ -1410,6 +1441,10 @@ k_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     if constexpr (!PMODE) {
 #pragma unroll
         for (int I = 0; I < NBT; ++I) settle(a[I]);
+        // (panels of one or two blocks only: there the sweep is bound by HBM and up to half of the rows can be padding; from
+        // three blocks on the ~2 scalar instructions per piece and tile cost the matrix pipe more than the bytes save --
+        // profiles/r3_ab_padding_rows_from_l2.txt)
+        if constexpr (NBT <= 2) rows.live = live_piece_mask<NBT>(a, -INFINITY);
     }
     double aS[NBT];  // exponent arguments are formed directly in table units: t = (a - logden - u) S log2(e)
 #pragma unroll
@@ -1595,7 +1630,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
     constexpr bool PINNED = true;
     const int ks = lane & 15, ns = lane >> 4;
     char* buf = smem + EXP_TABLE_BYTES;  // two tile buffers shared by the four waves
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
     const int64_t G = gridDim.x;
 
@@ -1812,7 +1847,7 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
     const int ks = lane & 15, ns = lane >> 4;
     char* buf = smem;  // two tile buffers shared by the four waves; behind them the table of partial normalisers
     double* xs = reinterpret_cast<double*>(smem + 2 * TILE_BYTES);  // [wave][candidate][16 samples]
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
     const int64_t G = gridDim.x;
 
@@ -2059,7 +2094,7 @@ __device__ __forceinline__ void gram_pair_body(const double* __restrict__ u, int
     const int64_t S = (int64_t)gridDim.x * STREAMS;
     const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
     const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;  // block-uniform trip count
-    const RowIdentity rows{row0};
+    RowIdentity rows{row0};
     const StageOffsets so = make_stage_offsets(ld, lane);
 
     double a[NB];
@@ -2171,7 +2206,7 @@ __device__ __forceinline__ void gram_xchg_body(const double* __restrict__ u, int
     const int64_t S = (int64_t)gridDim.x * STREAMS;
     const int64_t gs0 = (int64_t)blockIdx.x * STREAMS;
     const int64_t niter = ntiles > gs0 ? (ntiles - gs0 + S - 1) / S : 0;
-    const RowIdentity rows{row0};
+    RowIdentity rows{row0};
     const StageOffsets so = make_stage_offsets(ld, lane);
 
     double a[NB];
@@ -2631,7 +2666,7 @@ k_build_sweep(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntile
     char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
     double a[NB], acc[NB];
@@ -2642,6 +2677,7 @@ k_build_sweep(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntile
     }
 #pragma unroll
     for (int I = 0; I < NB; ++I) settle(a[I]);
+    rows.live = live_piece_mask<NB>(a, -INFINITY);
     const int rd_base = ks * (TS * 8);
     int pos[GROUPS];
 #pragma unroll
@@ -2723,7 +2759,7 @@ k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles
     char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
     double a[NB], acc[NB];
@@ -2734,6 +2770,7 @@ k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles
     }
 #pragma unroll
     for (int I = 0; I < NB; ++I) settle(a[I]);
+    if constexpr (NB <= 2) rows.live = live_piece_mask<NB>(a, -INFINITY);  // (narrow panels only: see k_gram)
     v4d G[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) G[b] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -2890,7 +2927,7 @@ k_psweep(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, co
     char* buf = smem + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
     double c[NF][NB], acc[NF][NB];
@@ -2905,6 +2942,12 @@ k_psweep(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, co
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int I = 0; I < NB; ++I) settle(c[f][I]);
+    {   // rows whose multipliers are zero for every candidate (states without samples, padding: their rows of P are zero too)
+        double cany[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) cany[I] = NF == 2 ? fabs(c[0][I]) + fabs(c[NF - 1][I]) : c[0][I];
+        rows.live = live_piece_mask<NB>(cany, 0.0);
+    }
     const int rd_base = ks * (TS * 8);
     int pos[GROUPS];
 #pragma unroll
@@ -3043,7 +3086,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
     char* buf = smem + wave * (2 * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
     double acc[2][NB];
@@ -3051,6 +3094,12 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
     for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
+    {   // rows whose multipliers are zero for both candidates (states without samples, padding: their rows of P are zero too)
+        double cany[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) cany[I] = fabs(cmul[16 * I + ks]) + fabs(cmul[ROWS + 16 * I + ks]);
+        if constexpr (NB <= 2) rows.live = live_piece_mask<NB>(cany, 0.0);  // (narrow panels only: see k_gram)
+    }
     // The normalisers s_n = sum_k P_kn c_k of both candidates come from the matrix pipe as well: v_mfma_f64_4x4x4_4b
     // contracts over lane bits 4-5 (measured lane map, profiles/r2_mfma4x4_probe.txt: A lane = i + 4 b + 16 k, B lane =
     // j + 4 b + 16 k, D lane = j + 4 b + 16 i), so with the tile read a SECOND time as A(sample = lane & 15, state = 4 step +
@@ -3299,7 +3348,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                         for (int j = nm * NDMA / NM; j < (nm + 1) * NDMA / NM; ++j) {
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                             if (j < ROWS / 8)
-                                stage_piece<true>(P + rows(8 * j) * ld + tstage * TS, so.off[j & 1], cbuf + j * 1024, lane);
+                                stage_piece<true>(P + rows(8 * j) * ld + rows.cols(j, tstage * TS), so.off[j & 1], cbuf + j * 1024, lane);
                             else
                                 stage_w(tstage, cbuf);
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
@@ -4125,7 +4174,7 @@ k_solve_small(SmallArgs a) {
     char* buf = smem + wave * (DEPTH * TILE_BYTES);
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
     const int64_t W = (int64_t)G * 4;
-    const RowIdentity rows{0};
+    RowIdentity rows{0};
     const StageOffsets so = make_stage_offsets(a.ld, lane);
     const int rd_base = ks * (TS * 8);
     int pos[GROUPS];

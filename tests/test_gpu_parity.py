@@ -867,3 +867,44 @@ def test_padding_blocks_left_out_of_the_one_read_sweeps(DM, K, N, unsampled):
     assert np.array_equal(r0["history"], r1["history"]) and np.array_equal(f0, f1) and np.array_equal(w0, w1)
     f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=1e-10, min_sc_iter=0)
     np.testing.assert_allclose(f1[sws] - f1[sws[0]], (f_or - f_or[sws[0]])[sws], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("K,N,unsampled", [(5, 20000, ()), (8, 9000, (2,)), (20, 30000, ()), (24, 30000, (0, 23)), (48, 20000, tuple(range(8, 16)) + tuple(range(40, 48))),
+                                           (40, 50000, (39,)), (100, 20000, tuple(range(96, 100))), (32, 20000, tuple(range(16, 32)))])
+def test_rows_that_cannot_contribute_are_not_streamed(DM, K, N, unsampled):
+    """Aligned groups of 8 rows (2 in the few-state kernel) whose exponent constants are all -inf -- padding rows of the device
+    matrix, runs of states without samples -- are requested from the first tile's columns instead of the current tile's
+    (RowIdentity::cols: an L2 hit instead of HBM traffic).  Their terms are exactly zero either way, so nothing may change:
+    every reduced quantity against the oracle, with real (finite, different) energies in the unsampled rows, and the outputs
+    that DO depend on those rows (log numerators of unsampled states, log weights, W^T W) as well."""
+    u_kn, N_k, f = random_problem(K, N, seed=11 * K + 1, unsampled=unsampled)
+    if unsampled and 0 in unsampled:  # (random_problem moves the samples of emptied states to state 0: give them to state 1 instead)
+        N_k[1] += N_k[0]
+        N_k[0] = 0
+    sws = np.where(N_k > 0)[0]
+    rng = np.random.default_rng(K)
+    c_n = rng.integers(0, 3, size=N).astype(float)
+    with DM.from_host(u_kn) as dm:
+        check_l1(dm, u_kn, N_k, f, tag=f"K={K}")
+        np.testing.assert_allclose(-dm.lognum(f), oracle.self_consistent_update(u_kn, N_k, f), rtol=1e-11, atol=1e-10)
+        np.testing.assert_allclose(ms.mbar_log_W_nk(dm, N_k, f), oracle.mbar_log_W_nk(u_kn, N_k, f), rtol=1e-12, atol=1e-11)
+        W = oracle.mbar_W_nk(u_kn, N_k, f)
+        np.testing.assert_allclose(dm.gram_w(f)[0], W.T @ W, rtol=1e-9, atol=1e-14)
+        dm.set_sample_weights(c_n)  # (weighted sums: the oracle sees repeated columns)
+        u_rep = np.ascontiguousarray(np.repeat(u_kn, c_n.astype(int), axis=1))
+        part = oracle.shard_partials(u_rep, N_k, f, want_gram=True)
+        psum, _, gram = dm.eval(f, gram=True)
+        np.testing.assert_allclose(psum[0], part["psum"], rtol=1e-10, atol=1e-11 * N_k.max())
+        np.testing.assert_allclose(gram, part["gram"], rtol=1e-9, atol=1e-12 * N_k.max())
+        dm.set_sample_weights(None)
+        for opts in (dict(), dict(pmode=0), dict(fused=0), dict(device_loop=0)):
+            for k, v in opts.items():
+                dm.set_option(k, v)
+            fa, ra = dm.solve_adaptive(np.zeros(K), tol=1e-10, min_sc_iter=0)
+            f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=1e-10, min_sc_iter=0)
+            assert ra["success"]
+            np.testing.assert_allclose(fa[sws] - fa[sws[0]], (f_or - f_or[sws[0]])[sws], rtol=1e-8, atol=1e-8, err_msg=str(opts))
+            for k in opts:
+                dm.set_option(k, 1)
+        fs, rs = dm.solve_sci(np.zeros(K), tol=1e-9, maxiter=5000)
+        np.testing.assert_allclose(fs[sws] - fs[sws[0]], (f_or - f_or[sws[0]])[sws], atol=1e-6)
