@@ -878,9 +878,7 @@ def test_rows_that_cannot_contribute_are_not_streamed(DM, K, N, unsampled):
     every reduced quantity against the oracle, with real (finite, different) energies in the unsampled rows, and the outputs
     that DO depend on those rows (log numerators of unsampled states, log weights, W^T W) as well."""
     u_kn, N_k, f = random_problem(K, N, seed=11 * K + 1, unsampled=unsampled)
-    if unsampled and 0 in unsampled:  # (random_problem moves the samples of emptied states to state 0: give them to state 1 instead)
-        N_k[1] += N_k[0]
-        N_k[0] = 0
+    N = u_kn.shape[1]
     sws = np.where(N_k > 0)[0]
     rng = np.random.default_rng(K)
     c_n = rng.integers(0, 3, size=N).astype(float)
