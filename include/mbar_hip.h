@@ -131,6 +131,16 @@ int mbar_ctx_copy_rows(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t s
 int mbar_ctx_row_sub(mbar_ctx* ctx, int64_t row, const double* v_host);
 int mbar_ctx_rows_sub(mbar_ctx* ctx, int64_t dst_row0, int64_t src_row0, int64_t nrows, const double* v_host);
 int mbar_ctx_rows_rsub(mbar_ctx* ctx, int64_t dst_row0, int64_t src_row0, int64_t nrows);
+/* Observables into log space ON THE DEVICE (mbar.py:858-867: every observable is shifted to be positive; :886-903: its log
+ * enters the augmented log-weight matrix): rows [row0, row0 + nrows) hold raw observable values A_i[n] (uploaded with
+ * mbar_ctx_upload_rows, or copied from a resident matrix with mbar_ctx_copy_rows) and leave as log(A_i[n] - shift_i) with
+ * shift_i = min_n A_i[n] - |4 eps min_n A_i[n]| (shift_out[i]; the reference's A_min - logfactor, which the host adds back to
+ * the expectation) -- in place of three host passes over nrows x N doubles and nrows N libm logarithms.  mbar_ctx_rows_rsub then
+ * turns them into observable rows u - log A.  Single-context matrices only (the minimum is not reduced across ranks). */
+int mbar_ctx_rows_logshift(mbar_ctx* ctx, int64_t row0, int64_t nrows, double* shift_out);
+/* The same for ONE observable evaluated at many states: A[N_local] (host) is uploaded into the context's staging vector and
+ * becomes log(A - shift) there; mbar_ctx_rows_sub / mbar_ctx_row_sub with v = NULL then subtract it. */
+int mbar_ctx_vec_logshift(mbar_ctx* ctx, const double* A, double* shift_out);
 /* Free-energy-surface histograms (fes.py:1383-1402: one extra column of W per populated bin, W[n, K+i] = exp(log_w_n + f_i)
  * on the bin's samples and 0 elsewhere): rows [row0, row0 + nrows) of the augmented matrix become
  *   u[row0 + i][n] = label[n] == i ? v[n] : +inf      (v = the target potential u_n; label[n] = bin of sample n, -1 = none)

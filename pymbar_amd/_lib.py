@@ -69,6 +69,8 @@ SIGNATURES = {
     "mbar_ctx_row_sub": (C.c_int, [_ctx, C.c_int64, _dp]),
     "mbar_ctx_rows_sub": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_int64, _dp]),
     "mbar_ctx_rows_rsub": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_int64]),
+    "mbar_ctx_rows_logshift": (C.c_int, [_ctx, C.c_int64, C.c_int64, _dp]),
+    "mbar_ctx_vec_logshift": (C.c_int, [_ctx, _dp, _dp]),
     "mbar_ctx_fill_masked_rows": (C.c_int, [_ctx, C.c_int64, C.c_int64, _dp, C.POINTER(C.c_int32)]),
     "mbar_ctx_generate_harmonic": (C.c_int, [_ctx, C.c_uint64, _dp, _dp, _ip, C.c_int64]),
     "mbar_ctx_set_Nk": (C.c_int, [_ctx, _dp]),

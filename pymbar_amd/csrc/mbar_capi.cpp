@@ -2086,6 +2086,37 @@ int mbar_ctx_rows_rsub(mbar_ctx* c, int64_t dst_row0, int64_t src_row0, int64_t 
     return sync_stream(c);
 }
 
+// shared tail of the two log-shift entry points: `base` holds nrows rows of raw observable values
+static int logshift_rows(mbar_ctx* c, double* base, int64_t nrows, double* shift_host) {
+    int rc = ensure(c, &c->scratch, &c->scratch_doubles, (size_t)nrows * 257);
+    if (rc) return rc;
+    double* shift_dev = c->scratch + (size_t)nrows * 256;
+    HIPCHK(c, launch_rows_logshift(c->stream, base, c->ld, nrows, c->N, c->scratch, shift_dev));
+    HIPCHK(c, hipMemcpyAsync(shift_host, shift_dev, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return sync_stream(c);
+}
+
+int mbar_ctx_rows_logshift(mbar_ctx* c, int64_t row0, int64_t nrows, double* shift_out) {
+    if (!c || !shift_out) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > c->K) return fail(c, MBAR_ERR_ARG, "row range out of bounds");
+    if (nrows == 0) return MBAR_OK;
+    if (c->nranks > 1) return fail(c, MBAR_ERR_STATE, "mbar_ctx_rows_logshift: the minimum is taken over this context's samples only");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->u_checked = false;
+    c->P_valid = false;
+    c->last_psum.clear();
+    return logshift_rows(c, c->u + row0 * c->ld, nrows, shift_out);
+}
+
+int mbar_ctx_vec_logshift(mbar_ctx* c, const double* A_host, double* shift_out) {
+    if (!c || !A_host || !shift_out) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (c->nranks > 1) return fail(c, MBAR_ERR_STATE, "mbar_ctx_vec_logshift: the minimum is taken over this context's samples only");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->vec_tmp) HIPCHK(c, cache_malloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
+    HIPCHK(c, hipMemcpyAsync(c->vec_tmp, A_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return logshift_rows(c, c->vec_tmp, 1, shift_out);
+}
+
 int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const double* v_host, const int32_t* label_host) {
     if (!c || !v_host || !label_host) return fail(c, MBAR_ERR_ARG, "NULL argument");
     if (row0 < 0 || nrows < 0 || row0 + nrows > c->K) return fail(c, MBAR_ERR_ARG, "row range out of bounds");

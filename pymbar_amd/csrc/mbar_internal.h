@@ -89,6 +89,9 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
 hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n);  // row[i] -= v[i]
 hipError_t launch_rows_sub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, const double* v, int64_t n);
 hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n);
+// rows r < nrows of base (pitch ld, n valid entries): row <- log(row - shift_r), shift_r = min_r - |4 eps min_r| -> shift_out[r]
+// (device); part: scratch of 256 * nrows doubles
+hipError_t launch_rows_logshift(hipStream_t s, double* base, int64_t ld, int64_t nrows, int64_t n, double* part, double* shift_out);
 // rows[i][k] = label[k] == i ? v[k] : +inf,  i < nrows (row pitch ld)
 hipError_t launch_fill_masked_rows(hipStream_t s, double* rows, int64_t ld, int64_t n, int64_t nrows, const double* v,
                                    const int* label);

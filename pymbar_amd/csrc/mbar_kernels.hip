@@ -4963,6 +4963,44 @@ __global__ void __launch_bounds__(256) k_rows_rsub(double* __restrict__ dst, con
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
             dst[r * ld + i] = src[r * ld + i] - dst[r * ld + i];
 }
+// Observables into log space on the device (mbar.py:858-867 shifts every observable to be positive, :886-903 takes its log):
+//   level 1: part[r][blockIdx.x] = min over a slice of row r;
+//   level 2: shift_r = min_r - |4 eps min_r| (so that the smallest shifted value is a positive number of relative size 4 eps, or
+//            zero when the minimum is zero -- the reference's choice), row r <- log(row r - shift_r) in place, shift_r handed back.
+__global__ void __launch_bounds__(256) k_rows_min_partial(const double* __restrict__ base, int64_t ld, int64_t nrows, int64_t n,
+                                                          double* __restrict__ part) {
+    __shared__ double red[4];
+    for (int64_t r = blockIdx.y; r < nrows; r += gridDim.y) {
+        double m = INFINITY;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            m = fmin(m, base[r * ld + i]);
+        m = -block256_max(-m, red);
+        if (threadIdx.x == 0) part[r * gridDim.x + blockIdx.x] = m;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_rows_logshift(double* __restrict__ base, int64_t ld, int64_t nrows, int64_t n,
+                                                       const double* __restrict__ part, int nparts, double* __restrict__ shift_out) {
+    __shared__ double red[4];
+    for (int64_t r = blockIdx.y; r < nrows; r += gridDim.y) {
+        double m = INFINITY;
+        for (int i = threadIdx.x; i < nparts; i += blockDim.x) m = fmin(m, part[r * nparts + i]);
+        m = -block256_max(-m, red);
+        const double shift = m - fabs(8.881784197001252e-16 * m);  // 4 eps (mbar.py:827-832)
+        if (blockIdx.x == 0 && threadIdx.x == 0) shift_out[r] = shift;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            base[r * ld + i] = log(base[r * ld + i] - shift);
+        __syncthreads();
+    }
+}
+hipError_t launch_rows_logshift(hipStream_t s, double* base, int64_t ld, int64_t nrows, int64_t n, double* part, double* shift_out) {
+    const int64_t want = (n + 2047) / 2048;
+    const unsigned gx = (unsigned)(want < 256 ? (want < 1 ? 1 : want) : 256);
+    const unsigned gy = (unsigned)(nrows < 1024 ? (nrows < 1 ? 1 : nrows) : 1024);
+    hipLaunchKernelGGL(k_rows_min_partial, dim3(gx, gy), dim3(256), 0, s, base, ld, nrows, n, part);
+    hipLaunchKernelGGL(k_rows_logshift, dim3(gx, gy), dim3(256), 0, s, base, ld, nrows, n, part, (int)gx, shift_out);
+    return hipGetLastError();
+}
 hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n) {
     const int64_t want = (n + 255) / 256;
     const unsigned gx = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);

@@ -141,6 +141,23 @@ class DeviceMatrix:
         ``log A`` become observable rows ``u - log A``."""
         self._check(self._lib.mbar_ctx_rows_rsub(self._ctx, int(dst_row0), int(src_row0), int(nrows)))
 
+    def rows_logshift(self, row0, nrows):
+        """Rows ``[row0, row0 + nrows)`` hold raw observable values and become ``log(A - shift)`` in place, ``shift = min A -
+        |4 eps min A|`` per row (returned): the reference's shift-to-positive + log (mbar.py:858-867, :886-903) on the device."""
+        shift = np.empty(int(nrows), dtype=np.float64)
+        self._check(self._lib.mbar_ctx_rows_logshift(self._ctx, int(row0), int(nrows), _dptr(shift)))
+        return shift
+
+    def vec_logshift(self, A_n):
+        """One observable ``A_n`` (N_local,) into the staging vector as ``log(A - shift)``; returns ``shift``.  ``rows_sub`` /
+        ``row_sub`` with ``v_n=None`` subtract it."""
+        A_n = np.ascontiguousarray(A_n, dtype=np.float64)
+        if A_n.shape != (self.N_local,):
+            raise ValueError("A_n must have N_local entries")
+        shift = np.empty(1, dtype=np.float64)
+        self._check(self._lib.mbar_ctx_vec_logshift(self._ctx, _dptr(A_n), _dptr(shift)))
+        return float(shift[0])
+
     def fill_masked_rows(self, row0, nrows, v_n, label_n):
         """Rows ``row0 + i`` (``i < nrows``) become ``v_n`` on the samples with ``label_n == i`` and ``+inf`` (weight zero)
         elsewhere: one extra "state" per histogram bin of a free energy surface, built on the device."""

@@ -29,21 +29,32 @@ from .utils import DataError, ParameterError, kln_to_kn, kn_to_n
 
 logger = logging.getLogger(__name__)
 
-_LOGFACTOR = 4.0 * np.finfo(np.float64).eps  # pymbar/mbar.py:827-832
 
 
-def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device):
-    """Assemble ``[u_kn; u_ln[L_list]; u_ln[state_rows[s]] - log A[obs_rows[s]]]`` ON THE DEVICE, the extra rows as unsampled states
-    (N_k = 0: they do not enter the denominator).  The resident ``u_kn`` is copied device to device; a new-state row
-    that IS a resident row (``u_ln is mbar.u_kn``, the default of compute_expectations) likewise; only genuinely new
-    rows and the S vectors ``log A_n`` cross PCIe -- never the N x (K + NL + S) host array of mbar.py:886-903."""
+def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device, dedup=False):
+    """Assemble ``[u_kn; u_ln[L_list]; u_ln[state_rows[s]] - log(A[obs_rows[s]] - shift)]`` ON THE DEVICE, the extra rows as
+    unsampled states (N_k = 0: they do not enter the denominator).  The resident ``u_kn`` is copied device to device; a
+    new-state row that IS a resident row (``u_ln is mbar.u_kn``, the default of compute_expectations) likewise, and so are
+    observables that are resident rows (entropy / enthalpy: the reduced potentials themselves); only genuinely new rows and
+    the RAW observables cross PCIe -- never the N x (K + NL + S) host array of mbar.py:886-903.  The shift that makes an
+    observable positive (mbar.py:858-867: ``A - (min A - |4 eps min A|)``) and the logarithm are taken on the device
+    (``rows_logshift`` / ``vec_logshift``); returns ``(dm, N_aug, shift, col)`` with ``shift[i]`` of observable ``i`` and
+    ``col[l]`` the row that holds state ``l``.
+
+    ``dedup`` (only when the new states ARE resident rows): the copies are not made at all -- state ``l`` is row ``l`` -- and the
+    matrix has K + S rows instead of K + NL + S (compute_expectations and the entropy / enthalpy decomposition at 128 states:
+    256 rows instead of 384, which keeps the sweeps on the one-read kernels); the caller expands the Gram matrix."""
     from .device import DeviceMatrix
 
     K, N = mbar.K, mbar.N
     NL, S = len(L_list), len(state_rows)
+    resident = u_ln is mbar.u_kn
+    dedup = dedup and resident
+    if dedup:
+        NL = 0
     dm = DeviceMatrix.empty(K + NL + S, N, device=device)
     dm.copy_rows_from(mbar._dm, 0, 0, K)
-    resident = u_ln is mbar.u_kn
+    shift = np.zeros(len(A_n) if S > 0 else 0, dtype=np.float64)
 
     def runs(pairs):
         """(dst, src) row pairs -> maximal (dst0, src0, n) runs with both indices consecutive: one device call per run."""
@@ -55,37 +66,40 @@ def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device):
                 out.append([d, s_, 1])
         return out
 
-    if resident:
-        for d0, s0, n in runs([(K + j, int(l)) for j, l in enumerate(L_list)]):
-            dm.copy_rows_from(mbar._dm, d0, s0, n)
+    if dedup:
+        col = {int(l): int(l) for l in L_list}
     else:
-        for j, l in enumerate(L_list):
-            dm.upload_rows(K + j, u_ln[int(l)][np.newaxis, :])
-    col = {int(l): K + j for j, l in enumerate(L_list)}
+        if resident:
+            for d0, s0, n in runs([(K + j, int(l)) for j, l in enumerate(L_list)]):
+                dm.copy_rows_from(mbar._dm, d0, s0, n)
+        else:
+            for j, l in enumerate(L_list):
+                dm.upload_rows(K + j, u_ln[int(l)][np.newaxis, :])
+        col = {int(l): K + j for j, l in enumerate(L_list)}
     uniq = np.unique(obs_rows) if S > 0 else []
     if len(uniq) > 2 and len(uniq) * 2 > S:
-        # mostly DIFFERENT observables (entropy / enthalpy: the K reduced potentials, each at its own state): their log A rows
-        # go up in ONE transfer, straight into the observable rows, and become u - log A in one launch per run of rows
-        log_A = A_n[np.asarray(obs_rows, dtype=int)]  # (a gather: already a private array)
-        with np.errstate(divide="ignore"):
-            np.log(log_A, out=log_A)
-        dm.upload_rows(K + NL, log_A)
-        del log_A
+        # mostly DIFFERENT observables (entropy / enthalpy: the K reduced potentials, each at its own state): the raw rows go
+        # into the observable rows (device to device when they are rows of the resident matrix, one transfer per run of
+        # consecutive observables otherwise), become log(A - shift) there and then u - log(A - shift), one launch per run
+        for d0, o0, n in runs([(K + NL + s, int(obs_rows[s])) for s in range(S)]):
+            if A_n is mbar.u_kn:
+                dm.copy_rows_from(mbar._dm, d0, o0, n)
+            else:
+                dm.upload_rows(d0, A_n[o0:o0 + n])
+        shift_rows = dm.rows_logshift(K + NL, S)
+        shift[np.asarray(obs_rows, dtype=int)] = shift_rows
         for d0, s0, n in runs([(K + NL + s, col[int(state_rows[s])]) for s in range(S)]):
             dm.rows_rsub(d0, s0, n)
         uniq = []
-    for i in uniq:  # one upload of log A_i, subtracted at every state it is evaluated at
-        with np.errstate(divide="ignore"):
-            log_A = np.log(A_n[int(i)])
-        first = True
-        # observable rows = state rows - log A_i, written in one pass per run of consecutive rows (no copy + subtract pair)
+    for i in uniq:  # one upload of A_i; its log, shifted, is subtracted at every state it is evaluated at
+        shift[int(i)] = dm.vec_logshift(A_n[int(i)])
+        # observable rows = state rows - log(A_i - shift), written in one pass per run of consecutive rows
         for d0, s0, n in runs([(K + NL + s, col[int(state_rows[s])]) for s in range(S) if int(obs_rows[s]) == int(i)]):
-            dm.rows_sub(d0, s0, n, log_A if first else None)
-            first = False
+            dm.rows_sub(d0, s0, n, None)
     N_aug = np.zeros(K + NL + S, dtype=np.float64)
     N_aug[:K] = mbar.N_k
     dm.set_Nk(N_aug)
-    return dm, N_aug
+    return dm, N_aug, shift, col
 
 
 def _augmented_solve(dm, K, R, f_k):
@@ -114,22 +128,17 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
     u_ln = np.asarray(u_ln, dtype=np.float64)
     if u_ln.ndim == 1:
         u_ln = u_ln.reshape(1, -1)
-    A_n = np.array(A_n, dtype=np.float64)  # private copy: shifted below
+    A_n = np.asarray(A_n, dtype=np.float64)  # (never modified: the shift to positive values and the log are taken on the device)
     if A_n.ndim == 1:
         A_n = A_n.reshape(1, -1)
     K, N = mbar.K, mbar.N
     L_list = np.unique(state_list)
     NL = len(L_list)
-    col_of_state = {int(l): j for j, l in enumerate(L_list)}  # column K + j of the augmented matrix
-
-    # observables are made strictly positive so that they can live in log space (mbar.py:858-867)
-    A_used = np.unique(obs_list) if S > 0 else np.zeros(0, dtype=int)
-    A_min = np.zeros(len(A_n)) if S > 0 else np.zeros(0)
-    logfactors = np.zeros(len(A_n)) if S > 0 else np.zeros(0)
-    for i in A_used:
-        A_min[i] = np.min(A_n[i, :])
-        logfactors[i] = np.abs(_LOGFACTOR * A_min[i])
-        A_n[i, :] = A_n[i, :] - (A_min[i] - logfactors[i])
+    col_of_state = {int(l): j for j, l in enumerate(L_list)}  # column K + j of the reference's augmented matrix (:886-903)
+    # New states that ARE resident rows (the default of compute_expectations, the entropy / enthalpy decomposition) are not
+    # duplicated on the device: W_l = W_k exp(f_l - f_k) column for column, so the Gram matrix of the reference's
+    # (K + NL + S)-column layout is the (K + S)-row one with rows / columns repeated and scaled.  ("svd" needs W itself.)
+    dedup = u_ln is mbar.u_kn and uncertainty_method != "svd"
 
     result_vals = dict()
     bootstrap = uncertainty_method == "bootstrap"
@@ -140,8 +149,12 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
     Theta_ij = None
     # The augmented matrix goes to the device once.  A bootstrap replicate (mbar.py:905-912 gathers
     # u_kn[:, bootstrap_rints[n]]) is the same matrix with per-sample multiplicities = draw counts.
-    dm, N_aug = _augmented_matrix(mbar, u_ln, L_list, state_list[:S] if S > 0 else [], A_n, obs_list,
-                                  getattr(mbar, "_device", None))
+    # (observables are made strictly positive so that they can live in log space, mbar.py:858-867: shift[i] is the reference's
+    # A_min[i] - logfactors[i], found on the device)
+    dm, N_dm, shift, row_of_state = _augmented_matrix(mbar, u_ln, L_list, state_list[:S] if S > 0 else [], A_n, obs_list,
+                                                      getattr(mbar, "_device", None), dedup=dedup)
+    R_dm = len(N_dm) - K      # extra rows on the device: S when the state rows are not duplicated, NL + S otherwise
+    obs_row0 = len(N_dm) - S  # first observable row
     try:
         for n in range(n_total):
             if n == 0:
@@ -149,21 +162,32 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
             else:
                 f_k = mbar.f_k_boots[n - 1, :]
                 dm.set_sample_weights(np.bincount(mbar.bootstrap_rints[n - 1], minlength=N))
-            f_full, lognum = _augmented_solve(dm, K, NL + S, f_k)
-            f_states = np.array([f_full[K + col_of_state[int(l)]] for l in state_list])
-            A_i = np.array([np.exp(lognum[K + NL + s] - lognum[K + col_of_state[int(state_list[s])]]) for s in range(S)])
+            f_full, lognum = _augmented_solve(dm, K, R_dm, f_k)
+            f_states = np.array([-lognum[row_of_state[int(l)]] for l in state_list])
+            A_i = np.array([np.exp(lognum[obs_row0 + s] - lognum[row_of_state[int(state_list[s])]]) for s in range(S)])
             if n == 0:
                 if S > 0:
-                    result_vals["observables"] = A_i + (A_min[obs_list] - logfactors[obs_list])
+                    result_vals["observables"] = A_i + shift[obs_list]
                 if return_theta:
                     # (the column sums go along: like the reference's check_w_normalized on the augmented W, weights that
                     # do not sum to one raise instead of silently producing a Theta)
                     G, wsum = dm.gram_w(f_full)
-                    Theta_ij = mbar._theta_from_gram(G, N_aug.astype(np.int64), uncertainty_method, wsum=wsum, dm=dm,
-                                                     f_full=f_full)
+                    if dedup:
+                        # the reference's layout [K sampled | NL state copies | S observables] from the rows on the device:
+                        # copy l is row l scaled by exp(f_l - f_k[l]), f_l = -lognum[l] its normaliser as an unsampled state
+                        src = np.concatenate((np.arange(K), L_list.astype(int), K + np.arange(S))).astype(int)
+                        scale = np.concatenate((np.ones(K), np.exp(-lognum[L_list.astype(int)] - f_k[L_list.astype(int)]), np.ones(S)))
+                        G = (scale[:, None] * G[np.ix_(src, src)]) * scale[None, :]
+                        wsum = scale * wsum[src]
+                        N_full = np.zeros(K + NL + S, dtype=np.int64)
+                        N_full[:K] = mbar.N_k
+                        Theta_ij = mbar._theta_from_gram(G, N_full, uncertainty_method, wsum=wsum)
+                    else:
+                        Theta_ij = mbar._theta_from_gram(G, N_dm.astype(np.int64), uncertainty_method, wsum=wsum, dm=dm,
+                                                         f_full=f_full)
                 result_vals["f"] = f_states
             else:
-                A_i_bootstrap[n - 1, :] = A_i + (A_min[obs_list] - logfactors[obs_list]) if S > 0 else 0.0
+                A_i_bootstrap[n - 1, :] = A_i + shift[obs_list] if S > 0 else 0.0
                 f_bootstrap[n - 1, :] = f_states
     finally:
         dm.close()
@@ -176,7 +200,7 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
         idx = np.concatenate((si, li)).astype(int)
         result_vals["Theta"] = Theta_ij[np.ix_(idx, idx)]
         if S > 0:
-            result_vals["Amin"] = A_min[obs_list] - logfactors[obs_list]
+            result_vals["Amin"] = shift[obs_list]
     return result_vals
 
 

@@ -63,6 +63,22 @@ class OracleMatrix:
     def rows_rsub(self, dst_row0, src_row0, nrows):
         self.u[dst_row0:dst_row0 + nrows] = self.u[src_row0:src_row0 + nrows] - self.u[dst_row0:dst_row0 + nrows]
 
+    def rows_logshift(self, row0, nrows):
+        rows = self.u[row0:row0 + nrows]
+        amin = rows.min(axis=1)
+        shift = amin - np.abs(4.0 * np.finfo(np.float64).eps * amin)
+        with np.errstate(divide="ignore"):
+            rows[...] = np.log(rows - shift[:, None])
+        return shift
+
+    def vec_logshift(self, A_n):
+        A_n = np.asarray(A_n, dtype=np.float64)
+        amin = A_n.min()
+        shift = amin - np.abs(4.0 * np.finfo(np.float64).eps * amin)
+        with np.errstate(divide="ignore"):
+            self._last_v = np.log(A_n - shift)
+        return float(shift)
+
     def fill_masked_rows(self, row0, nrows, v_n, label_n):
         v_n = np.asarray(v_n, dtype=np.float64)
         label_n = np.asarray(label_n)

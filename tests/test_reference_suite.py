@@ -41,9 +41,10 @@ def test_reference_tests_pass_on_the_drop_in(test_file, min_passed):
         # 8 threads, for trust-exact -- 9744 iterations' worth of warnings -- and once to the limit at 1 thread).  The
         # reference's own numpy path behaves the same.  All four are covered from a cold start by
         # tests/test_host_logic.py::test_every_method_reaches_reference_solution and the GPU parity tests ("every method").
-        for method in ("dogleg", "trust-exact", "trust-ncg", "trust-krylov"):
-            cmd += ["--deselect", os.path.join(REF, "pymbar", "tests", test_file) + f"::test_protocols[{method}]"]
-            min_passed -= 1
+        # (by keyword: with --rootdir=/tmp the node ids of a file outside the rootdir carry no path, and a --deselect by path
+        # silently matches nothing)
+        cmd += ["-k", "not (test_protocols and (dogleg or trust))"]
+        min_passed -= 4
     out = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=1500)  # a timeout here FAILS
     tail = out.stdout[-3000:]
     assert out.returncode == 0, tail + out.stderr[-2000:]
