@@ -86,9 +86,19 @@ def initialize_with_bar(u_kn, N_k, x_kindices, f_k_init=None):
     K = len(N_k)
     order = np.where(N_k > 0)[0]
     f_k_init = np.zeros(K) if f_k_init is None else np.array(f_k_init, dtype=np.float64)
+    # the samples of every state, grouped once (the reference builds a boolean mask over all N samples per pair, :1958-1967)
+    x = np.asarray(x_kindices)
+    sorted_already = x.size == 0 or bool(np.all(x[:-1] <= x[1:]))
+    counts = np.bincount(x, minlength=K)[:K] if x.size else np.zeros(K, dtype=np.int64)
+    offs = np.concatenate(([0], np.cumsum(counts)))
+    by_state = None if sorted_already else np.argsort(x, kind="stable")
+
+    def samples_of(k):  # a slice (a view of the row) in the default layout, an index array otherwise
+        return slice(int(offs[k]), int(offs[k + 1])) if sorted_already else by_state[offs[k]:offs[k + 1]]
+
     for k, l in zip(order[:-1], order[1:]):
-        from_k = x_kindices == k
-        from_l = x_kindices == l
+        from_k = samples_of(k)
+        from_l = samples_of(l)
         w_F = u_kn[l, from_k] - u_kn[k, from_k]
         w_R = u_kn[k, from_l] - u_kn[l, from_l]
         if len(w_F) > 0 and len(w_R) > 0:

@@ -2200,27 +2200,29 @@ int mbar_ctx_set_Nk(mbar_ctx* c, const double* N_k) {
 int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
     if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<double> w((size_t)c->N, 1.0);
     bool weighted = false;
-    if (c_n) {
+    if (c_n) {  // (validated in place: no host copy of the vector; a draw-count vector of a 1e8-sample matrix is 0.8 GB)
+        bool bad = false;
         for (int64_t n = 0; n < c->N; ++n) {
-            if (!(c_n[n] >= 0.0) || !std::isfinite(c_n[n])) return fail(c, MBAR_ERR_ARG, "sample weights must be finite and >= 0");
-            w[n] = c_n[n];
-            if (c_n[n] != 1.0) weighted = true;
+            bad |= !(c_n[n] >= 0.0) || !(c_n[n] <= 1.7976931348623157e308);
+            weighted |= c_n[n] != 1.0;
         }
+        if (bad) return fail(c, MBAR_ERR_ARG, "sample weights must be finite and >= 0");
     }
     if (weighted && !c->lden_eff) {
         HIPCHK(c, cache_malloc((void**)&c->lden_eff, (size_t)c->ld * sizeof(double)));
         HIPCHK(c, hipMemsetAsync(c->lden_eff, 0, (size_t)c->ld * sizeof(double), c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->cw, w.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (weighted)
+        HIPCHK(c, hipMemcpyAsync(c->cw, c_n, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    else
+        HIPCHK(c, launch_fill(c->stream, c->cw, 1.0, c->N));  // (the padding behind N stays 0)
     if (weighted) {  // sqrt(c_n) for the MFMA operands of the fused sweep (plain 0 / 1 weights are their own square roots)
         if (!c->cwsq) {
             HIPCHK(c, cache_malloc((void**)&c->cwsq, (size_t)c->ld * sizeof(double)));
             HIPCHK(c, hipMemsetAsync(c->cwsq, 0, (size_t)c->ld * sizeof(double), c->stream));
         }
-        for (int64_t n = 0; n < c->N; ++n) w[n] = std::sqrt(w[n]);
-        HIPCHK(c, hipMemcpyAsync(c->cwsq, w.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_sqrt_vec(c->stream, c->cwsq, c->cw, c->N));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->weighted = weighted;

@@ -242,6 +242,7 @@ hipError_t launch_build_gram(hipStream_t s, int nb, const LaunchGeom& g, const d
 hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
                          const double* logden, double* P);
 hipError_t launch_fill(hipStream_t s, double* v, double value, int64_t n);
+hipError_t launch_sqrt_vec(hipStream_t s, double* dst, const double* src, int64_t n);  // dst[i] = sqrt(src[i])
 hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,
                                 const LoopCtl& lc = LoopCtl());
 // K x K Newton system (gauge-fixed, Gauss-Jordan in registers, one workgroup) + both candidates + sweep inputs

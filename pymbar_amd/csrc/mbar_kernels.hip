@@ -2051,6 +2051,10 @@ k_make_p(const double* __restrict__ u, int64_t ld, int64_t N, int64_t rows, cons
 __global__ void __launch_bounds__(256) k_fill(double* __restrict__ v, double value, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = value;
 }
+// dst = sqrt(src): the roots of the sample multiplicities for the matrix-core operands of the weighted sweeps
+__global__ void __launch_bounds__(256) k_sqrt_vec(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = sqrt(src[i]);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Gram pass, paired-wave variant for a full 128-state panel (NB = 8: 36 upper-triangular blocks =
@@ -5326,6 +5330,12 @@ hipError_t launch_fill(hipStream_t s, double* v, double value, int64_t n) {
     int64_t bx = (n + 255) / 256;
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(k_fill, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, v, value, n);
+    return hipGetLastError();
+}
+hipError_t launch_sqrt_vec(hipStream_t s, double* dst, const double* src, int64_t n) {
+    int64_t bx = (n + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_sqrt_vec, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, dst, src, n);
     return hipGetLastError();
 }
 hipError_t launch_fused(hipStream_t s, int nb, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, const double* cmul,

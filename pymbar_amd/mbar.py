@@ -80,6 +80,35 @@ def _small_blas(K):
 _BLAS_CONTROLLER = None
 
 
+def _private_copy(src):
+    """``np.array(src)`` of a float64 C-contiguous matrix; from 64 MB on the rows are copied by several threads (numpy releases
+    the GIL in ``copyto``): a fresh 4 GB array is bound by the first touch of its pages on one thread (13 GB/s on the GPU box's
+    host), which several threads take in parallel."""
+    if src.nbytes < (64 << 20) or src.ndim != 2 or src.shape[0] < 2:
+        return np.array(src, dtype=np.float64)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    nt = max(1, min(16, src.shape[0], (os.cpu_count() or 1)))
+    out = np.empty_like(src)
+    bounds = np.linspace(0, src.shape[0], nt + 1).astype(int)
+    with ThreadPoolExecutor(nt) as ex:
+        list(ex.map(lambda i: np.copyto(out[bounds[i]:bounds[i + 1]], src[bounds[i]:bounds[i + 1]]), range(nt)))
+    return out
+
+
+def _sample_groups(x_kindices, K):
+    """``[np.where(x_kindices == k)[0] for k in range(K)]`` in one pass: slices of a stable argsort, or plain ``range`` objects when
+    the samples are already ordered by state (the default layout: no index arrays at all)."""
+    x = np.asarray(x_kindices)
+    counts = np.bincount(x, minlength=K)[:K] if x.size else np.zeros(K, dtype=np.int64)
+    offs = np.concatenate(([0], np.cumsum(counts)))
+    if x.size == 0 or np.all(x[:-1] <= x[1:]):
+        return [range(int(offs[k]), int(offs[k + 1])) for k in range(K)]
+    order = np.argsort(x, kind="stable")
+    return [order[offs[k]:offs[k + 1]] for k in range(K)]
+
+
 class MBAR:
     """Multistate Bennett acceptance ratio estimator; free energies are solved on construction.
 
@@ -104,7 +133,7 @@ class MBAR:
         src = np.ascontiguousarray(u_kn, dtype=np.float64)   # (a conversion already yields a private array)
         shared = src is u_kn or src.base is not None
         if copy and shared:
-            self.u_kn = np.array(src, dtype=np.float64)
+            self.u_kn = _private_copy(src)
         elif shared:
             self.u_kn = src.view()
             self.u_kn.setflags(write=False)
@@ -181,11 +210,20 @@ class MBAR:
             self.n_bootstraps = n_bootstraps
             self.f_k_boots = np.zeros([n_bootstraps, K])
             self.bootstrap_rints = np.zeros([n_bootstraps, self.N], int)
+            # the samples of every state, ascending (what np.where(x_kindices == k)[0] yields in the reference's loop,
+            # mbar.py:425-431, found there K times per replicate: O(K N) each): grouped ONCE; the random stream -- one
+            # rng.integers(N_k, size=N_k) per state and replicate, in state order -- is the reference's
+            groups = _sample_groups(self.x_kindices, K)
             for b in range(n_bootstraps):
                 rints = np.zeros(self.N, int)
                 for k in range(K):
-                    k_indices = np.where(self.x_kindices == k)[0]
-                    rints[k_indices] = k_indices[self.rng.integers(int(self.N_k[k]), size=int(self.N_k[k]))]
+                    k_indices = groups[k]
+                    draw = self.rng.integers(int(self.N_k[k]), size=int(self.N_k[k]))
+                    if isinstance(k_indices, range):  # default layout: the samples of state k are one contiguous run
+                        rints[k_indices.start:k_indices.stop] = draw
+                        rints[k_indices.start:k_indices.stop] += k_indices.start
+                    else:
+                        rints[k_indices] = k_indices[draw]
                 # a replicate is the vector of draw counts: the resident matrix is re-used, nothing is gathered
                 self._dm.set_sample_weights(np.bincount(rints, minlength=self.N))
                 f_k_init = self.f_k.copy()

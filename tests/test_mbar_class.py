@@ -94,6 +94,40 @@ def test_bootstrap_is_deterministic_under_rseed():
     assert np.all(np.abs(r["dDelta_f"] - ra["dDelta_f"]) < 0.2)
 
 
+def test_bootstrap_draws_are_the_references(golden):
+    """The replicate indices come out of the reference's loop (mbar.py:425-431: per state, np.where over all samples, one
+    rng.integers(N_k, size=N_k)) -- here with the samples of every state grouped ONCE; same random stream, same indices, for the
+    default layout (contiguous runs) and for samples interleaved through x_kindices; and the threaded private copy of a large
+    matrix is a faithful copy."""
+    from pymbar_amd.mbar import _private_copy, _sample_groups
+
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn([0.0, 1.0, 2.0, 3.0], [1.0, 2.0, 4.0, 3.0], [60, 0, 50, 40], seed=4)
+    N = int(np.sum(N_k))
+
+    def reference_draws(x_kindices, rseed, n_bootstraps):
+        rng = np.random.default_rng(rseed)
+        rng.choice(np.arange(N), min(50, N))  # (the same-state probe of the constructor draws first: mbar.py:273-279)
+        out = np.zeros([n_bootstraps, N], int)
+        for b in range(n_bootstraps):
+            for k in range(len(N_k)):
+                k_indices = np.where(x_kindices == k)[0]
+                out[b, k_indices] = k_indices[rng.integers(int(N_k[k]), size=int(N_k[k]))]
+        return out
+
+    default = np.repeat(np.arange(len(N_k)), N_k)
+    m = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=3, rseed=7)
+    assert np.array_equal(m.bootstrap_rints, reference_draws(default, 7, 3))
+    perm = np.random.default_rng(0).permutation(N)  # the same samples in another order, labelled by x_kindices
+    m2 = pymbar_amd.MBAR(u_kn[:, perm], N_k, n_bootstraps=3, rseed=7, x_kindices=default[perm])
+    assert np.array_equal(m2.bootstrap_rints, reference_draws(default[perm], 7, 3))
+    for x in (default, default[perm], np.zeros(0, dtype=int)):
+        groups = _sample_groups(x, len(N_k))
+        for k in range(len(N_k)):
+            assert np.array_equal(np.asarray(groups[k], dtype=int), np.where(x == k)[0])
+    big = np.random.default_rng(1).random((37, 250_000))  # 74 MB: the threaded path
+    assert np.array_equal(_private_copy(big), big) and _private_copy(big) is not big
+
+
 def test_initialize_bar_and_unnormalized_log_weights(golden):
     """initialize="BAR" feeds the solver the chained pairwise guess (tests/golden/bar_init.npz holds the reference's
     values); _computeUnnormalizedLogWeights is the reference's one-line logsumexp (mbar.py:1919-1934)."""
