@@ -33,6 +33,13 @@ def bar_zero(w_F, w_R, DeltaF):
     w_F = np.asarray(w_F, dtype=np.float64)
     w_R = np.asarray(w_R, dtype=np.float64)
     M = np.log(float(w_F.size) / float(w_R.size))
+    # fast path: the Fermi functions summed directly (one exponential per work value; e^x = inf gives f = 0); only when a sum
+    # underflows to zero -- no overlap at all at this DeltaF -- the log-space form below is needed
+    with np.errstate(over="ignore"):
+        s_F = np.sum(1.0 / (1.0 + np.exp(M + w_F - DeltaF)))
+        s_R = np.sum(1.0 / (1.0 + np.exp(-(M - w_R - DeltaF))))
+    if s_F > 0.0 and s_R > 0.0 and np.isfinite(s_F) and np.isfinite(s_R):
+        return np.log(s_F) - np.log(s_R)
     log_f_F = -np.logaddexp(0.0, M + w_F - DeltaF)
     log_f_R = -np.logaddexp(0.0, -(M - w_R - DeltaF))
     return logsumexp(log_f_F) - logsumexp(log_f_R)
