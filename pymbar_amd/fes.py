@@ -48,17 +48,35 @@ def label_samples(x_n, bin_edges):
     dims = len(bin_edges)
     if x_n.shape[1] != dims:
         raise DataError("x_n and bin_edges have inconsistent dimension")
-    bin_n = np.stack([np.digitize(x_n[:, d], bin_edges[d]) - 1 for d in range(dims)], axis=1)
-    sample_label = np.zeros(len(x_n), dtype=np.int64)
-    order, grid = {}, []
-    for n in range(len(x_n)):
-        key = tuple(int(v) for v in bin_n[n])
-        if min(key) < 0:
-            key = None  # every off-grid-to-the-left sample shares the reference's label -1
-        if key not in order:
-            order[key] = len(grid)
-            grid.append(key)
-        sample_label[n] = order[key]
+    N = len(x_n)
+    if N == 0:
+        return np.zeros(0, dtype=np.int64), []
+    bin_n = [np.digitize(x_n[:, d], bin_edges[d]) - 1 for d in range(dims)]  # each in -1 .. len(edges) - 1
+    sizes = tuple(len(bin_edges[d]) + 1 for d in range(dims))
+    # one integer per grid cell (0 = "off the grid to the left in some dimension": all such samples share the reference's
+    # label -1), then the populated cells numbered in order of first appearance -- without a Python loop over the samples
+    flat = np.ravel_multi_index(tuple(b + 1 for b in bin_n), sizes) + 1
+    left = np.zeros(N, dtype=bool)
+    for b in bin_n:
+        left |= b < 0
+    flat[left] = 0
+    P = int(np.prod(sizes, dtype=np.float64)) + 1
+    if P <= 50_000_000:
+        first = np.full(P, N, dtype=np.int64)
+        first[flat[::-1]] = np.arange(N - 1, -1, -1)  # (duplicates: the last write wins, so the smallest n is kept)
+        cells = np.nonzero(first < N)[0]
+        cells = cells[np.argsort(first[cells], kind="stable")]
+        rank = np.zeros(P, dtype=np.int64)
+        rank[cells] = np.arange(len(cells))
+        sample_label = rank[flat]
+    else:  # a grid with more cells than that: sort the samples' cells instead of tabulating the grid
+        cells, first, inv = np.unique(flat, return_index=True, return_inverse=True)
+        by_first = np.argsort(first, kind="stable")
+        rank = np.empty(len(cells), dtype=np.int64)
+        rank[by_first] = np.arange(len(cells))
+        sample_label = rank[inv]
+        cells = cells[by_first]
+    grid = [None if c == 0 else tuple(int(v) - 1 for v in np.unravel_index(int(c) - 1, sizes)) for c in cells]
     return sample_label, grid
 
 
