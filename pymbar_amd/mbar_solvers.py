@@ -77,8 +77,8 @@ class _ResidentCache:
     which calls this module several times with the same ``self.u_kn`` (mbar.py:413 ``solve_mbar_for_all_states``, :455
     ``mbar_log_W_nk``, :910 again per expectation) -- uploads the matrix ONCE instead of once per call.
 
-    A host array is recognised by (address, shape, strides) AND a digest of 4096 elements spread evenly over it plus its first
-    and last row: the array object may have been freed and another one allocated at the same address, or modified in place
+    A host array is recognised by (address, shape, strides) AND a digest of 4096 elements spread evenly over it plus 4096
+    spread over its first and over its last row: the array object may have been freed and another one allocated at the same address, or modified in place
     (``u_kn -= shift`` changes every sampled element; a caller who pokes single elements into a matrix between two calls of this
     module is not detected and must call :func:`drop_resident_cache` -- the reference's ``MBAR`` never writes to its copy).
     Bounded: ``PYMBAR_AMD_RESIDENT_CACHE`` entries (default 2; 0 switches the cache off) and
@@ -102,10 +102,11 @@ class _ResidentCache:
 
         flat = a.reshape(-1)  # (a view: the array is C-contiguous)
         idx = np.linspace(0, flat.size - 1, min(flat.size, 4096)).astype(np.int64)
+        cols = np.linspace(0, a.shape[1] - 1, min(a.shape[1], 4096)).astype(np.int64)
         h = hashlib.blake2b(digest_size=16)
         h.update(flat[idx].tobytes())
-        h.update(a[0].tobytes())
-        h.update(a[-1].tobytes())
+        h.update(a[0, cols].tobytes())   # (bounded: hashing two whole rows of a 1e7-sample matrix took 0.16 s per call)
+        h.update(a[-1, cols].tobytes())
         return (a.ctypes.data, a.shape, a.strides, h.digest())
 
     def get(self, u_kn):
