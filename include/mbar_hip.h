@@ -66,8 +66,9 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local);
 void mbar_ctx_destroy(mbar_ctx* ctx);
 int mbar_ctx_synchronize(mbar_ctx* ctx);
 /* Device and pinned-host blocks freed by contexts are kept for re-use (hipMalloc / hipFree cost more than a sweep at the
- * sizes pymbar is typically run at); bounded by MBAR_CACHE_MB (environment, default 2048; 0 = off).  This returns every
- * parked block to the driver. */
+ * sizes pymbar is typically run at, and 0.3-0.7 s for the 6-8 GB augmented matrix of an expectation call at K=128, N=4e6);
+ * bounded by MBAR_CACHE_MB (environment; default a quarter of the device's memory; 0 = off); an allocation that fails empties
+ * the cache and is tried again.  This returns every parked block to the driver. */
 int mbar_cache_trim(void);
 /* hipDeviceSynchronize on `device` (every stream of every context): the bracket of a timed region. */
 int mbar_device_synchronize(int device);

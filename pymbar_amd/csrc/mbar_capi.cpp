@@ -67,9 +67,12 @@ RcclApi g_rccl;
 // hipMalloc / hipFree / hipHostMalloc cost 0.1 - 1 ms each (hipFree also synchronises the device): a context makes ~15
 // allocations, and pymbar's real workloads (K ~ 40, N ~ 1e5: sweeps of ~10 us) build and drop contexts all the time -- the
 // MBAR object, one augmented matrix per expectation call, one temporary per module-level function call.  Freed blocks are
-// therefore kept (per device, bounded: MBAR_CACHE_MB, default 2048 MB of device memory and 64 MB of pinned host memory;
-// bigger blocks go straight back to the driver) and handed out again to requests of about the same size.  Every API
-// call of this library leaves its stream idle before it frees anything, so a cached block has no work in flight.
+// therefore kept (per device, bounded: MBAR_CACHE_MB, default a quarter of the device's memory -- 72 GB of 288 -- and 64 MB of
+// pinned host memory; blocks of more than half the bound go straight back to the driver) and handed out again to requests of
+// about the same size.  (The bound used to be 2 GB: the augmented matrix of an expectation call at K=128, N=4e6 is 6-8 GB, and
+// its hipMalloc / hipFree pair cost 0.3-0.7 s per call against 15-45 ms of work.)  An allocation that fails empties the cache
+// and is tried again, and mbar_cache_trim() hands everything back.  Every API call of this library leaves its stream idle
+// before it frees anything, so a cached block has no work in flight.
 struct MemCache {
     struct Pool {
         std::multimap<size_t, void*> free_blocks;
@@ -83,12 +86,23 @@ struct MemCache {
     void configure() {
         if (configured) return;
         configured = true;
-        size_t mb = 2048;
-        if (const char* e = std::getenv("MBAR_CACHE_MB")) mb = (size_t)std::strtoull(e, nullptr, 10);
-        dev_limit = mb << 20;
-        pinned.limit = std::min<size_t>(dev_limit, (size_t)64 << 20);
+        if (const char* e = std::getenv("MBAR_CACHE_MB")) {
+            dev_limit = (size_t)std::strtoull(e, nullptr, 10) << 20;
+            limit_from_env = true;
+        }
+        pinned.limit = limit_from_env ? std::min<size_t>(dev_limit, (size_t)64 << 20) : (size_t)64 << 20;
     }
-    size_t dev_limit = 0;
+    size_t dev_limit = (size_t)2048 << 20;
+    bool limit_from_env = false;
+    size_t device_limit() const {  // (called with the device current)
+        if (limit_from_env) return dev_limit;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            return dev_limit;
+        }
+        return std::max(dev_limit, total_b / 4);
+    }
     static size_t round_up(size_t b) { return (b + 4095) / 4096 * 4096; }
     static void* take(Pool& p, size_t want) {
         auto it = p.free_blocks.lower_bound(want);
@@ -108,7 +122,7 @@ struct MemCache {
             if (e != hipSuccess) return e;
         }
         Pool& p = host ? pinned : dev[d];
-        if (!host) p.limit = dev_limit;
+        if (!host && p.limit == 0) p.limit = device_limit();
         size_t got = want;
         void* q = take(p, want);
         if (q) {
