@@ -204,6 +204,9 @@ int mbar_logden(mbar_ctx* ctx, const double* f, double* out_n);
 /* log W_nk = f_k - u_kn - logden_n written as out[k][n] with row pitch ld_out (this rank's
  * shard).  Memory-identical to the reference's F-ordered (N, K) result (mbar_solvers.py:439-449). */
 int mbar_logw(mbar_ctx* ctx, const double* f, double* out_kn, int64_t ld_out);
+/* The weights themselves, W_kn = exp(log W_kn) (mbar_solvers.py:476-486 `mbar_W_nk`: exp of the log weights, taken on the host
+ * there -- 1 s of single-threaded numpy for config 3's 1.28e9 entries), same layout as mbar_logw. */
+int mbar_w(mbar_ctx* ctx, const double* f, double* out_kn, int64_t ld_out);
 /* gramW[K][K] = sum_n W_ni W_nj and wsum[k] = sum_n W_nk for ALL states (W^T W of
  * mbar.py:1816,1849 and compute_overlap mbar.py:606); fp64 MFMA. */
 int mbar_gram_w(mbar_ctx* ctx, const double* f, double* gramW, double* wsum);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "mbar_lognum": (C.c_int, [_ctx, _dp, _dp]),
     "mbar_logden": (C.c_int, [_ctx, _dp, _dp]),
     "mbar_logw": (C.c_int, [_ctx, _dp, _dp, C.c_int64]),
+    "mbar_w": (C.c_int, [_ctx, _dp, _dp, C.c_int64]),
     "mbar_gram_w": (C.c_int, [_ctx, _dp, _dp, _dp]),
     "mbar_solve_adaptive": (C.c_int, [_ctx, _dp, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_int,
                                       _dp, C.c_int64, C.POINTER(SolveResult)]),

@@ -2449,7 +2449,10 @@ int mbar_lognum(mbar_ctx* c, const double* f, double* lognum) {
     return MBAR_OK;
 }
 
-int mbar_logw(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out) {
+static int logw_impl(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out, bool exponentiate);
+int mbar_logw(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out) { return logw_impl(c, f, out_kn, ld_out, false); }
+int mbar_w(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out) { return logw_impl(c, f, out_kn, ld_out, true); }
+static int logw_impl(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out, bool exponentiate) {
     if (!c || !f || !out_kn || ld_out < c->N) return fail(c, MBAR_ERR_ARG, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = eval_core(c, f, 1, 0, c->logden[0], nullptr, nullptr, nullptr, nullptr);
@@ -2467,7 +2470,7 @@ int mbar_logw(mbar_ctx* c, const double* f, double* out_kn, int64_t ld_out) {
         const int64_t nr = std::min(rows_per, c->K - k0);
         {
             ScopedTimer t(c, MBAR_TIMER_OTHER);
-            hipError_t e = launch_logw(c->stream, c->u + k0 * c->ld, c->ld, c->N, nr, d_f(c) + k0, c->logden[0], stage, c->ld);
+            hipError_t e = launch_logw(c->stream, c->u + k0 * c->ld, c->ld, c->N, nr, d_f(c) + k0, c->logden[0], stage, c->ld, exponentiate);
             if (e != hipSuccess) { (void)cache_free(stage); return fail(c, MBAR_ERR_HIP, hipGetErrorString(e)); }
         }
         hipError_t e = hipMemcpy2DAsync(out_kn + k0 * ld_out, (size_t)ld_out * sizeof(double), stage,

@@ -140,7 +140,7 @@ int64_t lognum_chunks(int64_t N, int64_t K);
 hipError_t launch_lognum_merge(hipStream_t s, const double* pmax, const double* psum, int64_t K,
                                int64_t nchunks, double* out_max /*[K]*/, double* out_sum /*[K]*/);
 hipError_t launch_logw(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K,
-                       const double* f, const double* logden, double* out, int64_t ld_out);
+                       const double* f, const double* logden, double* out, int64_t ld_out, bool exponentiate = false);
 // flags |= 1 if any u[k][n] is NaN, |= 2 if any is -inf (k < K, n < N)
 hipError_t launch_check_u(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, int* flags);
 hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_t N, int64_t K,

@@ -2484,13 +2484,16 @@ k_lognum_merge(const double* __restrict__ pmax, const double* __restrict__ psum,
     }
 }
 
+template <bool EXP>  // EXP: the weights themselves (mbar_solvers.py:476-486 takes exp of the log weights on the host)
 __global__ void __launch_bounds__(256)
 k_logw(const double* __restrict__ u, int64_t ld, int64_t N, const double* __restrict__ f,
        const double* __restrict__ logden, double* __restrict__ out, int64_t ld_out) {
     const int64_t k = blockIdx.y;
     const double fk = f[k];
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
-        out[k * ld_out + n] = fk - u[k * ld + n] - logden[n];
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const double lw = fk - u[k * ld + n] - logden[n];
+        out[k * ld_out + n] = EXP ? exp(lw) : lw;
+    }
 }
 
 // Boundary check of the matrix: bit 0 = some entry is NaN, bit 1 = some entry is -inf, bit 2 = some entry is +inf (legal:
@@ -4890,11 +4893,14 @@ hipError_t launch_lognum_merge(hipStream_t s, const double* pmax, const double* 
 }
 
 hipError_t launch_logw(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, const double* f,
-                       const double* logden, double* out, int64_t ld_out) {
+                       const double* logden, double* out, int64_t ld_out, bool exponentiate) {
     int64_t bx = (N + 255) / 256;
     if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(k_logw, dim3((unsigned)bx, (unsigned)K), dim3(256), 0, s, u, ld, N, f, logden, out, ld_out);
+    if (exponentiate)
+        hipLaunchKernelGGL(k_logw<true>, dim3((unsigned)bx, (unsigned)K), dim3(256), 0, s, u, ld, N, f, logden, out, ld_out);
+    else
+        hipLaunchKernelGGL(k_logw<false>, dim3((unsigned)bx, (unsigned)K), dim3(256), 0, s, u, ld, N, f, logden, out, ld_out);
     return hipGetLastError();
 }
 

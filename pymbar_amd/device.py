@@ -175,7 +175,9 @@ class DeviceMatrix:
         self._check(self._lib.mbar_ctx_synchronize(self._ctx))
 
     def to_host(self):
-        out = np.empty((self.K, self.N_local), dtype=np.float64)
+        from .utils import prefault
+
+        out = prefault(np.empty((self.K, self.N_local), dtype=np.float64))
         self._check(self._lib.mbar_ctx_download_u(self._ctx, _dptr(out), self.N_local))
         return out
 
@@ -279,8 +281,20 @@ class DeviceMatrix:
         """``log W`` of this shard as a C-ordered (K, N_local) array; its ``.T`` is the reference's
         F-ordered (N, K) ``Log_W_nk``."""
         f = np.ascontiguousarray(f, dtype=np.float64)
-        out = np.empty((self.K, self.N_local), dtype=np.float64)
+        from .utils import prefault
+
+        out = prefault(np.empty((self.K, self.N_local), dtype=np.float64))  # (pages touched by several threads first)
         self._check(self._lib.mbar_logw(self._ctx, _dptr(f), _dptr(out), self.N_local))
+        return out
+
+    def w_kn(self, f):
+        """The weights ``W`` of this shard as a C-ordered (K, N_local) array (``exp`` taken on the device); its ``.T`` is the
+        reference's (N, K) ``W_nk``."""
+        from .utils import prefault
+
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        out = prefault(np.empty((self.K, self.N_local), dtype=np.float64))
+        self._check(self._lib.mbar_w(self._ctx, _dptr(f), _dptr(out), self.N_local))
         return out
 
     def gram_w(self, f):

@@ -80,21 +80,7 @@ def _small_blas(K):
 _BLAS_CONTROLLER = None
 
 
-def _private_copy(src):
-    """``np.array(src)`` of a float64 C-contiguous matrix; from 64 MB on the rows are copied by several threads (numpy releases
-    the GIL in ``copyto``): a fresh 4 GB array is bound by the first touch of its pages on one thread (13 GB/s on the GPU box's
-    host), which several threads take in parallel."""
-    if src.nbytes < (64 << 20) or src.ndim != 2 or src.shape[0] < 2:
-        return np.array(src, dtype=np.float64)
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-
-    nt = max(1, min(16, src.shape[0], (os.cpu_count() or 1)))
-    out = np.empty_like(src)
-    bounds = np.linspace(0, src.shape[0], nt + 1).astype(int)
-    with ThreadPoolExecutor(nt) as ex:
-        list(ex.map(lambda i: np.copyto(out[bounds[i]:bounds[i + 1]], src[bounds[i]:bounds[i + 1]]), range(nt)))
-    return out
+from .utils import private_copy as _private_copy  # noqa: E402
 
 
 def _sample_groups(x_kindices, K):
@@ -261,7 +247,11 @@ class MBAR:
 
     @property
     def W_nk(self):
-        return np.exp(self.Log_W_nk)
+        """(N, K) weights: ``exp(Log_W_nk)`` taken on the device (not cached: 10 GB at config 3)."""
+        if self._Log_W_nk is not None:  # (already on the host, or assigned by the caller: the reference's exp(self.Log_W_nk))
+            return np.exp(self._Log_W_nk)
+        self._dm.set_Nk(self.N_k)
+        return self._dm.w_kn(self.f_k).T
 
     def weights(self):
         return self.W_nk

@@ -253,8 +253,10 @@ def mbar_log_W_nk(u_kn, N_k, f_k):
 
 
 def mbar_W_nk(u_kn, N_k, f_k):
-    """``exp(mbar_log_W_nk)`` (mbar_solvers.py:476-507)."""
-    return np.exp(mbar_log_W_nk(u_kn, N_k, f_k))
+    """``exp(mbar_log_W_nk)`` (mbar_solvers.py:476-507), the exponential taken on the device (``mbar_w``)."""
+    with _Resident(u_kn) as h:
+        N_k, f_k = _prep(h, N_k, f_k)
+        return h.w_kn(f_k).T
 
 
 def precondition_u_kn(u_kn, N_k, f_k):

@@ -155,6 +155,9 @@ class OracleMatrix:
         f = np.asarray(f, dtype=np.float64)
         return f[:, None] - self.u - self._logden(f)[None, :]
 
+    def w_kn(self, f):
+        return np.exp(self.logw_kn(f))
+
     def gram_w(self, f):
         W = np.exp(self.logw_kn(f)).T
         buf = np.concatenate([(W.T @ W).ravel(), W.sum(0)])

@@ -125,6 +125,9 @@ def test_unsampled_states_and_logw(DM):
         logW = ms.mbar_log_W_nk(dm, N_k, f)
         assert logW.shape == (3000, 24) and logW.flags.f_contiguous
         np.testing.assert_allclose(logW, oracle.mbar_log_W_nk(u_kn, N_k, f), rtol=1e-13, atol=1e-12)
+        Wd = ms.mbar_W_nk(dm, N_k, f)  # (the exponential taken on the device: mbar_w)
+        assert Wd.shape == (3000, 24) and Wd.flags.f_contiguous
+        np.testing.assert_allclose(Wd, oracle.mbar_W_nk(u_kn, N_k, f), rtol=1e-12, atol=1e-300)
         G, wsum = dm.gram_w(f)
         W = oracle.mbar_W_nk(u_kn, N_k, f)
         np.testing.assert_allclose(G, W.T @ W, rtol=1e-10, atol=1e-14)
