@@ -58,9 +58,11 @@ def _resolve_protocol(protocol, default, robust, maximum_iterations, verbose, pn
 def _small_blas(K):
     """A few hundred states: the eigendecomposition / pseudo-inverse / products of the covariance are K x K host matrices, and a
     BLAS that wakes every core of a large host for them spends tens of milliseconds on its threads (16-95 ms instead of 3 at
-    K = 120 on a 256-thread box).  One thread while they run, if threadpoolctl is there to ask."""
+    K = 120 on a 256-thread box; 130 instead of 23 ms at 384, 267 instead of 60 at 512).  One thread while they run up to 256
+    states, four beyond (measured best there: 34.7 / 26.8 / 23.3 / 23.9 ms at 1 / 2 / 4 / 8 threads for 384), if threadpoolctl is
+    there to ask."""
     global _BLAS_CONTROLLER
-    if K > 512 or K < 48:  # (below ~50 states the products are too small for the BLAS to thread at all)
+    if K < 48:  # (below ~50 states the products are too small for the BLAS to thread at all)
         yield
         return
     if _BLAS_CONTROLLER is None:
@@ -73,7 +75,7 @@ def _small_blas(K):
     if not _BLAS_CONTROLLER:
         yield
         return
-    with _BLAS_CONTROLLER.limit(limits=1):
+    with _BLAS_CONTROLLER.limit(limits=1 if K <= 256 else 4):
         yield
 
 
