@@ -283,7 +283,8 @@ class MBAR:
         """Overlap matrix ``O = N_k * (W^T W)``, its eigenvalues and ``1 - second largest`` (mbar.py:563-617)."""
         G, _ = self._gram_w()
         O = self.N_k * G
-        eigenvals = np.sort(np.linalg.eigvals(O))[::-1]
+        with _small_blas(self.K):
+            eigenvals = np.sort(np.linalg.eigvals(O))[::-1]
         return dict(scalar=1 - eigenvals[1], eigenvalues=eigenvals, matrix=O)
 
     # ---- free energy differences --------------------------------------------------------------------
