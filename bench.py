@@ -169,9 +169,15 @@ def api_end_to_end(K, N_total, seed, dev, O_k, K_k, N_k):
     ok = bool(np.all(np.isfinite(r["dDelta_f"])))
     stats = dict(getattr(mbar, "upload_stats", {}) or {})
     mbar.close()
-    del u_host
+    del mbar
+    # the constructor as most callers use it: with the object's own host copy of the matrix (the reference's semantics)
+    t2 = time.perf_counter()
+    mbar = pymbar_amd.MBAR(u_host, N_k, device=dev)
+    t_ctor_copy = time.perf_counter() - t2
+    mbar.close()
+    del mbar, u_host
     return {"api_end_to_end_s": total, "constructor_s": t_ctor, "compute_free_energy_differences_s": t_diff,
-            "host_bytes": 8.0 * K * N_total, "finite": ok, **stats}
+            "constructor_with_private_host_copy_s": t_ctor_copy, "host_bytes": 8.0 * K * N_total, "finite": ok, **stats}
 
 
 def spawn_ranks(n):
