@@ -100,7 +100,8 @@ def check_case(DM, case):
         g_or = oracle.mbar_gradient(u_or[sws], Nf[sws], ro["x"])
         assert np.abs(g_dev).max() <= 10.0 * np.abs(g_or).max() + 1e-8 * scale, (np.abs(g_dev).max(), np.abs(g_or).max())
         if ra.get("psum") is not None:
-            np.testing.assert_allclose((ra["psum"] - Nf)[sws], -g_dev, rtol=0, atol=1e-9 * scale + 1e-6 * np.abs(g_dev).max(), err_msg="psum at the result")
+            # (mbar_gradient = psum - N_k; non-zero where the reference's loop itself runs out of iterations -- case 4089)
+            np.testing.assert_allclose((ra["psum"] - Nf)[sws], g_dev, rtol=0, atol=1e-9 * scale + 1e-6 * np.abs(g_dev).max(), err_msg="psum at the result")
         close_call = any(abs(h["gnorm_sci"] - h["gnorm_nr"]) <= 1e-6 * max(h["gnorm_sci"], h["gnorm_nr"]) + 1e-9 * scale for h in hist)
         near_tol = any(0.1 * tol < h["max_delta"] < 10 * tol for h in hist)
         if not close_call and not near_tol:
