@@ -206,3 +206,45 @@ def test_bench_without_a_launcher_refuses_to_measure_fewer_ranks_than_asked():
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 3, (p.returncode, p.stderr[-400:])
     assert "GPU(s) visible" in p.stderr and not p.stdout.strip()
+
+
+def test_threaded_host_helpers_and_blas_limit():
+    """utils.private_copy / utils.prefault: faithful below and above the 64 MB threshold (threads only above it); the covariance
+    algebra never runs with the BLAS' default thread count from 48 states on."""
+    from pymbar_amd import mbar as mbar_mod
+    from pymbar_amd.utils import prefault, private_copy
+
+    small = np.arange(12.0).reshape(3, 4)
+    c = private_copy(small)
+    assert np.array_equal(c, small) and c is not small and c.flags.c_contiguous
+    big = np.random.default_rng(0).random((9, 1_000_000))  # 72 MB
+    c = private_copy(big)
+    assert np.array_equal(c, big) and c is not big
+    out = prefault(np.empty((9, 1_000_000)))
+    assert out.shape == (9, 1_000_000) and np.all(out == 0.0)
+    tiny = np.empty((2, 3))
+    assert prefault(tiny) is tiny
+
+    limits = []
+
+    class FakeController:
+        def limit(self, limits=None):
+            import contextlib
+
+            @contextlib.contextmanager
+            def cm():
+                limits_seen.append(limits)
+                yield
+
+            return cm()
+
+    limits_seen = limits
+    old = mbar_mod._BLAS_CONTROLLER
+    mbar_mod._BLAS_CONTROLLER = FakeController()
+    try:
+        for K in (10, 48, 128, 256, 257, 384, 600):
+            with mbar_mod._small_blas(K):
+                pass
+    finally:
+        mbar_mod._BLAS_CONTROLLER = old
+    assert limits == [1, 1, 1, 4, 4, 4]
