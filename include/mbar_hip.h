@@ -67,9 +67,14 @@ void mbar_ctx_destroy(mbar_ctx* ctx);
 int mbar_ctx_synchronize(mbar_ctx* ctx);
 /* Device and pinned-host blocks freed by contexts are kept for re-use (hipMalloc / hipFree cost more than a sweep at the
  * sizes pymbar is typically run at, and 0.3-0.7 s for the 6-8 GB augmented matrix of an expectation call at K=128, N=4e6);
- * bounded by MBAR_CACHE_MB (environment; default a quarter of the device's memory; 0 = off); an allocation that fails empties
+ * bounded by MBAR_CACHE_MB (environment; default an eighth of the device's memory; 0 = off); an allocation that fails empties
  * the cache and is tried again.  This returns every parked block to the driver. */
 int mbar_cache_trim(void);
+/* 128-bit content digest of a HOST buffer, computed at memory speed on `threads` host threads (0 = all cores).  The reference's
+ * module-level functions are pure functions of the u_kn they are handed (mbar_solvers.py:260-292: every call reads the current
+ * array); the Python binding keeps device copies of recently seen host matrices and re-uses one only when the digest of the
+ * bytes now behind the address equals the digest of what it uploaded.  A change of ONE element always changes the digest. */
+int mbar_host_digest(const void* data, int64_t nbytes, int threads, uint64_t* out2);
 /* hipDeviceSynchronize on `device` (every stream of every context): the bracket of a timed region. */
 int mbar_device_synchronize(int device);
 /* Tuning / test knobs (defaults are the measured best; every variant is parity-tested):

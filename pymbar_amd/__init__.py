@@ -6,9 +6,10 @@ the solver-facing part of ``pymbar.MBAR``.  All K x N sweeps run in ``csrc/libmb
 does not load the library or touch a GPU; the first computation does, and fails loudly if it cannot.
 """
 from . import mbar_solvers, testsystems, utils
-from ._lib import BackendUnavailable, MbarHipError
+from ._lib import BackendUnavailable, MbarHipError, trim_device_cache
 from .mbar import MBAR
 from .utils import ParameterError
 
-__all__ = ["MBAR", "mbar_solvers", "testsystems", "utils", "ParameterError", "BackendUnavailable", "MbarHipError"]
+__all__ = ["MBAR", "mbar_solvers", "testsystems", "utils", "ParameterError", "BackendUnavailable", "MbarHipError",
+           "trim_device_cache"]
 __version__ = "0.1.0"

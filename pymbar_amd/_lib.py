@@ -61,6 +61,7 @@ SIGNATURES = {
     "mbar_ctx_synchronize": (C.c_int, [_ctx]),
     "mbar_device_synchronize": (C.c_int, [C.c_int]),
     "mbar_cache_trim": (C.c_int, []),
+    "mbar_host_digest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]),
     "mbar_ctx_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int64]),
     "mbar_ctx_upload_u": (C.c_int, [_ctx, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "mbar_ctx_download_u": (C.c_int, [_ctx, _dp, C.c_int64]),
@@ -130,6 +131,19 @@ def last_error(ctx=None):
 def check(code, ctx=None):
     if code != MBAR_OK:
         raise MbarHipError(code, last_error(ctx))
+
+
+def host_digest(a, threads=0):
+    """16-byte digest of every byte of a C-contiguous numpy array (``mbar_host_digest``; host only, no GPU needed)."""
+    out = (C.c_uint64 * 2)()
+    check(load_library().mbar_host_digest(C.c_void_p(a.ctypes.data), a.nbytes, int(threads), out))
+    return bytes(out)
+
+
+def trim_device_cache():
+    """Hand every device / pinned block this library has parked for re-use back to the driver (``mbar_cache_trim``; the bound
+    of the cache is ``MBAR_CACHE_MB``, see include/mbar_hip.h)."""
+    check(load_library().mbar_cache_trim())
 
 
 def device_count():

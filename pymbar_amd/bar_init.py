@@ -34,11 +34,12 @@ def bar_zero(w_F, w_R, DeltaF):
     w_R = np.asarray(w_R, dtype=np.float64)
     M = np.log(float(w_F.size) / float(w_R.size))
     # fast path: the Fermi functions summed directly (one exponential per work value; e^x = inf gives f = 0); only when a sum
-    # underflows to zero -- no overlap at all at this DeltaF -- the log-space form below is needed
+    # underflows towards zero / the denormal range -- (almost) no overlap at this DeltaF -- the log-space form below is needed
     with np.errstate(over="ignore"):
         s_F = np.sum(1.0 / (1.0 + np.exp(M + w_F - DeltaF)))
         s_R = np.sum(1.0 / (1.0 + np.exp(-(M - w_R - DeltaF))))
-    if s_F > 0.0 and s_R > 0.0 and np.isfinite(s_F) and np.isfinite(s_R):
+    floor = np.finfo(np.float64).tiny / np.finfo(np.float64).eps  # below it a sum is made of denormals: log(s) has lost digits
+    if s_F > floor and s_R > floor and np.isfinite(s_F) and np.isfinite(s_R):
         return np.log(s_F) - np.log(s_R)
     log_f_F = -np.logaddexp(0.0, M + w_F - DeltaF)
     log_f_R = -np.logaddexp(0.0, -(M - w_R - DeltaF))
@@ -94,14 +95,13 @@ def initialize_with_bar(u_kn, N_k, x_kindices, f_k_init=None):
     order = np.where(N_k > 0)[0]
     f_k_init = np.zeros(K) if f_k_init is None else np.array(f_k_init, dtype=np.float64)
     # the samples of every state, grouped once (the reference builds a boolean mask over all N samples per pair, :1958-1967)
-    x = np.asarray(x_kindices)
-    sorted_already = x.size == 0 or bool(np.all(x[:-1] <= x[1:]))
-    counts = np.bincount(x, minlength=K)[:K] if x.size else np.zeros(K, dtype=np.int64)
-    offs = np.concatenate(([0], np.cumsum(counts)))
-    by_state = None if sorted_already else np.argsort(x, kind="stable")
+    from .utils import state_index_groups
+
+    groups = state_index_groups(x_kindices, K)
 
     def samples_of(k):  # a slice (a view of the row) in the default layout, an index array otherwise
-        return slice(int(offs[k]), int(offs[k + 1])) if sorted_already else by_state[offs[k]:offs[k + 1]]
+        g = groups[k]
+        return slice(g.start, g.stop) if isinstance(g, range) else g
 
     for k, l in zip(order[:-1], order[1:]):
         from_k = samples_of(k)

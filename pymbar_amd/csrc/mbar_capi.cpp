@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -67,7 +68,8 @@ RcclApi g_rccl;
 // hipMalloc / hipFree / hipHostMalloc cost 0.1 - 1 ms each (hipFree also synchronises the device): a context makes ~15
 // allocations, and pymbar's real workloads (K ~ 40, N ~ 1e5: sweeps of ~10 us) build and drop contexts all the time -- the
 // MBAR object, one augmented matrix per expectation call, one temporary per module-level function call.  Freed blocks are
-// therefore kept (per device, bounded: MBAR_CACHE_MB, default a quarter of the device's memory -- 72 GB of 288 -- and 64 MB of
+// therefore kept (per device, bounded: MBAR_CACHE_MB, default an eighth of the device's memory -- 36 GB of 288: room for config 3's
+// matrix + probability matrix or one augmented expectation matrix, while other users of the GPU keep 7/8 -- and 64 MB of
 // pinned host memory; blocks of more than half the bound go straight back to the driver) and handed out again to requests of
 // about the same size.  (The bound used to be 2 GB: the augmented matrix of an expectation call at K=128, N=4e6 is 6-8 GB, and
 // its hipMalloc / hipFree pair cost 0.3-0.7 s per call against 15-45 ms of work.)  An allocation that fails empties the cache
@@ -101,7 +103,7 @@ struct MemCache {
             (void)hipGetLastError();
             return dev_limit;
         }
-        return std::max(dev_limit, total_b / 4);
+        return std::max(dev_limit, total_b / 8);
     }
     static size_t round_up(size_t b) { return (b + 4095) / 4096 * 4096; }
     static void* take(Pool& p, size_t want) {
@@ -1830,7 +1832,9 @@ int mbar_device_info(int device, char* name, int name_len, int* compute_units, i
 int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
     if (!out) return fail(nullptr, MBAR_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (K < 1 || N_local < 1) return fail(nullptr, MBAR_ERR_ARG, "K and N_local must be >= 1");
+    // (N_local = 0 is a legal shard: with more ranks than 16-sample tiles a rank owns no column, yet it must take part in every
+    // collective of the loop; it keeps one all-padding tile so that every kernel has something to launch on)
+    if (K < 1 || N_local < 0) return fail(nullptr, MBAR_ERR_ARG, "K must be >= 1 and N_local >= 0");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
         return fail(nullptr, MBAR_ERR_NODEVICE, "no HIP device visible (libmbar_hip needs an MI355X / gfx950 GPU)");
@@ -1842,6 +1846,7 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
     c->N = N_local;
     // row pitch: whole 16-sample tiles; whole 64-sample tiles where the few-state evaluation kernel may run (K <= 32)
     c->ld = c->Kp <= 32 ? (N_local + 63) / 64 * 64 : (N_local + TS - 1) / TS * TS;
+    if (c->ld == 0) c->ld = c->Kp <= 32 ? 64 : TS;
 #define CRT(expr)                                                                                   \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \
@@ -1958,6 +1963,74 @@ int mbar_ctx_synchronize(mbar_ctx* c) {
 
 int mbar_cache_trim(void) {
     g_mem.trim();
+    return MBAR_OK;
+}
+
+// ---- content digest of a host buffer ------------------------------------------------------------------------------------
+// The module-level functions of the reference are pure functions of their arguments (mbar_solvers.py:260-292): a caller may edit
+// u_kn in place between two calls.  The Python side keeps device copies of recently seen host matrices and has to know whether
+// the bytes behind an address are still the bytes it uploaded; this is that test, at memory speed on all host cores.
+// 128 bits: every 1 MiB chunk runs four independent 64-bit lanes acc <- rotl(acc ^ w, 29) * ODD over its 8-byte words (a
+// bijection of acc for a fixed word and injective in the word for a fixed acc, so a change of ONE word always changes its
+// lane), the lanes fold into two words by maps that are injective in each lane, and the chunk digests are chained in chunk
+// order by the same step with two different multipliers.  A single changed element is therefore ALWAYS detected; an arbitrary
+// multi-element change escapes with probability ~2^-128.  Not cryptographic (nobody is forging matrices).
+namespace {
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+constexpr uint64_t DG_M0 = 0x9E3779B97F4A7C15ull, DG_M1 = 0xC2B2AE3D27D4EB4Full, DG_M2 = 0x165667B19E3779F9ull,
+                   DG_M3 = 0xD6E8FEB86659FD93ull;
+constexpr int64_t DG_CHUNK = 1 << 20;
+
+void digest_chunk(const unsigned char* p, int64_t n, uint64_t out[2]) {
+    uint64_t a0 = DG_M0 ^ (uint64_t)n, a1 = DG_M1, a2 = DG_M2, a3 = DG_M3;
+    int64_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        a0 = rotl64(a0 ^ w[0], 29) * DG_M1;
+        a1 = rotl64(a1 ^ w[1], 29) * DG_M2;
+        a2 = rotl64(a2 ^ w[2], 29) * DG_M3;
+        a3 = rotl64(a3 ^ w[3], 29) * DG_M0;
+    }
+    if (i < n) {  // tail: zero-padded (the length is part of the seed)
+        uint64_t w[4] = {0, 0, 0, 0};
+        std::memcpy(w, p + i, (size_t)(n - i));
+        a0 = rotl64(a0 ^ w[0], 29) * DG_M1;
+        a1 = rotl64(a1 ^ w[1], 29) * DG_M2;
+        a2 = rotl64(a2 ^ w[2], 29) * DG_M3;
+        a3 = rotl64(a3 ^ w[3], 29) * DG_M0;
+    }
+    out[0] = a0 ^ rotl64(a1, 13) ^ rotl64(a2, 29) ^ rotl64(a3, 47);
+    out[1] = a0 * DG_M2 + a1 * DG_M3 + a2 * DG_M0 + a3 * DG_M1;
+}
+}  // namespace
+
+int mbar_host_digest(const void* data, int64_t nbytes, int threads, uint64_t* out2) {
+    if ((!data && nbytes > 0) || nbytes < 0 || !out2) return fail(nullptr, MBAR_ERR_ARG, "mbar_host_digest: bad argument");
+    const unsigned char* p = (const unsigned char*)data;
+    const int64_t nchunks = (nbytes + DG_CHUNK - 1) / DG_CHUNK;
+    std::vector<uint64_t> part((size_t)nchunks * 2);
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)nt, (int64_t)64, nchunks / 8}));  // (>= 8 MiB per thread)
+    auto work = [&](int t) {
+        for (int64_t c = t; c < nchunks; c += nt)
+            digest_chunk(p + c * DG_CHUNK, std::min<int64_t>(DG_CHUNK, nbytes - c * DG_CHUNK), &part[(size_t)c * 2]);
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    uint64_t h0 = DG_M3 ^ (uint64_t)nbytes, h1 = DG_M2 + (uint64_t)nbytes;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        h0 = rotl64(h0 ^ part[(size_t)c * 2], 31) * DG_M0;
+        h1 = rotl64(h1 ^ part[(size_t)c * 2 + 1], 27) * DG_M1;
+    }
+    out2[0] = h0 ^ (h0 >> 32);
+    out2[1] = h1 ^ (h1 >> 29);
     return MBAR_OK;
 }
 

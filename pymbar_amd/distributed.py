@@ -61,6 +61,26 @@ def _recv_msg(sock):
     return _recv_exact(sock, n) if n else b""
 
 
+def _bind_candidates(addr):
+    """Addresses rank 0 tries to listen on, in order.  ``MBAR_RDZV_BIND`` overrides everything.  A loopback ``MASTER_ADDR``
+    binds loopback only (single node: nothing off the host can reach the hub).  Otherwise the interface ``MASTER_ADDR``
+    resolves to -- unless that is a loopback alias (Debian's ``127.0.1.1`` entry for the own hostname) or not a local interface
+    at all (a NAT / VIP / service address: ``bind`` fails), in which cases remote ranks could never connect to it and the
+    wildcard address is used; the token handshake (launch parameters + ``MBAR_RDZV_SECRET``) authenticates peers either way."""
+    override = os.environ.get("MBAR_RDZV_BIND")
+    if override:
+        return [override]
+    if addr in ("localhost", "::1") or addr.startswith("127."):
+        return ["127.0.0.1"]
+    try:
+        resolved = socket.gethostbyname(addr)
+    except OSError:
+        return ["0.0.0.0"]
+    if resolved.startswith("127."):  # the own hostname mapped to a loopback alias: remote ranks need a real interface
+        return ["0.0.0.0"]
+    return [resolved, "0.0.0.0"]
+
+
 class HostGroup:
     """Minimal process group over TCP (standard library only): rank 0 listens, the others connect.
 
@@ -73,37 +93,39 @@ class HostGroup:
     (or ``MBAR_RDZV_PORT``) and the clients probe the same range; a handshake token derived from the launch
     (address, port, run id, world size -- plus ``MBAR_RDZV_SECRET`` when the launcher exports one, which ``bench.py``'s own
     spawner does with a random value) tells this group's hub from anything else listening there.  Rank 0 binds the interface
-    of ``MASTER_ADDR`` only (loopback for a single node), never the wildcard address.  ``timeout`` bounds the rendezvous;
-    once the group stands, a collective may wait ``data_timeout`` (default one hour) for a slow peer -- ranks skew by minutes
-    when one of them uploads tens of GB first."""
+    of ``MASTER_ADDR`` (loopback for a single node; the wildcard address only when that name is not a usable local interface --
+    see ``_bind_candidates`` -- or ``MBAR_RDZV_BIND`` says so).  ``timeout`` bounds the rendezvous; once the group stands, a
+    collective may wait ``data_timeout`` for a slow peer (default ``MBAR_RDZV_DATA_TIMEOUT`` or 600 s: ranks skew by minutes
+    when one of them uploads tens of GB first, but a dead peer must not hang a job for an hour).  Messages above 64 MB travel
+    in pieces (a K x K all-reduce on the host transport is 8 K^2 bytes)."""
 
-    def __init__(self, rank, world, addr="127.0.0.1", base_port=29501, token="", timeout=120.0, data_timeout=3600.0):
+    def __init__(self, rank, world, addr="127.0.0.1", base_port=29501, token="", timeout=120.0, data_timeout=None):
         self.rank, self.world = int(rank), int(world)
         self._socks = {}     # rank 0: peer rank -> socket
         self._sock = None    # other ranks: socket to rank 0
         self._listener = None
         if self.world <= 1:
             return
+        if data_timeout is None:
+            data_timeout = float(os.environ.get("MBAR_RDZV_DATA_TIMEOUT", "600"))
         tok = hashlib.sha256(f"{token}|{self.world}".encode()).digest()[:16]
         deadline = time.time() + timeout
         if self.rank == 0:
-            bind_addr = "127.0.0.1" if addr in ("localhost", "::1") else addr
-            try:
-                bind_addr = socket.gethostbyname(bind_addr)  # the interface MASTER_ADDR names, not 0.0.0.0
-            except OSError:
-                bind_addr = "127.0.0.1"
             last = None
-            for port in range(base_port, base_port + _PORT_SPAN):
-                try:
-                    ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-                    ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                    ls.bind((bind_addr, port))
-                    ls.listen(self.world)
-                    self._listener = ls
+            for bind_addr in _bind_candidates(addr):
+                for port in range(base_port, base_port + _PORT_SPAN):
+                    try:
+                        ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                        ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                        ls.bind((bind_addr, port))
+                        ls.listen(self.world)
+                        self._listener = ls
+                        break
+                    except OSError as exc:
+                        last = exc
+                        ls.close()
+                if self._listener is not None:
                     break
-                except OSError as exc:
-                    last = exc
-                    ls.close()
             if self._listener is None:
                 raise RuntimeError(f"rendezvous: no free port in [{base_port}, {base_port + _PORT_SPAN}): {last}")
             self._listener.settimeout(1.0)
@@ -184,30 +206,36 @@ class HostGroup:
         return m[1:] if m[:1] == b"\x01" else None
 
     def allreduce(self, arr, op="sum"):
-        """In-place all-reduce of a float64 numpy array (``op`` "sum", "max" or "min"); rank order on the hub."""
+        """In-place all-reduce of a float64 numpy array (``op`` "sum", "max" or "min"); rank order on the hub.  Arrays beyond
+        the message bound travel in pieces (every rank cuts at the same places)."""
         if self.world <= 1:
             return arr
+        if op not in ("sum", "max", "min"):
+            raise ValueError(op)
         a = np.ascontiguousarray(arr, dtype=np.float64)
-        if self.rank == 0:
-            acc = a.copy()
-            for r in sorted(self._socks):
-                other = np.frombuffer(_recv_msg(self._socks[r]), dtype=np.float64).reshape(a.shape)
-                if op == "sum":
-                    acc += other
-                elif op == "max":
-                    np.fmax(acc, other, out=acc)   # (like ncclMax: the non-NaN operand wins)
-                elif op == "min":
-                    np.fmin(acc, other, out=acc)
-                else:
-                    raise ValueError(op)
-            out = acc.tobytes()
-            for r in sorted(self._socks):
-                _send_msg(self._socks[r], out)
-            res = acc
-        else:
-            _send_msg(self._sock, a.tobytes())
-            res = np.frombuffer(_recv_msg(self._sock), dtype=np.float64).reshape(a.shape)
-        arr[...] = res
+        flat = a.reshape(-1)
+        res = np.empty_like(flat)
+        piece = _MAX_MSG // 16  # doubles per message (half the bound)
+        for lo in range(0, max(1, flat.size), piece):
+            part = flat[lo:lo + piece]
+            if self.rank == 0:
+                acc = part.copy()
+                for r in sorted(self._socks):
+                    other = np.frombuffer(_recv_msg(self._socks[r]), dtype=np.float64)
+                    if op == "sum":
+                        acc += other
+                    elif op == "max":
+                        np.fmax(acc, other, out=acc)   # (like ncclMax: the non-NaN operand wins)
+                    else:
+                        np.fmin(acc, other, out=acc)
+                out = acc.tobytes()
+                for r in sorted(self._socks):
+                    _send_msg(self._socks[r], out)
+                res[lo:lo + piece] = acc
+            else:
+                _send_msg(self._sock, part.tobytes())
+                res[lo:lo + piece] = np.frombuffer(_recv_msg(self._sock), dtype=np.float64)
+        arr[...] = res.reshape(a.shape)
         return arr
 
     def barrier(self):

@@ -55,13 +55,25 @@ def label_samples(x_n, bin_edges):
     sizes = tuple(len(bin_edges[d]) + 1 for d in range(dims))
     # one integer per grid cell (0 = "off the grid to the left in some dimension": all such samples share the reference's
     # label -1), then the populated cells numbered in order of first appearance -- without a Python loop over the samples
-    flat = np.ravel_multi_index(tuple(b + 1 for b in bin_n), sizes) + 1
     left = np.zeros(N, dtype=bool)
     for b in bin_n:
         left |= b < 0
+    P = float(np.prod(sizes, dtype=np.float64)) + 1.0
+    if P >= 2.0 ** 62:
+        # more cells than an int64 can number (many dimensions): sort the samples' index TUPLES instead of flat cell numbers
+        stacked = np.stack([np.where(left, -1, b) for b in bin_n], axis=1)  # (all left-overflow samples share one tuple)
+        tuples, first, inv = np.unique(stacked, axis=0, return_index=True, return_inverse=True)
+        by_first = np.argsort(first, kind="stable")
+        rank = np.empty(len(tuples), dtype=np.int64)
+        rank[by_first] = np.arange(len(tuples))
+        sample_label = rank[np.asarray(inv).reshape(-1)]
+        grid = [None if t[0] < 0 else tuple(int(v) for v in t) for t in tuples[by_first]]
+        return sample_label, grid
+    flat = np.ravel_multi_index(tuple(b + 1 for b in bin_n), sizes) + 1
     flat[left] = 0
-    P = int(np.prod(sizes, dtype=np.float64)) + 1
-    if P <= 50_000_000:
+    P = int(P)
+    if P <= 50_000_000 and P <= 8 * N + 1024:
+        # a grid no larger than a few cells per sample: tabulate it (two int64 tables over the grid, no sort)
         first = np.full(P, N, dtype=np.int64)
         first[flat[::-1]] = np.arange(N - 1, -1, -1)  # (duplicates: the last write wins, so the smallest n is kept)
         cells = np.nonzero(first < N)[0]
@@ -69,7 +81,7 @@ def label_samples(x_n, bin_edges):
         rank = np.zeros(P, dtype=np.int64)
         rank[cells] = np.arange(len(cells))
         sample_label = rank[flat]
-    else:  # a grid with more cells than that: sort the samples' cells instead of tabulating the grid
+    else:  # a fine grid and few samples (or a huge grid): sort the samples' cells instead of tabulating the grid
         cells, first, inv = np.unique(flat, return_index=True, return_inverse=True)
         by_first = np.argsort(first, kind="stable")
         rank = np.empty(len(cells), dtype=np.int64)

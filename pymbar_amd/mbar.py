@@ -86,15 +86,10 @@ from .utils import private_copy as _private_copy  # noqa: E402
 
 
 def _sample_groups(x_kindices, K):
-    """``[np.where(x_kindices == k)[0] for k in range(K)]`` in one pass: slices of a stable argsort, or plain ``range`` objects when
-    the samples are already ordered by state (the default layout: no index arrays at all)."""
-    x = np.asarray(x_kindices)
-    counts = np.bincount(x, minlength=K)[:K] if x.size else np.zeros(K, dtype=np.int64)
-    offs = np.concatenate(([0], np.cumsum(counts)))
-    if x.size == 0 or np.all(x[:-1] <= x[1:]):
-        return [range(int(offs[k]), int(offs[k + 1])) for k in range(K)]
-    order = np.argsort(x, kind="stable")
-    return [order[offs[k]:offs[k + 1]] for k in range(K)]
+    """The samples of every state (see :func:`pymbar_amd.utils.state_index_groups`)."""
+    from .utils import state_index_groups
+
+    return state_index_groups(x_kindices, K)
 
 
 class MBAR:

@@ -7,7 +7,8 @@ a machine without the library or without a gfx950 device these functions raise
 ``pymbar_amd._lib.BackendUnavailable``.
 
 ``u_kn`` may be a numpy array (uploaded on first sight and kept in a small cache of device copies, so that the reference's
-unchanged ``MBAR`` class uploads its matrix once per object, not once per call -- see ``_ResidentCache``) or a resident
+unchanged ``MBAR`` class uploads its matrix once per object, not once per call; a copy is re-used only while a digest of the
+whole host array still matches, so an array edited in place between two calls is simply uploaded again -- see ``_ResidentCache``) or a resident
 :class:`pymbar_amd.device.DeviceMatrix` (or any object with the same methods: the tests drive the
 protocol logic below with a CPU stand-in built from the oracle).
 
@@ -77,65 +78,105 @@ class _ResidentCache:
     which calls this module several times with the same ``self.u_kn`` (mbar.py:413 ``solve_mbar_for_all_states``, :455
     ``mbar_log_W_nk``, :910 again per expectation) -- uploads the matrix ONCE instead of once per call.
 
-    A host array is recognised by (address, shape, strides) AND a digest of 4096 elements spread evenly over it plus 4096
-    spread over its first and over its last row: the array object may have been freed and another one allocated at the same address, or modified in place
-    (``u_kn -= shift`` changes every sampled element; a caller who pokes single elements into a matrix between two calls of this
-    module is not detected and must call :func:`drop_resident_cache` -- the reference's ``MBAR`` never writes to its copy).
+    The functions of this module stay pure functions of their arguments (mbar_solvers.py:260-292: every call of the reference
+    reads the array it is handed): a device copy is re-used only when a digest of EVERY byte of the host array
+    (``mbar_host_digest``: 128 bits, all host cores, memory speed -- ~0.1 s for config 3's 10 GB against the 0.2 s upload it
+    saves; a change of one element always changes it) equals the digest taken when the copy was uploaded.  An in-place edit
+    of any kind therefore costs a fresh upload, never a stale answer.
+    An entry in use is never closed: handles are reference-counted (an evicted entry is closed by its last user), every cache
+    operation runs under a lock, and a handle -- a context is not thread-safe -- is used by one thread at a time.
     Bounded: ``PYMBAR_AMD_RESIDENT_CACHE`` entries (default 2; 0 switches the cache off) and
-    ``PYMBAR_AMD_RESIDENT_CACHE_GB`` (default 64) of device memory; least recently used first out."""
+    ``PYMBAR_AMD_RESIDENT_CACHE_GB`` (default 32) of device memory; least recently used first out;
+    :func:`drop_resident_cache` releases everything."""
+
+    class Entry:
+        __slots__ = ("handle", "nbytes", "users", "evicted", "lock")
+
+        def __init__(self, handle, nbytes):
+            import threading
+
+            self.handle, self.nbytes, self.users, self.evicted = handle, nbytes, 0, False
+            self.lock = threading.RLock()  # (one thread at a time on the context; re-entrant for nested calls of one thread)
 
     def __init__(self):
+        import threading
         from collections import OrderedDict
 
-        self.entries = OrderedDict()  # key -> (handle, nbytes)
+        self.entries = OrderedDict()  # key -> Entry
         self.uploads = 0              # (counted for the boundary test)
         self.hits = 0
+        self.mutex = threading.RLock()
 
     @staticmethod
     def limits():
         return (int(os.environ.get("PYMBAR_AMD_RESIDENT_CACHE", "2")),
-                float(os.environ.get("PYMBAR_AMD_RESIDENT_CACHE_GB", "64")) * 1e9)
+                float(os.environ.get("PYMBAR_AMD_RESIDENT_CACHE_GB", "32")) * 1e9)
 
     @staticmethod
-    def key_of(a):
-        import hashlib
+    def digest(a):
+        """128-bit digest of every byte of the C-contiguous array ``a`` (the C library's threaded hash; ``hashlib`` when the
+        library cannot be loaded -- only the stand-in device of the CPU tests gets there)."""
+        try:
+            from . import _lib
 
-        flat = a.reshape(-1)  # (a view: the array is C-contiguous)
-        idx = np.linspace(0, flat.size - 1, min(flat.size, 4096)).astype(np.int64)
-        cols = np.linspace(0, a.shape[1] - 1, min(a.shape[1], 4096)).astype(np.int64)
-        h = hashlib.blake2b(digest_size=16)
-        h.update(flat[idx].tobytes())
-        h.update(a[0, cols].tobytes())   # (bounded: hashing two whole rows of a 1e7-sample matrix took 0.16 s per call)
-        h.update(a[-1, cols].tobytes())
-        return (a.ctypes.data, a.shape, a.strides, h.digest())
+            return _lib.host_digest(a)
+        except Exception:  # pragma: no cover - library not built
+            import hashlib
 
-    def get(self, u_kn):
-        """A resident handle for the host array, or ``(None, None)`` when it cannot be cached (caller uploads a temporary)."""
+            return hashlib.blake2b(a.reshape(-1).view(np.uint8), digest_size=16).digest()
+
+    def key_of(self, a):
+        return (a.ctypes.data, a.shape, a.strides, self.digest(a))
+
+    def acquire(self, u_kn):
+        """A resident entry for the host array (its ``users`` count raised, its lock held), or ``None`` when it cannot be
+        cached (the caller uploads a temporary)."""
         max_entries, max_bytes = self.limits()
         a = u_kn
         if (max_entries <= 0 or not isinstance(a, np.ndarray) or a.ndim != 2 or a.dtype != np.float64
                 or not a.flags.c_contiguous or a.size == 0 or a.nbytes > max_bytes):
-            return None, None
+            return None
         key = self.key_of(a)
-        hit = self.entries.get(key)
-        if hit is not None:
-            self.entries.move_to_end(key)
-            self.hits += 1
-            return hit[0], key
-        from .device import DeviceMatrix  # deferred: importing this module must not need a GPU
+        with self.mutex:
+            entry = self.entries.get(key)
+            if entry is not None:
+                self.entries.move_to_end(key)
+                self.hits += 1
+            else:
+                # a different content behind the same address / shape: the old copy can never be hit again
+                for old_key in [k for k in self.entries if k[:3] == key[:3]]:
+                    self._evict(old_key)
+                from .device import DeviceMatrix  # deferred: importing this module must not need a GPU
 
-        handle = DeviceMatrix.from_host(a)
-        self.uploads += 1
-        self.entries[key] = (handle, a.nbytes)
-        while len(self.entries) > max_entries or sum(b for _, b in self.entries.values()) > max_bytes:
-            _, (old, _) = self.entries.popitem(last=False)
-            old.close()
-        return handle, key
+                entry = self.Entry(DeviceMatrix.from_host(a), a.nbytes)
+                self.uploads += 1
+                self.entries[key] = entry
+                for old_key in list(self.entries):
+                    if len(self.entries) <= max_entries and sum(e.nbytes for e in self.entries.values()) <= max_bytes:
+                        break
+                    if old_key != key:
+                        self._evict(old_key)
+            entry.users += 1
+        entry.lock.acquire()
+        return entry
+
+    def release(self, entry):
+        entry.lock.release()
+        with self.mutex:
+            entry.users -= 1
+            if entry.evicted and entry.users == 0:
+                entry.handle.close()
+
+    def _evict(self, key):
+        entry = self.entries.pop(key)
+        entry.evicted = True
+        if entry.users == 0:
+            entry.handle.close()
 
     def clear(self):
-        while self.entries:
-            _, (old, _) = self.entries.popitem(last=False)
-            old.close()
+        with self.mutex:
+            for key in list(self.entries):
+                self._evict(key)
 
 
 _resident_cache = _ResidentCache()
@@ -153,19 +194,23 @@ class _Resident:
     def __init__(self, u_kn):
         self.u_kn = u_kn
         self.owned = None
+        self.entry = None
 
     def __enter__(self):
         if _is_handle(self.u_kn):
             return self.u_kn
-        handle, _ = _resident_cache.get(self.u_kn)
-        if handle is not None:
-            return handle
+        self.entry = _resident_cache.acquire(self.u_kn)
+        if self.entry is not None:
+            return self.entry.handle
         from .device import DeviceMatrix  # deferred: importing this module must not need a GPU
 
         self.owned = DeviceMatrix.from_host(self.u_kn)
         return self.owned
 
     def __exit__(self, *exc):
+        if self.entry is not None:
+            _resident_cache.release(self.entry)
+            self.entry = None
         if self.owned is not None:
             self.owned.close()
 

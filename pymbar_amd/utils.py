@@ -127,6 +127,36 @@ def kln_to_kn(kln, N_k=None, cleanup=False):
     return kn
 
 
+def state_index_groups(x_kindices, K):
+    """``[np.where(x_kindices == k)[0] for k in range(K)]`` (pymbar/mbar.py:424, :1958-1967) in one pass: ``range`` objects
+    when the samples are already ordered by state (the default layout: no index arrays at all), otherwise slices of a stable
+    argsort.  Like the reference's ``==`` masks this accepts float-typed indices (integral values match their state,
+    anything else matches none) and values outside ``[0, K)`` (they belong to no state)."""
+    x = np.asarray(x_kindices)
+    if x.size == 0:
+        return [range(0, 0) for _ in range(K)]
+    if x.dtype.kind in "iu":
+        xi = x.astype(np.int64, copy=False)
+        valid = (xi >= 0) & (xi < K)
+    else:
+        xf = np.asarray(x, dtype=np.float64)
+        with np.errstate(invalid="ignore"):
+            valid = (xf >= 0) & (xf < K) & (xf == np.floor(xf))
+        xi = np.where(valid, xf, 0).astype(np.int64)
+    if valid.all():
+        counts = np.bincount(xi, minlength=K)[:K]
+        offs = np.concatenate(([0], np.cumsum(counts)))
+        if np.all(xi[:-1] <= xi[1:]):
+            return [range(int(offs[k]), int(offs[k + 1])) for k in range(K)]
+        order = np.argsort(xi, kind="stable")
+        return [order[offs[k]:offs[k + 1]] for k in range(K)]
+    idx = np.nonzero(valid)[0]
+    counts = np.bincount(xi[idx], minlength=K)[:K]
+    offs = np.concatenate(([0], np.cumsum(counts)))
+    order = idx[np.argsort(xi[idx], kind="stable")]
+    return [order[offs[k]:offs[k + 1]] for k in range(K)]
+
+
 def _row_chunks(nrows, nthreads):
     import numpy as _np
 

@@ -58,3 +58,22 @@ def test_mbar_initialize_bar_on_gpu(tag, u_kn, N_k):
 
     m = MBAR(u_kn, N_k, initialize="BAR")
     np.testing.assert_allclose(m.f_k, GOLD[tag + "_f_k"], rtol=1e-8, atol=1e-9)
+
+
+def test_bar_zero_keeps_its_digits_when_the_overlap_is_almost_nil():
+    """Fermi sums in the denormal range (overlap ~ e^-720) must take the log-space form: ``log`` of a denormal sum has lost most
+    of its digits (the reference works in log space throughout, other_estimators.py:129-151)."""
+    from scipy.special import logsumexp
+
+    from pymbar_amd.bar_init import bar_zero
+
+    rng = np.random.RandomState(1)
+    w_F = 725.0 + rng.standard_normal(200)
+    w_R = -3.0 + rng.standard_normal(300)
+    M = np.log(len(w_F) / len(w_R))
+    want = logsumexp(-np.logaddexp(0.0, M + w_F - 0.0)) - logsumexp(-np.logaddexp(0.0, -(M - w_R - 0.0)))
+    assert abs(bar_zero(w_F, w_R, 0.0) - want) < 1e-12 * abs(want)
+    # and the fast path still agrees with it where both are fine
+    w_F2 = 2.0 + rng.standard_normal(200)
+    want2 = logsumexp(-np.logaddexp(0.0, M + w_F2 - 0.5)) - logsumexp(-np.logaddexp(0.0, -(M - w_R - 0.5)))
+    assert abs(bar_zero(w_F2, w_R, 0.5) - want2) < 1e-12

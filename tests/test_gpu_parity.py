@@ -909,3 +909,63 @@ def test_rows_that_cannot_contribute_are_not_streamed(DM, K, N, unsampled):
                 dm.set_option(k, 1)
         fs, rs = dm.solve_sci(np.zeros(K), tol=1e-9, maxiter=5000)
         np.testing.assert_allclose(fs[sws] - fs[sws[0]], (f_or - f_or[sws[0]])[sws], atol=1e-6)
+
+
+def test_module_functions_see_in_place_edits_of_a_host_matrix():
+    """The reference's module-level functions are pure functions of the array they are handed (mbar_solvers.py:260-292).  The
+    drop-in keeps a device copy of a host matrix between calls; ONE element edited in place between two calls -- outside any
+    sampled spot check -- must give the oracle's NEW answer, and an unchanged array must not be uploaded again."""
+    ms.drop_resident_cache()
+    x_n, u_kn, N_k, s_n, _, _ = ts.config2(seed=3, K=24, N=240_000)
+    f = ts.harmonic_free_energies(np.linspace(1.0, 3.0, 24)) * 0.9
+    Nf = N_k.astype(float)
+    g0 = ms.mbar_gradient(u_kn, N_k, f)
+    up0 = ms._resident_cache.uploads
+    H0 = ms.mbar_hessian(u_kn, N_k, f)
+    assert ms._resident_cache.uploads == up0  # same bytes: the resident copy serves the second call
+    np.testing.assert_allclose(g0, oracle.mbar_gradient(u_kn, Nf, f), rtol=1e-10, atol=1e-8)
+    u_kn[3, 12_345] += 1.0
+    g1 = ms.mbar_gradient(u_kn, N_k, f)
+    assert ms._resident_cache.uploads == up0 + 1
+    np.testing.assert_allclose(g1, oracle.mbar_gradient(u_kn, Nf, f), rtol=1e-10, atol=1e-8)
+    assert np.max(np.abs(g1 - g0)) > 1e-6  # (the edit is visible in the answer: a stale copy would have failed above)
+    u_kn[5, 200_001:200_004] = np.inf  # a masked-out run of samples, the other in-place edit users make
+    g2 = ms.mbar_gradient(u_kn, N_k, f)
+    np.testing.assert_allclose(g2, oracle.mbar_gradient(u_kn, Nf, f), rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(ms.mbar_hessian(u_kn, N_k, f), oracle.mbar_hessian(u_kn, Nf, f), rtol=1e-9, atol=1e-8)
+    assert ms._resident_cache.uploads == up0 + 2 and len(ms._resident_cache.entries) == 1  # stale copies are dropped at once
+    assert np.max(np.abs(H0 - oracle.mbar_hessian(u_kn, Nf, f))) > 1e-9
+    ms.drop_resident_cache()
+
+
+def test_call_sequence_of_the_unchanged_reference_class_on_host_arrays(golden):
+    """What the reference's UNCHANGED ``MBAR`` does with ``pymbar.mbar.mbar_solvers`` re-bound to this module, call for call
+    (mbar.py:413 ``solve_mbar_for_all_states(self.u_kn, ...)``, :455 ``mbar_log_W_nk(self.u_kn, ...)``, :701-729 Theta from
+    ``exp(Log_W_nk)``, :910 ``mbar_log_W_nk`` again per expectation) -- host arrays in, through the C library, ONE upload --
+    against the reference's own results for config 5 (the reference tree itself cannot travel to the GPU box)."""
+    import copy
+
+    g = golden("config5_alch_K40_N95000.npz")
+    x_n, u_kn, N_k, s_n, _, _ = ts.config5(seed=0)
+    K = len(N_k)
+    ms.drop_resident_cache()
+    up0 = ms._resident_cache.uploads
+    u_self = np.array(u_kn, dtype=np.float64)                         # mbar.py:243
+    sws = np.where(N_k > 0)[0]                                         # mbar.py:383
+    protocol = copy.deepcopy(ms.DEFAULT_SOLVER_PROTOCOL)
+    for stage in protocol:                                             # mbar.py:391-406
+        stage.setdefault("options", dict())
+        stage["options"].setdefault("maxiter", 10000)
+        stage["options"].setdefault("verbose", False)
+    f_k = ms.solve_mbar_for_all_states(u_self, N_k, np.zeros(K), sws, protocol)   # mbar.py:413
+    Log_W_nk = ms.mbar_log_W_nk(u_self, N_k, f_k)                                  # mbar.py:455
+    again = ms.mbar_log_W_nk(u_self, N_k, f_k)                                     # mbar.py:910
+    assert ms._resident_cache.uploads == up0 + 1
+    assert Log_W_nk.shape == (u_kn.shape[1], K) and Log_W_nk.flags.f_contiguous and np.array_equal(Log_W_nk, again)
+    np.testing.assert_allclose(f_k, g["f_k"], rtol=1e-8, atol=1e-9)
+    W = np.exp(Log_W_nk)                                                            # mbar.py:702
+    np.testing.assert_allclose(W.sum(0), 1.0, rtol=1e-10)
+    np.testing.assert_allclose(W @ N_k, 1.0, rtol=1e-10)
+    Theta = oracle.covariance_theta(W, N_k, "svd-ew")                              # mbar.py:703 (restated in the oracle)
+    np.testing.assert_allclose(oracle.error_of_differences(Theta), g["dDelta_f_svd_ew"], rtol=1e-7, atol=1e-10)
+    ms.drop_resident_cache()

@@ -1,0 +1,157 @@
+"""Reference answers AT THE SIZES THE METRIC IS QUOTED ON (tests/golden/scale_*.npz, tests/golden/make_golden_scale.py).
+
+The fixtures hold what the UNMODIFIED reference (pymbar numpy backend) computes for BASELINE.json config 2 at full size
+(K=32, N=1e6), for the headline state count at K=128, N=1e6 (its whole class journey: MBAR(), Delta_f, dDelta_f) and for config
+3 ITSELF (K=128, N=1e7: the adaptive solve from zeros, ~16 min and ~50 GB on the build container).  Outputs only: the
+matrices are regenerated here from the seed by the host generator (legacy ``np.random.seed`` stream, identical across numpy
+versions -- pymbar/testsystems/harmonic_oscillators.py:154-188), uploaded, and solved with the DEFAULT options of the library
+(resident probability matrix, fused sweep, hipGraph batches), on one context and on 2 / 8 logical ranks.
+
+Tolerances (BASELINE.json north_star: Deltaf_ij within 1e-8 relative, fp64): ``Delta_f`` rtol 1e-8, ``dDelta_f`` rtol 1e-7,
+iteration / Newton-Raphson / self-consistent counts and the per-iteration choice identical to the reference's."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from pymbar_amd import mbar_solvers as ms  # noqa: E402
+from pymbar_amd import testsystems as ts  # noqa: E402
+from pymbar_amd.distributed import shard_bounds  # noqa: E402
+from tests.test_gpu_loopback import run_ranks  # noqa: E402
+
+DELTA_F_RTOL, DDELTA_F_RTOL = 1e-8, 1e-7
+
+
+def _delta(f):
+    return f[None, :] - f[:, None]
+
+
+def _assert_delta_f(f, f_ref, what):
+    # Delta_f_ij = f_j - f_i within 1e-8 relative; entries that are zero by construction (the diagonal) get 1e-12 absolute
+    np.testing.assert_allclose(_delta(f - f[0]), _delta(f_ref - f_ref[0]), rtol=DELTA_F_RTOL, atol=1e-12, err_msg=what)
+
+
+def _assert_counts(res, g, suffix=""):
+    assert res["success"] and bool(g["adaptive_success" if not suffix else "adaptive_success"])
+    assert res["iterations"] == int(g["adaptive_iters" + suffix])
+    assert res["nr_iter"] == int(g["adaptive_nr" + suffix]) and res["sci_iter"] == int(g["adaptive_sci" + suffix])
+    choices = g["adaptive_choices" + suffix]
+    # (the LAST iteration of a converged solve compares two gradient norms at round-off level: noise in the reference itself)
+    n = len(choices) - 1
+    assert np.array_equal(res["history"][:n, 0].astype(np.int8), choices[:n])
+
+
+def _mbar_journey(u_kn, N_k, g):
+    import pymbar_amd
+
+    m = pymbar_amd.MBAR(u_kn, N_k, copy=False)
+    try:
+        r = m.compute_free_energy_differences(uncertainty_method="svd-ew")
+        _assert_delta_f(m.f_k, g["f_k"], "MBAR().f_k")
+        np.testing.assert_allclose(r["Delta_f"], g["Delta_f"], rtol=DELTA_F_RTOL, atol=1e-12)
+        np.testing.assert_allclose(r["dDelta_f"], g["dDelta_f_svd_ew"], rtol=DDELTA_F_RTOL, atol=1e-12)
+    finally:
+        m.close()
+
+
+def _logical_ranks(u_kn, N_k, nranks, g, shards=None):
+    """The device-resident loop across ``nranks`` logical ranks (config-4-shaped column sharding, ONE all-reduce per iteration
+    on the stream -- what runs under RCCL across GPUs): same counts as the reference, same Delta_f, ranks bit-identical."""
+    from pymbar_amd.device import DeviceMatrix, LoopbackGroup
+
+    K, N = u_kn.shape
+    bounds = shards if shards is not None else [shard_bounds(N, r, nranks) for r in range(nranks)]
+    with LoopbackGroup(nranks) as grp:
+        def worker(r):
+            n0, n1 = bounds[r]
+            with DeviceMatrix.from_host(u_kn, columns=(n0, n1)) as dm:
+                dm.set_loopback(grp, r)
+                dm.set_Nk(N_k)
+                out = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+                dm.comm_destroy()
+                return out
+
+        ranks = run_ranks(nranks, worker)
+    for f, res in ranks[1:]:
+        assert np.array_equal(f, ranks[0][0]) and res["iterations"] == ranks[0][1]["iterations"]
+    f, res = ranks[0]
+    _assert_counts(res, g)
+    _assert_delta_f(f, g["f_adaptive"], f"{nranks} logical ranks")
+
+
+def test_config2_full_size_matches_the_reference(golden):
+    """BASELINE.json config 2 as quoted: K=32, N=1e6.  Pure self-consistent iteration (92 iterations in the reference), the
+    adaptive solve with min_sc_iter 0 and 2, and the class journey."""
+    from pymbar_amd.device import DeviceMatrix
+
+    g = golden("scale_config2_K32_N1e6.npz")
+    x_n, u_kn, N_k, s_n, _, _ = ts.config2(seed=int(g["seed"]))
+    assert np.array_equal(N_k, g["N_k"])
+    K = u_kn.shape[0]
+    with DeviceMatrix.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        f_sci, r_sci = dm.solve_sci(np.zeros(K), tol=1e-12)
+        assert r_sci["success"] and r_sci["iterations"] == int(g["sci_iters"])
+        _assert_delta_f(f_sci, g["f_sci"], "pure SCI")
+        f, res = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+        _assert_counts(res, g)
+        _assert_delta_f(f, g["f_adaptive"], "adaptive")
+        f2, res2 = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=2, history_rows=64)
+        _assert_counts(res2, g, "_msc2")
+        _assert_delta_f(f2, g["f_adaptive_msc2"], "adaptive, min_sc_iter=2")
+    _mbar_journey(u_kn, N_k, g)
+    _logical_ranks(u_kn, N_k, 2, g)
+
+
+def test_128_states_1e6_samples_match_the_reference(golden):
+    """The headline state count at the largest N the reference's whole class journey is comfortable with (K=128, N=1e6):
+    adaptive from zeros on one context, on 2 and on 8 logical ranks (config-4-shaped sharding; N / 8 = 125 000 is not a multiple
+    of the 16-sample tile, one more run has a rank with an EMPTY shard), and MBAR() -> Delta_f / dDelta_f."""
+    from pymbar_amd.device import DeviceMatrix
+
+    g = golden("scale_K128_N1e6.npz")
+    O_k, K_k, N_k = ts.config3_params(128, 1_000_000)
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn(O_k, K_k, N_k, seed=int(g["seed"]))
+    assert np.array_equal(N_k, g["N_k"])
+    K, N = u_kn.shape
+    with DeviceMatrix.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        f, res = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+        _assert_counts(res, g)
+        _assert_delta_f(f, g["f_adaptive"], "adaptive")
+        assert res["builds"] == 1 and res["gram_sweeps"] == 0  # (the default path: P mode, fused, no rejected speculation)
+    # the module-level function on the HOST array (upload + solve: what the unchanged reference class calls)
+    f_host, r_host = ms.solve_mbar_once(u_kn, N_k, np.zeros(K), method="adaptive", tol=1e-12, options=dict(min_sc_iter=0))
+    _assert_delta_f(f_host, g["f_adaptive"], "solve_mbar_once(host array)")
+    _mbar_journey(u_kn, N_k, g)
+    _logical_ranks(u_kn, N_k, 2, g)
+    _logical_ranks(u_kn, N_k, 8, g)
+    ragged = [(0, 100_003), (100_003, 100_003), (100_003, 333_329), (333_329, 600_000), (600_000, 600_017), (600_017, 777_777),
+              (777_777, 999_999), (999_999, N)]  # (an empty shard, shards of 14 and 1 columns, nothing tile-aligned)
+    _logical_ranks(u_kn, N_k, 8, g, shards=ragged)
+
+
+def test_config3_itself_matches_the_reference(golden):
+    """BASELINE.json config 3 as quoted: K=128, N=1e7 (10.24 GB regenerated on the host from the seed, ~30 s), solved with the
+    default options; the reference's own f_k for this matrix is the fixture."""
+    from pymbar_amd.device import DeviceMatrix
+
+    g = golden("scale_config3_K128_N1e7.npz")
+    N = int(g["N_k"].sum())
+    O_k, K_k, N_k = ts.config3_params(128, N)
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn(O_k, K_k, N_k, seed=int(g["seed"]))
+    del x_n, s_n
+    K = u_kn.shape[0]
+    with DeviceMatrix.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        f, res = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+        _assert_counts(res, g)
+        _assert_delta_f(f, g["f_adaptive"], "config 3, one context")
+        assert res["builds"] == 1 and res["gram_sweeps"] == 0
+        # the same answer from the classic sweeps on u (no resident probability matrix) and from a warm start
+        dm.set_option("pmode", 0)
+        f0, res0 = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+        _assert_counts(res0, g)
+        _assert_delta_f(f0, g["f_adaptive"], "config 3, classic sweeps")
+        dm.set_option("pmode", 1)
+    _logical_ranks(u_kn, N_k, 8, g)

@@ -248,3 +248,154 @@ def test_threaded_host_helpers_and_blas_limit():
     finally:
         mbar_mod._BLAS_CONTROLLER = old
     assert limits == [1, 1, 1, 4, 4, 4]
+
+
+def test_host_digest_sees_every_byte():
+    """``mbar_host_digest`` (host-only entry point of the C library): thread-count independent, length-sensitive, and a change
+    of ONE element anywhere -- first, last, the ragged tail of a chunk -- changes it."""
+    from pymbar_amd import _lib
+
+    rng = np.random.RandomState(0)
+    a = rng.standard_normal((7, 300_001))  # (16.8 MB: several 1 MiB chunks and a ragged tail)
+    d = _lib.host_digest(a)
+    assert len(d) == 16 and _lib.host_digest(a, threads=1) == d and _lib.host_digest(a, threads=3) == d
+    for idx in [(0, 0), (6, 300_000), (3, 12_345), (5, 131_072)]:
+        old = a[idx]
+        a[idx] = np.nextafter(old, np.inf)
+        assert _lib.host_digest(a) != d, idx
+        a[idx] = old
+        assert _lib.host_digest(a) == d
+    assert _lib.host_digest(np.zeros(3)) != _lib.host_digest(np.zeros(4))
+    assert _lib.host_digest(np.zeros(0)) == _lib.host_digest(np.zeros(0))
+
+
+def test_resident_cache_never_answers_for_an_edited_matrix(monkeypatch, golden):
+    """The module-level functions are pure functions of the array they are handed (mbar_solvers.py:260-292): the device copy a
+    host matrix got on its first call is re-used while the array is unchanged and dropped when ANY element changed -- including
+    one that no sampled digest would see."""
+    import pymbar_amd.device
+
+    uploads = []
+
+    class Counting(OracleMatrix):
+        closed = 0
+
+        @classmethod
+        def from_host(cls, u_kn, device=None, columns=None):
+            uploads.append(np.shape(u_kn))
+            return super().from_host(u_kn, device=device, columns=columns)
+
+        def close(self):
+            Counting.closed += 1
+
+    monkeypatch.setattr(pymbar_amd.device, "DeviceMatrix", Counting)
+    ms.drop_resident_cache()
+    x_n, u_kn, N_k, s_n, _, _ = ts.config2(seed=3, K=6, N=30_000)
+    f = np.linspace(0.0, 0.5, 6)
+    g0 = ms.mbar_gradient(u_kn, N_k, f)
+    g1 = ms.mbar_gradient(u_kn, N_k, f)
+    assert len(uploads) == 1 and np.array_equal(g0, g1)
+    np.testing.assert_allclose(g0, oracle.mbar_gradient(u_kn, N_k, f), rtol=1e-12, atol=1e-9)
+    u_kn[3, 12_345] += 1.0  # (outside every sample a spot-check digest would take)
+    g2 = ms.mbar_gradient(u_kn, N_k, f)
+    assert len(uploads) == 2 and Counting.closed == 1  # re-uploaded, and the stale copy went away at once
+    np.testing.assert_allclose(g2, oracle.mbar_gradient(u_kn, N_k, f), rtol=1e-12, atol=1e-9)
+    assert not np.array_equal(g2, g0)
+    # an entry in use is not closed by eviction: the last user closes it
+    monkeypatch.setenv("PYMBAR_AMD_RESIDENT_CACHE", "1")
+    other = u_kn[:, :1000].copy()
+    with ms._Resident(u_kn) as h:
+        closed_before = Counting.closed
+        ms.mbar_gradient(other, N_k, f)  # evicts u_kn's entry (one entry allowed) while h is in use
+        assert Counting.closed == closed_before
+        np.testing.assert_allclose(ms.mbar_gradient(h, N_k, f), g2, rtol=0, atol=0)
+    assert Counting.closed == closed_before + 1
+    # switched off: every call uploads its own temporary
+    monkeypatch.setenv("PYMBAR_AMD_RESIDENT_CACHE", "0")
+    ms.drop_resident_cache()
+    n = len(uploads)
+    ms.mbar_gradient(u_kn, N_k, f)
+    ms.mbar_gradient(u_kn, N_k, f)
+    assert len(uploads) == n + 2
+
+
+def test_resident_cache_is_thread_safe(monkeypatch):
+    import threading
+
+    import pymbar_amd.device
+
+    monkeypatch.setattr(pymbar_amd.device, "DeviceMatrix", OracleMatrix)
+    ms.drop_resident_cache()
+    x_n, u_kn, N_k, s_n, _, _ = ts.config2(seed=4, K=5, N=5000)
+    mats = [u_kn, u_kn[:, :4000].copy(), u_kn[:, 1000:].copy()]
+    f = np.linspace(0.0, 0.4, 5)
+    want = [oracle.mbar_gradient(m, N_k, f) for m in mats]
+    errors = []
+
+    def worker(seed):
+        rng = np.random.RandomState(seed)
+        try:
+            for _ in range(30):
+                i = rng.randint(3)
+                np.testing.assert_allclose(ms.mbar_gradient(mats[i], N_k, f), want[i], rtol=1e-12, atol=1e-9)
+        except Exception as exc:  # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+
+
+def test_state_index_groups_accepts_what_the_reference_masks_accept():
+    """``x_kindices == k`` (mbar.py:424, :1958-1967) works for float-typed indices and ignores values outside [0, K)."""
+    from pymbar_amd.utils import state_index_groups
+
+    K = 4
+    rng = np.random.RandomState(2)
+    for x in (np.repeat(np.arange(K), 5),                          # default layout: ranges
+              rng.randint(0, K, size=50),                           # shuffled
+              rng.randint(0, K, size=50).astype(np.float64),        # float-typed (np.bincount would raise TypeError)
+              np.concatenate([rng.randint(-2, K + 2, size=60), [K, -1]]),  # out of range (np.bincount raises on negatives)
+              np.array([0.0, 1.5, 2.0, np.nan, 3.0, 1.0]),          # non-integral / NaN match no state
+              np.zeros(0, dtype=int)):
+        groups = state_index_groups(x, K)
+        assert len(groups) == K
+        for k in range(K):
+            np.testing.assert_array_equal(np.asarray(list(groups[k]), dtype=np.int64), np.where(np.asarray(x) == k)[0])
+
+
+def test_label_samples_paths_agree():
+    """Tabulated grid, sorted cells and (beyond int64 cell numbers) sorted index tuples give the labels of a plain loop."""
+    from pymbar_amd import fes
+
+    def naive(x_n, edges):
+        x_n = np.atleast_2d(np.asarray(x_n, dtype=float).T).T if np.ndim(x_n) == 1 else np.asarray(x_n, dtype=float)
+        if x_n.ndim == 1:
+            x_n = x_n[:, None]
+        seen, labels, grid = {}, [], []
+        for row in x_n:
+            idx = tuple(int(np.digitize(row[d], edges[d]) - 1) for d in range(len(edges)))
+            key = None if min(idx) < 0 else idx
+            if key not in seen:
+                seen[key] = len(seen)
+                grid.append(key)
+            labels.append(seen[key])
+        return np.array(labels), grid
+
+    rng = np.random.RandomState(5)
+    x1 = rng.uniform(-1.5, 1.5, size=3000)
+    e1 = [np.linspace(-1, 1, 11)]
+    lab, grid = fes.label_samples(x1, e1[0])                    # coarse grid, many samples: tabulated
+    nl, ng = naive(x1[:, None], e1)
+    assert np.array_equal(lab, nl) and grid == ng
+    x3 = rng.uniform(-1.2, 1.2, size=(200, 3))
+    e3 = [np.linspace(-1, 1, 41)] * 3                           # 74k cells for 200 samples: sorted cells
+    lab, grid = fes.label_samples(x3, e3)
+    nl, ng = naive(x3, e3)
+    assert np.array_equal(lab, nl) and grid == ng
+    x12 = rng.uniform(-1.2, 1.2, size=(150, 12))
+    e12 = [np.linspace(-1, 1, 60)] * 12                         # 61^12 cells > 2^62: sorted tuples (ravel_multi_index would raise)
+    lab, grid = fes.label_samples(x12, e12)
+    nl, ng = naive(x12, e12)
+    assert np.array_equal(lab, nl) and grid == ng

@@ -39,6 +39,14 @@ def _worker(rank, world, port, out_dir, blocker_port):
     out["sum"] = group.allreduce(a.copy(), "sum")
     out["max"] = group.allreduce(a.copy(), "max")
     out["min"] = group.allreduce(a.copy(), "min")
+    import pymbar_amd.distributed as dist
+
+    keep = dist._MAX_MSG
+    dist._MAX_MSG = 4096  # (every rank alike) an array beyond the message bound travels in pieces
+    big = np.arange(3001, dtype=np.float64).reshape(3001, 1) * (rank + 1.0)
+    out["big_ok"] = bool(np.array_equal(group.allreduce(big.copy(), "sum"),
+                                        np.arange(3001, dtype=np.float64).reshape(3001, 1) * (world * (world + 1) / 2.0)))
+    dist._MAX_MSG = keep
     group.barrier()
 
     x_n, u_kn, N_k, s_n = ts.harmonic_u_kn(np.linspace(0, 2, 6), np.linspace(1, 3, 6), [300, 200, 0, 250, 150, 100], seed=9)
@@ -86,7 +94,7 @@ def test_hostgroup_collectives_and_sharded_solve(tmp_path, world):
     rs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     base = np.arange(5, dtype=np.float64)
     for r in rs:
-        assert bool(r["payload_ok"]) and bool(r["none_ok"]) and str(r["kind"]) == "host"
+        assert bool(r["payload_ok"]) and bool(r["none_ok"]) and str(r["kind"]) == "host" and bool(r["big_ok"])
         np.testing.assert_array_equal(r["sum"], world * base + 10.0 * sum(range(world)))
         np.testing.assert_array_equal(r["max"], base + 10.0 * (world - 1))
         np.testing.assert_array_equal(r["min"], base)
@@ -120,3 +128,25 @@ def test_no_torch_in_the_product_package():
             if fn.endswith(".py"):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(import|from)\s+torch\b", src, re.M), os.path.join(dirpath, fn)
+
+
+def test_listener_address_choice(monkeypatch):
+    """Rank 0 listens on loopback for a single node, on the interface MASTER_ADDR names across hosts, and on the wildcard
+    address when that name resolves to a loopback alias (Debian's 127.0.1.1 line for the own hostname) or cannot be resolved;
+    ``MBAR_RDZV_BIND`` overrides."""
+    sys.path.insert(0, ROOT)
+    import pymbar_amd.distributed as dist
+
+    monkeypatch.delenv("MBAR_RDZV_BIND", raising=False)
+    assert dist._bind_candidates("127.0.0.1") == ["127.0.0.1"] and dist._bind_candidates("localhost") == ["127.0.0.1"]
+    monkeypatch.setattr(dist.socket, "gethostbyname", lambda name: {"node7": "10.1.2.3", "debian-host": "127.0.1.1"}[name])
+    assert dist._bind_candidates("node7") == ["10.1.2.3", "0.0.0.0"]  # (a VIP that is no local interface: bind fails, wildcard next)
+    assert dist._bind_candidates("debian-host") == ["0.0.0.0"]
+
+    def boom(name):
+        raise OSError("unresolvable")
+
+    monkeypatch.setattr(dist.socket, "gethostbyname", boom)
+    assert dist._bind_candidates("k8s-service") == ["0.0.0.0"]
+    monkeypatch.setenv("MBAR_RDZV_BIND", "192.168.0.9")
+    assert dist._bind_candidates("node7") == ["192.168.0.9"]
