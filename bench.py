@@ -180,6 +180,85 @@ def api_end_to_end(K, N_total, seed, dev, O_k, K_k, N_k):
             "constructor_with_private_host_copy_s": t_ctor_copy, "host_bytes": 8.0 * K * N_total, "finite": ok, **stats}
 
 
+def config2_object(dev, seed):
+    """BASELINE.json config 2 (K=32, N=1e6, fp64): the device-resident self-consistent iteration (mbar_solvers.py:231-242 in a
+    loop; the reference's stopping rule :627-631).  An iteration reads the matrix once: 8 K N bytes against HBM."""
+    from pymbar_amd import testsystems as ts
+    from pymbar_amd.device import DeviceMatrix
+
+    K, N = 32, 1_000_000
+    O_k, K_k, N_k = ts.config3_params(K=K, N=N)
+    with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=seed, n_global0=0, N_local=N, device=dev) as dm:
+        dm.set_Nk(N_k)
+        f0 = np.zeros(K)
+        dm.solve_sci(f0, tol=1e-12, maxiter=64, check_convergence=False)  # warm-up: graph capture, first-touch
+        iters = 1024
+        dm.device_synchronize()
+        t0 = time.perf_counter()
+        dm.solve_sci(f0, tol=1e-12, maxiter=iters, check_convergence=False)
+        dm.device_synchronize()
+        el = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        f_c, r_c = dm.solve_sci(f0, tol=1e-12)
+        t_conv = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        f_a, r_a = dm.solve_adaptive(f0, tol=1e-12, min_sc_iter=0)
+        t_ad = time.perf_counter() - t2
+        us = 1e6 * el / iters
+        return {
+            "workload": f"config2: harmonic ladder K={K}, N={N}, fp64, generated in HBM; pure self-consistent iteration, device-resident",
+            "sci_iterations_per_s": iters / el, "us_per_iteration": us, "iterations_timed": iters,
+            "roofline": {"bound": "hbm", "achieved": 8.0 * K * N / (us * 1e-6) * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": 8.0 * K * N / (us * 1e-6) * 1e-9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": 8.0 * K * N,
+                         "note": "whole iteration (sweep + update + launch gaps), not the sweep kernel alone"},
+            "sci_iterations_to_converge": int(r_c["iterations"]), "sci_converged": bool(r_c["success"]),
+            "sci_wallclock_to_converge_ms": 1e3 * t_conv,
+            "adaptive_iterations_to_converge": int(r_a["iterations"]), "adaptive_wallclock_to_converge_ms": 1e3 * t_ad,
+            "max_abs_difference_sci_vs_adaptive": float(np.max(np.abs(f_c - f_a))),
+            "max_abs_error_vs_analytic_f": float(np.max(np.abs(f_a - ts.harmonic_free_energies(K_k)))),
+        }
+
+
+def config5_object(dev):
+    """BASELINE.json config 5 (alchemical shape: K=40, N=95 000, two unsampled states): what a user of the class sees, host
+    arrays in -- ``MBAR(u_kn, N_k)`` (upload + default protocol) + ``compute_free_energy_differences()`` (covariance sweep on the
+    matrix cores + host eigh / pinv), steady state (median of 7 after one warm-up object)."""
+    import pymbar_amd
+    from pymbar_amd import testsystems as ts
+    from pymbar_amd.device import DeviceMatrix
+
+    x_n, u_kn, N_k, s_n, O_k, K_k = ts.config5(seed=0)
+    K, N = u_kn.shape
+    ctor, diff = [], []
+    for rep in range(8):
+        t0 = time.perf_counter()
+        m = pymbar_amd.MBAR(u_kn, N_k, device=dev)
+        t1 = time.perf_counter()
+        r = m.compute_free_energy_differences()
+        t2 = time.perf_counter()
+        m.close()
+        if rep:
+            ctor.append(t1 - t0)
+            diff.append(t2 - t1)
+    with DeviceMatrix.from_host(u_kn, device=dev) as dm:
+        dm.set_Nk(N_k)
+        dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+        solves = []
+        for _ in range(7):
+            dm.set_option("pcache", 0)
+            t0 = time.perf_counter()
+            f_a, r_a = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+            solves.append(time.perf_counter() - t0)
+    return {
+        "workload": f"config5: alchemical-shaped ladder K={K}, N={N} (states 7 and 23 unsampled), host arrays in",
+        "constructor_ms": 1e3 * float(np.median(ctor)), "compute_free_energy_differences_ms": 1e3 * float(np.median(diff)),
+        "class_journey_ms": 1e3 * float(np.median(np.add(ctor, diff))),
+        "adaptive_solve_resident_us": 1e6 * float(np.median(solves)), "adaptive_iterations": int(r_a["iterations"]),
+        "adaptive_us_per_iteration": 1e6 * float(np.median(solves)) / max(1, int(r_a["iterations"])),
+        "finite": bool(np.all(np.isfinite(r["dDelta_f"]))),
+    }
+
+
 def spawn_ranks(n):
     """``python bench.py --gpus N`` without a launcher: start N ranks of this script (one per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set as a launcher would) and wait.  Returns the exit code: 3 if the box has fewer than N GPUs, the
@@ -234,9 +313,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="columns for the CPU baseline (0 = skip)")
     ap.add_argument("--api-e2e", type=int, default=1, help="also time MBAR(u_kn_host, N_k) end to end (1 GPU only; 0 = skip)")
-    ap.add_argument("--staging", type=int, default=0)
-    ap.add_argument("--lse-variant", type=int, default=1)
-    ap.add_argument("--gram-variant", type=int, default=2)
+    ap.add_argument("--small-configs", type=int, default=1,
+                    help="also measure BASELINE.json configs 2 and 5 (1 GPU only, < 1 s of GPU time together; 0 = skip)")
     ap.add_argument("--device-loop", type=int, default=1, help="0 = host-driven adaptive loop (A/B)")
     ap.add_argument("--pmode", type=int, default=1,
                     help="1 = the device-resident loop sweeps the resident probability matrix P = exp(a0 - u - logden(a0)) "
@@ -278,14 +356,13 @@ def main():
     dev = local_rank % ndev  # one rank per GPU under the launcher; wraps only when ranks outnumber devices (testing)
     info = device_info(dev)
     dm = DeviceMatrix.harmonic(O_k, K_k, N_k, seed=args.seed, n_global0=n0, N_local=n_loc, device=dev)
-    dm.set_option("staging", args.staging)
-    dm.set_option("lse_variant", args.lse_variant)
-    dm.set_option("gram_variant", args.gram_variant)
     dm.set_option("device_loop", args.device_loop)
     dm.set_option("pmode", args.pmode)
     dm.set_option("fused", args.fused)
     dm.set_option("pcache", 0)  # every solver call of the timed region builds its own probability matrix (no warm starts)
-    dm.set_option("timing", 1)  # HIP-event pairs around the sweeps (off by default in the library)
+    # HIP-event pairs around the sweeps (off by default in the library); with several ranks also around the reduction, the
+    # all-reduce and the Newton / selection launches, so that a multi-GPU line explains where its iteration goes
+    dm.set_option("timing", 3 if world > 1 else 1)
     dm.set_option("graph", 0)  # eager launches: per-kernel HIP-event timers inside the timed region (the GPU queue never
     #                            runs dry at this size: an iteration is ~5 ms of kernels against ~0.1 ms of enqueueing)
     dm.set_Nk(N_k)
@@ -357,7 +434,7 @@ def main():
         Nk4 = Nk4.copy()
         Nk4[-1] += N4 - int(Nk4.sum())
         d4 = DeviceMatrix.harmonic(O4, K4, Nk4, seed=args.seed, n_global0=a0, N_local=a1 - a0, device=dev)
-        for key, val in (("staging", args.staging), ("device_loop", args.device_loop), ("pmode", args.pmode), ("fused", args.fused),
+        for key, val in (("device_loop", args.device_loop), ("pmode", args.pmode), ("fused", args.fused),
                          ("pcache", 0), ("timing", 1), ("graph", 0)):
             d4.set_option(key, val)
         d4.set_Nk(Nk4)
@@ -412,6 +489,14 @@ def main():
         dm = None
         e2e = api_end_to_end(K, N_total, args.seed, dev, O_k, K_k, N_k)
 
+    config2 = config5 = None
+    if rank == 0 and world == 1 and args.small_configs:
+        if dm is not None:
+            dm.close()
+            dm = None
+        config2 = config2_object(dev, args.seed)
+        config5 = config5_object(dev)
+
     if rank == 0:
         it_per_s = args.steps / elapsed
         ms_step = 1e3 * elapsed / args.steps
@@ -420,7 +505,7 @@ def main():
         fus_ms, fus_n = timing.get("fused", (0.0, 0))
         # (the device-resident loop, hence P mode and the fused sweep, needs RCCL or a single rank; with the host transport the
         # host-driven loop and its classic sweeps run)
-        pm = bool(args.pmode and args.device_loop and args.staging == 0 and allreduce in ("none", "rccl"))
+        pm = bool(args.pmode and args.device_loop and allreduce in ("none", "rccl"))
         fused = bool(pm and args.fused and fus_n > 0)
         flops = float(n_loc) * K * (K + 1)           # symmetric Gram: K(K+1)/2 entries x 2 flop x N (this rank's shard)
         bytes_pass = 8.0 * K * n_loc                 # one read of the shard per sweep
@@ -467,7 +552,7 @@ def main():
             tr_g, src_g = pmc_traffic("k_gram<", K, n_loc)
             tr_l, src_l = pmc_traffic("k_psweep<8, 2" if pm else "k_lse<8, 2", K, n_loc)
             roof = {
-                "kernel": ({0: "k_gram_xchg<8>", 1: "k_gram_pair<8>"}.get(args.gram_variant, "k_gram<8,8> one wave per SIMD" + (", operands P / s" if pm else ", operands by table exp")) + " (fp64 MFMA W^T W)") if K == 128 else "k_gram",
+                "kernel": ("k_gram<8,8> one wave per SIMD" + (", operands P / s" if pm else ", operands by table exp") + " (fp64 MFMA W^T W)") if K == 128 else "k_gram",
                 "bound": "mfma", "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": tr_g,
                 "traffic_source": f"committed PMC pass {src_g} (not collected in this run)" if src_g else None,
@@ -538,9 +623,23 @@ def main():
             "max_abs_error_vs_analytic_f": err_analytic,
             "gnorm_at_solution": float(conv["gnorm"]),
             "api_end_to_end": e2e,
+            "config2": config2,
             "config4": config4,
+            "config5": config5,
         }
         out.update(extra)
+        if world > 1:
+            def per_launch(name):
+                ms, n = timing.get(name, (0.0, 0))
+                return {"ms_per_iteration": ms / args.steps, "launches": n} if n else None
+            out["iteration_split_rank0"] = {
+                "note": "HIP-event pairs on rank 0's stream around each section of the device-resident iteration (timing level 3); "
+                        "the all-reduce interval includes waiting for the slowest rank's sweep",
+                "sweep": per_launch("fused") or per_launch("lse"), "separate_gram_sweep": per_launch("gram"),
+                "build_sweep_once_per_call": per_launch("other"),
+                "reduce": per_launch("reduce"), "all_reduce": per_launch("comm"), "newton_and_select": per_launch("newton"),
+                "all_reduce_doubles": int(2 * K + 2 + (K // 16) * (K // 16 + 1) // 2 * 256) if fused else None,
+            }
         if cpu is not None:
             out["speedup_vs_cpu_baseline"] = it_per_s / cpu["value"]
         print(json.dumps(out))

@@ -50,7 +50,9 @@ typedef struct mbar_ctx mbar_ctx;
 #define MBAR_TIMER_REDUCE 2 /* partial-sum reductions                                      */
 #define MBAR_TIMER_OTHER 3  /* logW writer, robust per-state LSE, generator, P-mode build  */
 #define MBAR_TIMER_FUSED 4  /* fused sweep of the adaptive loop (candidates + MFMA Gram)   */
-#define MBAR_TIMER_COUNT 5
+#define MBAR_TIMER_NEWTON 5 /* K x K Newton solve + candidate selection (timing level 3 only)   */
+#define MBAR_TIMER_COMM 6   /* the per-iteration all-reduce on the stream (timing level 3 only) */
+#define MBAR_TIMER_COUNT 7
 
 /* ---- library / device -------------------------------------------------------------------- */
 int mbar_version(void);
@@ -77,41 +79,45 @@ int mbar_cache_trim(void);
 int mbar_host_digest(const void* data, int64_t nbytes, int threads, uint64_t* out2);
 /* hipDeviceSynchronize on `device` (every stream of every context): the bracket of a timed region. */
 int mbar_device_synchronize(int device);
-/* Tuning / test knobs (defaults are the measured best; every variant is parity-tested):
- *   "staging"        0 = LDS-DMA tiles (default), 1 = through registers
+/* Tuning / test knobs.  Every key selects between code paths that are BOTH needed somewhere (a fallback when memory is short,
+ * a transport that needs the host in the loop, a state count outside a kernel's range), so that tests and A/B measurements can
+ * force the path a default configuration would not take; the defaults are the measured best.  (Rounds 1-3 carried further keys
+ * for kernel variants that were measured never-best -- "staging", "lse_variant", "gram_variant", "persistent" -- removed in
+ * round 4 with their kernels; profiles/README.md keeps the measurements.)
  *   "grid_blocks"    0 = auto
- *   "force_generic"  1 = layout-agnostic fallback kernels for any K
- *   "check_finite"   default 1
- *   "lse_variant"    evaluation sweep for 5-8 blocks of 16 states: 1 = one tile stream per wave (default),
- *                    0 = paired waves, 2 / 3 = early refill with one / two tile buffers
- *   "gram_variant"   full 128-state Gram panel: 2 = one wave per SIMD, pinned accumulator classes (default),
- *                    0 = operand exchange between paired waves, 1 = paired waves, duplicate operands
- *   "small_k_kernel" 1 = one-sample-per-lane sweep for K <= 32, single candidate (default), 0 = off
- *   "wide_k_kernel"  1 = single-buffer sweep with four waves per CU for 129 <= K <= 256 (default), 0 = off
- *   "device_loop"    1 = adaptive iterations run device-resident where possible (default), 0 = host-driven loop
+ *   "force_generic"  1 = layout-agnostic fallback kernels for any K (what K > 512 runs)
+ *   "check_finite"   default 1: NaN / -inf scan of the matrix after every upload
+ *   "small_k_kernel" 1 = one-sample-per-lane sweep for K <= 32, single candidate (default), 0 = the general sweep
+ *   "wide_k_kernel"  1 = single-buffer sweep with four waves per CU for 129 <= K <= 256 (default), 0 = the general sweep
+ *   "device_loop"    1 = adaptive iterations run device-resident where possible (default), 0 = host-driven loop (what the
+ *                    host all-reduce transport and K > 256 run)
  *   "adapt_batch"    adaptive iterations enqueued between two looks at the control words (default 8)
- *   "fused"          1 = in P mode ONE sweep per iteration: the candidate sweep also accumulates the Gram matrix of the
- *                    Newton-Raphson candidate, the separate Gram sweep runs only when that candidate is rejected (default)
  *   "pmode"          1 = the device-resident loop keeps P = exp(a0 - u - logden(a0)) resident (one more K x N array, built
  *                    once per solve) and sweeps that: no exponentials in the loop (default); 0 = sweeps recompute them from u
+ *                    (what runs when P does not fit on some rank)
+ *   "fused"          1 = in P mode ONE sweep per iteration: the candidate sweep also accumulates the Gram matrix of the
+ *                    candidate about to be accepted, a separate Gram sweep runs only when that speculation is rejected
+ *                    (default); 0 = two sweeps per iteration on P (evaluation + Gram): the A/B of the fusion
  *   "gram_quad"      1 = 129 <= K <= 256: the Gram sweep reads the matrix ONCE, the four waves of a workgroup share the tile
- *                    stream and split the panel's 78 / 136 blocks (default); 0 = 128-state panels + 64 x 128 rectangles (2.5 reads)
+ *                    stream and split the panel's 78 / 136 blocks (default); 0 = 128-state panels + 64 x 128 rectangles
+ *                    (2.5 reads: what K > 256 runs)
  *   "device_loop_wide" 1 = the device-resident loop also serves 129 <= K <= 256 (Newton system by a blocked Cholesky
  *                    factorisation in device memory; default); 0 = host-driven loop there
- *   "pcache"         1 = the resident probability matrix outlives the solve that built it: a later adaptive solve on the same
- *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
- *                    one fused sweep instead of the build sweep (default); 0 = every solve builds
- *   "persistent"     1 = small problems (up to 80 states, up to ~1e6 samples, one rank): the whole device-resident loop runs in
- *                    ONE launch of a persistent grid with grid barriers between its phases (parity-tested; measured slower than
- *                    the five launches per iteration it replaces: 77 against 51 us at K=40, N=95000); 0 = default
  *   "wide_pmode"     1 = 129 <= K <= 256 also keep a resident probability matrix and run ONE fused sweep per iteration
- *                    (k_fused_quad; default); 0 = two sweeps on u there (one-read Gram + evaluation sweep)
+ *                    (k_fused_quad; default); 0 = two sweeps on u there (what runs when P does not fit)
  *   "quad_trim"      1 = 129 .. 160 and 193 .. 224 states: the one-read Gram / fused sweeps skip the two padding blocks of the
  *                    192- / 256-row panel (default); 0 = the whole panel
+ *   "pcache"         1 = the resident probability matrix outlives the solve that built it: a later adaptive solve on the same
+ *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
+ *                    one fused sweep instead of the build sweep (default); 0 = every solve builds (cold-solve timings)
+ *   "merge_select"   1 = the selection of iteration i and the Newton solve of iteration i + 1 share a launch (default)
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
  *   "timing"         HIP-event timers (mbar_ctx_timing): 0 = off (default: an event pair per sweep costs ~10 us, a fifth of an
  *                    iteration at the problem sizes pymbar is mostly used on), 1 = event records around a launch, 2 = events
- *                    bound to the kernel dispatch in the device-resident loop (no marker packets between kernels) */
+ *                    bound to the kernel dispatch in the device-resident loop (no marker packets between kernels), 3 = level 1 plus
+ *                    event pairs around the reduction, the all-reduce and the Newton / selection launches of every iteration of
+ *                    the device-resident loop (the per-iteration split {sweep, reduce, all-reduce, Newton + selection} that
+ *                    explains a multi-GPU run; ~6 more marker packets per iteration) */
 int mbar_ctx_set_option(mbar_ctx* ctx, const char* key, int64_t value);
 
 /* ---- data ---------------------------------------------------------------------------------- */

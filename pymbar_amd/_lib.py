@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MBAR_HIP_LIBRARY") or os.path.join(HERE, "csrc", "lib
 MBAR_OK = 0
 EVAL_GRAM = 1
 EVAL_USE_OFFSET = 2
-TIMER_LSE, TIMER_GRAM, TIMER_REDUCE, TIMER_OTHER, TIMER_FUSED = 0, 1, 2, 3, 4
+TIMER_LSE, TIMER_GRAM, TIMER_REDUCE, TIMER_OTHER, TIMER_FUSED, TIMER_NEWTON, TIMER_COMM = 0, 1, 2, 3, 4, 5, 6
 
 
 class BackendUnavailable(RuntimeError):

@@ -273,18 +273,15 @@ struct mbar_ctx {
     size_t part_g_doubles = 0;
     double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
     double* chol = nullptr;         // workspace of the blocked Cholesky Newton solve (129 .. 256 states)
-    double* sm_buf = nullptr;       // persistent small-problem loop: per-workgroup records [2][grid][E] | reduced [2][E]
-    size_t sm_doubles = 0;
-    unsigned* sm_bar = nullptr;     // ... its grid-barrier counter and timeout flag
     // P outlives the solve that built it: a later solve on the same matrix whose start lies within the window of the anchor
     // (bootstrap replicates, protocol stages, continuation) starts with ONE fused sweep instead of the build sweep
     std::vector<double> last_psum;  // per-state sums at the f the last adaptive solve returned (empty: none)
     bool P_valid = false;
     std::vector<double> P_a0;       // anchor of the resident probability matrix: aden at the build point (Kp entries)
     // options
-    int64_t opt_staging = 0, opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
-    int64_t opt_lse_variant = 1, opt_gram_variant = 2;  // measured best: independent-wave LSE sweep, single-wave Gram (pinned accumulator classes)
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_persistent = 0, opt_merge_select = 1, opt_wide_pmode = 1, opt_quad_trim = 1;
+    const int64_t opt_staging = 0;  // (tiles are staged by LDS-DMA; the register-staged kernels of rounds 1-3 are gone)
+    int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_wide_pmode = 1, opt_quad_trim = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -551,13 +548,12 @@ int agree_with_rank0(mbar_ctx* c, double* v, int64_t count) {
 }
 
 // ---- evaluation building blocks -----------------------------------------------------------------
-// variants 2 / 3 (early refill of the tile buffer) exist for LDS-DMA staging only
-// Row pitches from 7.6e7 samples up need 64-bit lane offsets in the tile DMA; only the default kernels are
-// instantiated for that, so the optional variants fall back to them.
+// Which specialised evaluation kernels this context qualifies for (flags for lse_geometry).  Row pitches from 7.6e7 samples up
+// need 64-bit lane offsets in the tile DMA; only the general kernels are instantiated for that.
 bool wide_pitch(const mbar_ctx* c) { return (uint64_t)c->ld * 56u + 128u >= (1ull << 32); }
 int lse_variant_for(const mbar_ctx* c) {
-    if (wide_pitch(c)) return 1;
-    int v = (c->opt_lse_variant >= 2 && c->opt_staging != 0) ? 1 : (int)c->opt_lse_variant;
+    if (wide_pitch(c)) return 0;
+    int v = 0;
     // bit 4: the context qualifies for the few-state kernel (one sample per lane, 64-sample tiles); lse_geometry
     // takes it for single-candidate sweeps of up to 32 states
     if (c->opt_small && c->opt_staging == 0 && c->Kp <= 32 && c->ld % 64 == 0) v |= 0x10;
@@ -565,7 +561,6 @@ int lse_variant_for(const mbar_ctx* c) {
     if (c->opt_wide && c->opt_staging == 0 && c->Kp > 128) v |= 0x20;
     return v;
 }
-int gram_variant_for(const mbar_ctx* c) { return wide_pitch(c) ? 2 : (int)c->opt_gram_variant; }
 bool use_fast(const mbar_ctx* c) { return c->K <= MAX_FAST_K && !c->opt_force_generic; }
 
 // Host vector a[k] = f[k] + ln N_k (-inf where N_k = 0 or k >= K), written into out[rows].
@@ -748,7 +743,7 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
             continue;
         }
         const int tile_rows = it.diag ? it.nbi * 16 : (it.nbi + it.nbj) * 16;
-        LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
+        LaunchGeom g = gram_geometry(tile_rows, it.diag, c->num_cu, ntiles, c->opt_grid);
         const size_t rec = (size_t)it.nblk * 256;
         int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
         if (rc) return rc;
@@ -1219,7 +1214,6 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
 bool device_loop_eligible(const mbar_ctx* c) {
     if (!c->opt_device_loop || !use_fast(c)) return false;
     if (c->nranks > 1 && !stream_transport(c)) return false;  // the host transport needs the host in the loop
-    if (c->Kp == 128 && gram_variant_for(c) != 2) return false;
     const int64_t ntiles = (c->N + TS - 1) / TS;
     const LaunchGeom gl = lse_geometry((int)(c->Kp / 16), 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
     // 129 .. 256 states: the one-read Gram kernel, the four-waves-per-CU evaluation kernel and the blocked Cholesky solve
@@ -1311,7 +1305,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const bool fused = pmode && c->opt_fused;
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     LaunchGeom gg = wide ? gram_quad_geometry(nb, c->num_cu, ntiles, c->opt_grid)
-                         : gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid, gram_variant_for(c));
+                         : gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid);
     LaunchGeom gl = fused ? fused_geometry(nb, c->num_cu, ntiles, c->opt_grid)
                     : pmode ? psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid)
                             : lse_geometry(nb, 2, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
@@ -1336,17 +1330,6 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
                      std::max(((size_t)std::max(gg.nwaves, gl.nwaves) / 32 + 1) * (rec_g + rec_l + 2), ((size_t)gb.nwaves / 32 + 1) * (Kp + rec_g)));
     if (!arc && c->weighted && !c->lden_eff) arc = fail(c, MBAR_ERR_STATE, "weighted context without its logden buffer");
     if (!arc && fused) arc = ensure(c, &c->part_g, &c->part_g_doubles, (size_t)gl.nwaves * rec_g);
-    // Small problems on one rank, OPTIONAL ("persistent", off): the whole loop in ONE launch (persistent grid, k_solve_small) -- up
-    // to 80 states, matrices of up to ~1e6 samples.  Measured SLOWER than five launches per iteration (config 5: 77 against 51 us
-    // per iteration): a phase change through a grid barrier and device-scope visibility costs 10-20 us, a kernel boundary ~5
-    const bool small = fused && !wide && nb <= 5 && c->nranks <= 1 && !stream_transport(c) && c->opt_persistent && ntiles <= 65536 &&
-                       m - 1 <= (nb <= 4 ? 63 : 127);
-    const int sm_grid = small ? solve_small_grid(c->num_cu, ntiles, c->opt_grid) : 0;
-    const size_t sm_E = small ? solve_small_record_doubles(nb) : 0;
-    if (!arc && small) arc = ensure(c, &c->sm_buf, &c->sm_doubles, (size_t)2 * sm_grid * sm_E + 2 * sm_E);
-    if (!arc && small) arc = ensure(c, &c->part, &c->part_doubles, (size_t)psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid).nwaves * Kp);
-    if (!arc && small && !c->sm_bar && cache_malloc((void**)&c->sm_bar, 64) != hipSuccess)
-        arc = fail(c, MBAR_ERR_HIP, "allocation of the grid-barrier words failed");
     {
         bool ok = arc == MBAR_OK;
         const std::string local_err = c->error;
@@ -1589,15 +1572,38 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // so the loop proper is four launches per iteration; a solve of its own is needed at the start and after a pause)
     const bool merged = fused && !wide && c->opt_merge_select;
     bool need_newton = true;
+    // timing level 3: event pairs around the non-sweep sections too (the split that explains a multi-GPU iteration)
+    struct Section {
+        mbar_ctx* c;
+        TimerPair tp;
+        Section(mbar_ctx* c_, bool on, int which) : c(c_) {
+            tp.a = tp.b = nullptr;
+            tp.which = which;
+            if (!on) return;
+            tp.a = get_event(c);
+            tp.b = get_event(c);
+            if (tp.a && tp.b) (void)hipEventRecord(tp.a, c->stream);
+        }
+        ~Section() {
+            if (tp.a && tp.b) {
+                (void)hipEventRecord(tp.b, c->stream);
+                c->pending.push_back(tp);
+            }
+        }
+    };
     auto enqueue_iteration = [&](bool timed) -> int {
+        const bool split = timed && c->opt_timing == 3;
         if (!fused) {
             int r2 = enqueue_gram(timed);
             if (r2) return r2;
         }
-        if (wide)
-            HIPCHK(c, launch_newton_chol(c->stream, q, c->chol));
-        else if (!merged || need_newton)
-            HIPCHK(c, launch_newton(c->stream, q));
+        {
+            Section sec(c, split && (wide || !merged || need_newton), MBAR_TIMER_NEWTON);
+            if (wide)
+                HIPCHK(c, launch_newton_chol(c->stream, q, c->chol));
+            else if (!merged || need_newton)
+                HIPCHK(c, launch_newton(c->stream, q));
+        }
         need_newton = false;
         double* psum_part = c->part;
         double* obj_part = c->part + (size_t)gl.nwaves * rec_l;
@@ -1621,23 +1627,30 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             if (tp.a && tp.b) c->pending.push_back(tp);
         }
         int64_t ar_count = (int64_t)(rec_l + 2);
-        if (fused) {
-            HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, gram_part, (int64_t)rec_g, gl.nwaves, c->scratch, c->red,
-                                     c->red + off_gram));
-            ar_count = (int64_t)(off_gram + rec_g);
-        } else if (pmode) {  // (no objective sums in P mode: the adaptive loop does not use them)
-            HIPCHK(c, launch_reduce(c->stream, psum_part, gl.nwaves, (int64_t)rec_l, c->scratch, c->red));
-        } else {
-            HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, obj_part, 2, gl.nwaves, c->scratch, c->red, c->red + rec_l));
+        {
+            Section sec(c, split, MBAR_TIMER_REDUCE);
+            if (fused) {
+                HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, gram_part, (int64_t)rec_g, gl.nwaves, c->scratch, c->red,
+                                         c->red + off_gram));
+                ar_count = (int64_t)(off_gram + rec_g);
+            } else if (pmode) {  // (no objective sums in P mode: the adaptive loop does not use them)
+                HIPCHK(c, launch_reduce(c->stream, psum_part, gl.nwaves, (int64_t)rec_l, c->scratch, c->red));
+            } else {
+                HIPCHK(c, launch_reduce2(c->stream, psum_part, (int64_t)rec_l, obj_part, 2, gl.nwaves, c->scratch, c->red, c->red + rec_l));
+            }
         }
         if (stream_transport(c)) {
+            Section sec(c, split, MBAR_TIMER_COMM);
             int r2 = allreduce_dev(c, c->red, ar_count, 0);
             if (r2) return r2;
         }
-        if (merged)
-            HIPCHK(c, launch_select_newton(c->stream, q));
-        else
-            HIPCHK(c, launch_select(c->stream, q));
+        {
+            Section sec(c, split, MBAR_TIMER_NEWTON);
+            if (merged)
+                HIPCHK(c, launch_select_newton(c->stream, q));
+            else
+                HIPCHK(c, launch_select(c->stream, q));
+        }
         return MBAR_OK;
     };
 
@@ -1694,30 +1707,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         ++nbatch;
         ramp = std::min(batch, ramp * 2);
         int64_t nbat = std::min(want, maxiter - it);
-        if (small) {
-            // the persistent kernel runs until the loop stops by itself (converged, handed back, paused) or the budget ends
-            nbat = std::min<int64_t>(maxiter - it, 1 << 30);
-            SmallArgs sa;
-            sa.P = c->P;
-            sa.ld = c->ld;
-            sa.N = c->N;
-            sa.ntiles = ntiles;
-            sa.cw = c->cw;
-            sa.wsq = c->weighted ? c->cwsq : c->cw;
-            sa.rinv_base = c->logden[0];
-            sa.slot_stride = c->ld;
-            sa.rec = c->sm_buf;
-            sa.red = c->sm_buf + (size_t)2 * sm_grid * sm_E;
-            sa.bar = c->sm_bar;
-            sa.max_iters = (int)nbat;
-            sa.q = q;
-            HIPCHK(c, hipMemsetAsync(c->sm_bar, 0, 64, c->stream));
-            HIPCHK(c, launch_solve_small(c->stream, nb, sm_grid, sa));
-            unsigned hb[2] = {0, 0};
-            HIPCHK(c, hipMemcpyAsync(hb, c->sm_bar, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (hb[1] != 0) return fail(c, MBAR_ERR_STATE, "persistent solver kernel: a grid barrier was not met (workgroups not co-resident?)");
-        } else if (use_graph && nbat == batch) {
+        if (use_graph && nbat == batch) {
             rc = prepare_graph();
             if (rc) return rc;
             if (merged && need_newton) {  // (start of the solve / after a pause: the replayed iterations have no solve of their own)
@@ -1746,13 +1736,6 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             // Gram matrix has to be swept separately.  Every rank sees the same control words, so every rank comes by here.
             if (it_new <= it || it_new > it + nbat) return fail(c, MBAR_ERR_STATE, "device-resident adaptive loop lost count of its iterations");
             if (it_new < maxiter) {
-                if (small) {
-                    // the persistent kernel does not store the reciprocals 1 / s_n (nothing in its loop reads them): the Gram sweep of
-                    // the accepted candidate does, so they are recomputed here -- one single-candidate sweep with its multipliers
-                    const LaunchGeom gp = psweep_geometry(nb, c->num_cu, ntiles, c->opt_grid);
-                    HIPCHK(c, launch_psweep(c->stream, nb, 1, gp, c->P, c->ld, c->N, c->pm_vec + Kp, c->cw,
-                                            c->logden[0] + (int64_t)c->h_ctl[CTL_SLOT] * c->ld, nullptr, c->part, LoopCtl()));
-                }
                 rc = enqueue_gram(c->opt_timing != 0);
                 if (rc) return rc;
                 ++gram_sweeps;
@@ -1926,8 +1909,6 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->part_g) (void)cache_free(c->part_g);
     if (c->cwsq) (void)cache_free(c->cwsq);
     if (c->chol) (void)cache_free(c->chol);
-    if (c->sm_buf) (void)cache_free(c->sm_buf);
-    if (c->sm_bar) (void)cache_free(c->sm_bar);
     if (c->ad_ints) (void)cache_free(c->ad_ints);
     if (c->h_ctl) (void)cache_host_free(c->h_ctl);
     if (c->ad_graph) (void)hipGraphExecDestroy(c->ad_graph);
@@ -2044,16 +2025,13 @@ int mbar_device_synchronize(int device) {
 int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return fail(c, MBAR_ERR_ARG, "NULL argument");
     const std::string k(key);
-    if (k == "staging") c->opt_staging = value;
-    else if (k == "grid_blocks") c->opt_grid = value;
+    if (k == "grid_blocks") c->opt_grid = value;
     else if (k == "force_generic") c->opt_force_generic = value;
     else if (k == "small_k_kernel") c->opt_small = value;
     else if (k == "wide_k_kernel") c->opt_wide = value;
     else if (k == "check_finite") c->opt_check_finite = value;
     else if (k == "timing") c->opt_timing = value;
     else if (k == "graph") c->opt_graph = value;
-    else if (k == "lse_variant") c->opt_lse_variant = value;
-    else if (k == "gram_variant") c->opt_gram_variant = value;
     else if (k == "sci_batch") c->opt_sci_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
     else if (k == "device_loop") c->opt_device_loop = value;
     else if (k == "pmode") c->opt_pmode = value;
@@ -2061,7 +2039,6 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "gram_quad") c->opt_quad = value;
     else if (k == "device_loop_wide") c->opt_device_loop_wide = value;
     else if (k == "pcache") c->opt_pcache = value;
-    else if (k == "persistent") c->opt_persistent = value;
     else if (k == "merge_select") c->opt_merge_select = value;
     else if (k == "wide_pmode") c->opt_wide_pmode = value;
     else if (k == "quad_trim") {

@@ -72,7 +72,9 @@ struct LaunchGeom {
 // ---- evaluation pass -------------------------------------------------------------------------
 // psum_part: [nwaves][nf][16*nb], obj_part: [nwaves][nf]; logden0/1 may be null (not stored).
 // cw: per-sample multiplicities (ld doubles: 1 for plain data, bootstrap counts otherwise, 0 on the padding).
-// variant 0: paired waves for nb >= 6 (two waves share a tile stream), 1: always one tile stream per wave
+// variant: flags of the specialised kernels the context qualifies for (0x10: few-state kernel, one sample per lane, K <= 32,
+// one candidate; 0x20: single-buffer kernel for 129..256 states); the geometry records its choice in LaunchGeom::variant
+// (1 = k_lse, one tile stream per wave; 4 = k_lse_small; 5 = k_lse_wide)
 LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant);
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g,
                       const double* u, int64_t ld, int64_t N, const double* aden /*[nf][16nb]*/,
@@ -83,9 +85,7 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
 // Diagonal panel: states [row0, row0+16nb) against themselves, nblk = nb(nb+1)/2 blocks, block b
 // enumerates (I,J) with I<=J in row-major order.  Off-diagonal panel pair: nbi x nbj blocks.
 // gram_part: [nwaves][nblk][256], psum_part: [nwaves][16*nb] (diag only; may be null for off-diag).
-// nb8_variant (full 128-state diagonal panel only): 0 = paired waves with operand exchange, 1 = paired waves
-// that both compute every operand
-LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, int64_t grid_override, int nb8_variant);
+LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, int64_t grid_override);
 hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n);  // row[i] -= v[i]
 hipError_t launch_rows_sub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, const double* v, int64_t n);
 hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n);
@@ -196,27 +196,6 @@ struct AdaptArgs {
     int fused;
     double* cgram;           // [Kp]
 };
-// ---- small problems: the whole device-resident loop in ONE launch (k_solve_small) ---------------------------------------
-// Up to 80 states (nb <= 5 blocks of 16) and a matrix of a few hundred MB at most, single rank, P mode: a persistent grid of
-// one workgroup per compute unit runs {Newton solve, fused sweep, fold, grid barrier, reduction, grid barrier, selection}
-// per iteration until the loop stops (converged / handed back / paused / iteration budget) -- no launches in between.
-struct SmallArgs {
-    const double* P;
-    int64_t ld, N, ntiles;
-    const double* cw;
-    const double* wsq;
-    double* rinv_base;      // three slot vectors, pitch slot_stride
-    int64_t slot_stride;
-    double* rec;            // [2][grid][E] per-workgroup records, E = 2 Kp + nblk 256 (double-buffered by iteration parity)
-    double* red;            // [2][E] reduced records
-    unsigned* bar;          // [0] arrivals at the grid barriers of this launch (zeroed by the host), [1] timeout flag
-    int max_iters;          // iterations this launch may run
-    AdaptArgs q;            // the solver state in device memory (read at entry, written back at exit)
-};
-size_t solve_small_record_doubles(int nb);                 // E
-int solve_small_grid(int num_cu, int64_t ntiles, int64_t grid_override);
-hipError_t launch_solve_small(hipStream_t s, int nb, int grid, const SmallArgs& a);
-
 // ---- P mode: resident probability matrix P = exp(a0 - u - logden(a0)) (see k_psweep) ----------------------------------
 LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
 // cmul: [nf][16 nb] multipliers exp(a - a0); rinv0 = base of the three slot vectors when lc.ctl is set

@@ -1,0 +1,805 @@
+// gfx950 (CDNA4 / MI355X) kernels of the MBAR solver hot path -- evaluation sweeps (log-sum-exp over states + per-state sums): k_lse, k_lse_small, k_lse_wide, k_lse_split, layout-agnostic fallbacks.
+// One of the translation units of libmbar_hip.so (compiled in parallel by pymbar_amd/_build.py): the shared device helpers and
+// the data-layout notes are in mbar_device.h, the host-side interface of the launchers in mbar_internal.h.
+#include "mbar_device.h"
+
+namespace mbar {
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass: per-sample log-sum-exp over states + per-state sums of p_nk, for NF candidates f.
+//   aden[0][k] = f_k + ln N_k of the first candidate (-inf for unsampled / padded states)
+//   aden[1][k] = c_k = exp(aden'_k - aden_k) of the second candidate relative to the first (NF == 2)
+//   logden_n   = log sum_k exp(aden_k - u_kn)                    (mbar_solvers.py:238)
+//   p_nk       = exp(aden_k - u_kn - logden_n),  psum_k = sum_n p_nk   (= N_k sum_n W_nk)
+// One exp per matrix element in total: e = exp(x - max) is kept in registers, normalised by the reciprocal of
+// its sum, and re-used for the second candidate through the per-state ratio c_k.
+// ---------------------------------------------------------------------------------------------
+// Waves per workgroup of the default sweep: a 16-sample tile of few states is small, so more waves fit into LDS next to
+// the tables and the SIMDs get 2-4 waves each to hide the latency of the tile stream (K <= 64 ran one wave per SIMD at
+// 4.9 TB/s).
+template <int NB, int NF, bool DMA, bool WIDE>
+__global__ void __launch_bounds__(64 * lse_waves(NB))
+k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+      const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+      double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
+      double* __restrict__ obj_part, const int* __restrict__ ctl, int64_t slot_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl) {  // device-resident solver loop: stop flag + rotating logden slots (logden0 = base of the three vectors)
+        if (ctl[CTL_DONE] != 0) return;
+        const int s = ctl[CTL_SLOT];
+        logden1 = logden0 + (int64_t)((s + 2) % 3) * slot_stride;
+        logden0 = logden0 + (int64_t)((s + 1) % 3) * slot_stride;
+    }
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    exp_table_init(smem);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * (2 * TILE_BYTES);
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    RowIdentity rows{0};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+    // one global store per tile (lanes ks < 4 write logden0, 4 <= ks < 8 logden1) unless neither vector is wanted
+    const bool has_store = logden0 != nullptr || logden1 != nullptr;
+
+    double a[NB], c[NB], acc[NF][NB], objl = 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        a[I] = aden[16 * I + ks];
+        c[I] = NF == 2 ? aden[ROWS + 16 * I + ks] : 1.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        settle(a[I]);
+        if (NF == 2) settle(c[I]);
+    }
+    rows.live = live_piece_mask<NB>(a, -INFINITY);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
+    }
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    int64_t t = gw;
+    int cur = 0;
+    if constexpr (DMA) {
+        if (t < ntiles) {
+            stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
+            stage_vec16<true>(cw, t * TS, buf + U_BYTES, lane);
+        }
+    }
+    for (; t < ntiles; t += W) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        if constexpr (DMA) {
+            const int64_t tn = t + W;
+            if (tn < ntiles) {
+                char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+                // The next tile is requested in two halves -- even DMA pieces here, odd ones after the first group pair
+                // below -- which smooths the request stream of the 1024 waves (measured: -1.5 % on this sweep).
+                stage_tile<ROWS, true, 0, 2>(u, ld, tn * TS, nbuf, lane, so, rows);
+                stage_vec16<true>(cw, tn * TS, nbuf + U_BYTES, lane);
+                constexpr int NEVEN = (ROWS / 8 + 1) / 2 + 1;  // even pieces + the weight slot
+                // vmcnt counts stores too (in issue order with the loads on gfx9); the queue here is
+                // [even(t)][odd(t)][logden store of tile t - W][even(tn)], and tile t is needed now:
+                if (has_store && t != gw)
+                    wait_vm<NEVEN + 1>();
+                else
+                    wait_vm<NEVEN>();
+            } else {
+                wait_vm<0>();
+            }
+        } else {
+            stage_tile<ROWS, false, 0, 1>(u, ld, t * TS, cbuf, lane, so, rows);
+            stage_vec16<false>(cw, t * TS, cbuf + U_BYTES, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        double mm = 0.0, ss[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ss[f] = 1.0;
+        lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, rd_base, pos, 0, a, c, acc, ks, ns, mm, ss);
+        if constexpr (DMA) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + W < ntiles) stage_tile<ROWS, true, 1, 2>(u, ld, (t + W) * TS, buf + (cur ^ 1) * TILE_BYTES, lane, so, rows);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lse_group_pair<NB, NF>(cbuf, cbuf + U_BYTES, rd_base, pos, 2, a, c, acc, ks, ns, mm, ss);
+        // lanes with (ks & 3) == g hold (shift, sums) of sample 4 g + ns: one log per candidate per tile
+        {
+            const int64_t n = t * TS + 4 * (ks & 3) + ns;
+            const double wn = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * (ks & 3) + ns) * 8);
+            logden_out<NF>(mm, ss, ks, n < N, n, wn, logden0, logden1, dn, objl);
+        }
+        cur ^= 1;
+    }
+    // per-wave partial sums: fold the four sample sub-lanes, lanes 0..15 own one state each
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(gw * NF + f) * ROWS + 16 * I + lane] = v;
+        }
+    }
+    objective_out<NF>(objl, ks, lane, obj_part, gw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass for few states (K <= 32, one candidate): one SAMPLE per lane, all states of that sample in the
+// lane's registers.  In the MFMA operand layout of the other kernels a sample's states are spread over 16 lanes, so
+// every max / sum over states costs a 4-step DPP butterfly per 4-sample group; with 16-32 states that is more than
+// half of the instruction stream (and the matrix cores are not used by this pass anyway).  Here the reductions
+// over states are in-register trees and the only cross-lane work is one reduction of the per-state accumulators at
+// the end of the kernel.  A tile is 64 consecutive samples x all state rows (512 contiguous bytes per row, LDS row
+// k = bytes [512 k, 512 k + 512): the column read of lane n is conflict-free); each LDS-DMA instruction moves two
+// rows.  The tile is read into registers in one go, so its single buffer is refilled immediately (two waves per
+// SIMD, 8 per workgroup).  Requires a row pitch that is a multiple of 64 (mbar_ctx_create pads it for K <= 32).
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__global__ void __launch_bounds__(512, 2)
+k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+            const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+            const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TSS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TSS * 8;  // + the 64 sample weights of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    exp_table_init(smem);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * TILE_BYTES;
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    const bool has_store = logden0 != nullptr;
+    // DMA instruction j moves rows 2j, 2j+1: lane l -> row 2j + (l >> 5), bytes [16 (l & 31), +16) of its 512
+    const uint32_t voff = (uint32_t)(((int64_t)(lane >> 5) * ld + 2 * (lane & 31)) * 8);
+
+    double a[ROWS], acc[ROWS], objl = 0.0;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        a[k] = aden[k];
+        acc[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) settle(a[k]);
+    // pairs of rows whose exponent constants are both -inf (padding, states without samples): requested from the first tile's
+    // columns every time -- an L2 hit instead of HBM traffic (see RowIdentity::cols); 5 states in a 16-row matrix: half the bytes
+    uint32_t live = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS / 2; ++j) live |= (__ballot(a[2 * j] != -INFINITY || a[2 * j + 1] != -INFINITY) ? 1u : 0u) << j;
+
+    auto stage = [&](int64_t tile) {
+#pragma unroll
+        for (int j = 0; j < ROWS / 2; ++j)
+            stage_piece<true>(u + (int64_t)(2 * j) * ld + (((live >> j) & 1u) ? tile * TSS : 0), voff, buf + j * 1024, lane);
+        if (lane < 32) stage_piece<true>(cw + tile * TSS, (uint32_t)(lane * 16), buf + U_BYTES, lane);
+    };
+
+    int64_t t = gw;
+    if (t < ntiles) stage(t);
+    for (; t < ntiles; t += W) {
+        if (has_store && t != gw)
+            wait_vm<1>();  // [this tile][logden store of the previous one]: vmcnt counts stores too
+        else
+            wait_vm<0>();
+        double x[ROWS];
+        const double w = *reinterpret_cast<const double*>(buf + U_BYTES + lane * 8);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) x[k] = *reinterpret_cast<const double*>(buf + k * (TSS * 8) + lane * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is in registers: refill its buffer
+        if (t + W < ntiles) stage(t + W);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) x[k] = a[k] - x[k];
+        const double m = tree_max<ROWS>(x);
+        const double m2 = m * LOG2E_S;
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) x[k] = fma(x[k], LOG2E_S, -m2);
+#pragma unroll
+        for (int k0 = 0; k0 < ROWS; k0 += 8) {
+            double e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = x[k0 + i];
+            exp2s_batch<8>(e);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[k0 + i] = e[i];
+        }
+        const double ssum = tree_sum<ROWS>(x);
+        const double r = w * recip_fast(ssum);  // w: sample multiplicity (0 on the padding)
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) acc[k] = fma(x[k], r, acc[k]);
+        const double ldv = m + log_pos(ssum);
+        const int64_t n = t * TSS + lane;
+        if (n < N) {
+            if (logden0) logden0[n] = ldv;
+            objl = fma(w, dn ? (ldv - dn[n]) : ldv, objl);
+        }
+    }
+    // one partial record per WORKGROUP (the 8 waves are folded through LDS in a fixed order): few enough records for
+    // the SCI update kernel to sum directly, which saves the level-1 reduction launch of the device-resident loop
+    __syncthreads();  // every wave is done with its tile buffer: re-use the LDS behind the tables
+    double* fold = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) fold[wave * (ROWS + 1) + k] = v;
+    }
+    const double o = wave_sum(objl);
+    if (lane == 0) fold[wave * (ROWS + 1) + ROWS] = o;
+    __syncthreads();
+    if (threadIdx.x <= ROWS) {
+        double tot = 0.0;
+        for (int w = 0; w < nwv; ++w) tot += fold[w * (ROWS + 1) + threadIdx.x];
+        if (threadIdx.x < ROWS)
+            psum_part[(int64_t)blockIdx.x * ROWS + threadIdx.x] = tot;
+        else
+            obj_part[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass for wide panels (129 <= K <= 256: NB = 12 or 16).  A 16-sample tile is 24-33 KB here, so the
+// double-buffered k_lse fits only TWO waves per CU and half the SIMDs idle.  This variant gives every wave ONE tile
+// buffer (four waves per CU): groups 0 and 1 are processed straight from LDS, the operands of groups 2 and 3 are
+// pulled into registers together, and the buffer is refilled at that point -- half a tile period before it is needed.
+// ---------------------------------------------------------------------------------------------
+template <int NB, int NF>
+__global__ void __launch_bounds__(256, 1)
+k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+           const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+           double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
+           double* __restrict__ obj_part, const int* __restrict__ ctl, int64_t slot_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl) {  // device-resident solver loop: stop flag + rotating logden slots (logden0 = base of the three vectors)
+        if (ctl[CTL_DONE] != 0) return;
+        const int s = ctl[CTL_SLOT];
+        logden1 = logden0 + (int64_t)((s + 2) % 3) * slot_stride;
+        logden0 = logden0 + (int64_t)((s + 1) % 3) * slot_stride;
+    }
+    constexpr int ROWS = NB * 16;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the 16 sample weights of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int ks = lane & 15, ns = lane >> 4;
+    exp_table_init(smem);
+    __syncthreads();
+    char* buf = smem + EXP_TABLE_BYTES + wave * TILE_BYTES;
+    const char* wslot = buf + U_BYTES;
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    const int64_t W = (int64_t)gridDim.x * nwv;
+    RowIdentity rows{0};
+    const StageOffsets so = make_stage_offsets(ld, lane);
+    const bool has_store = logden0 != nullptr || logden1 != nullptr;  // one store instruction per tile
+
+    double a[NB], c[NB], acc[NF][NB], objl = 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        a[I] = aden[16 * I + ks];
+        c[I] = NF == 2 ? aden[ROWS + 16 * I + ks] : 1.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        settle(a[I]);
+        if (NF == 2) settle(c[I]);
+    }
+    rows.live = live_piece_mask<NB>(a, -INFINITY);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[f][I] = 0.0;
+    }
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    int64_t t = gw;
+    if (t < ntiles) {
+        stage_tile<ROWS, true, 0, 1>(u, ld, t * TS, buf, lane, so, rows);
+        stage_vec16<true>(cw, t * TS, buf + U_BYTES, lane);
+    }
+    for (; t < ntiles; t += W) {
+        if (has_store && t != gw)
+            wait_vm<1>();  // [this tile][logden store of the previous one]: vmcnt counts stores too
+        else
+            wait_vm<0>();
+        double w[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) w[g] = *reinterpret_cast<const double*>(wslot + (4 * g + ns) * 8);
+        const double wn = *reinterpret_cast<const double*>(wslot + (4 * (ks & 3) + ns) * 8);
+        const int gq = ks & 3;  // this lane keeps (shift, sums) of sample 4 gq + ns for the log below
+        double x0[NB], x1[NB], m2, sg[NF], mm = 0.0, ss[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ss[f] = 1.0;
+        auto keep = [&](int g) {
+            if (gq == g) {
+                mm = m2;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) ss[f] = sg[f];
+            }
+        };
+        lse_load1<NB>(buf, pos[0], a, x0);
+        lse_math1<NB, NF>(x0, c, acc, w[0], m2, sg);
+        keep(0);
+        lse_load1<NB>(buf, pos[1], a, x0);
+        lse_math1<NB, NF>(x0, c, acc, w[1], m2, sg);
+        keep(1);
+        lse_load1<NB>(buf, pos[2], a, x0);
+        lse_load1<NB>(buf, pos[3], a, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS operand of this tile is in registers
+        if (t + W < ntiles) {
+            stage_tile<ROWS, true, 0, 1>(u, ld, (t + W) * TS, buf, lane, so, rows);
+            stage_vec16<true>(cw, (t + W) * TS, buf + U_BYTES, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lse_math1<NB, NF>(x0, c, acc, w[2], m2, sg);
+        keep(2);
+        lse_math1<NB, NF>(x1, c, acc, w[3], m2, sg);
+        keep(3);
+        {
+            const int64_t n = t * TS + 4 * gq + ns;
+            logden_out<NF>(mm, ss, ks, n < N, n, wn, logden0, logden1, dn, objl);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) psum_part[(gw * NF + f) * ROWS + 16 * I + lane] = v;
+        }
+    }
+    objective_out<NF>(objl, ks, lane, obj_part, gw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation pass for 257 .. 512 states in ONE read of the matrix (the layout-agnostic path below reads it twice: a log-sum-exp
+// pass and a column-sum pass).  A 16-sample tile of 512 rows is 64 KB -- too much for one wave's registers and LDS share -- so
+// the EIGHT waves of a workgroup split the rows of one tile (16 NBW rows each, their own LDS-DMA, their own double buffer) and
+// meet twice per tile through two small LDS vectors: the per-sample maxima (so that every wave uses the same shift and there
+// is ONE exponential per element) and the per-sample sums.  Rows past the allocated pitch are never requested (their LDS rows
+// stay zero and their a_k is -inf).  Partial records: one per workgroup, `rows` entries + one objective term.
+// ---------------------------------------------------------------------------------------------
+template <int NBW, int NF>
+__global__ void __launch_bounds__(512, 1)
+k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, int64_t rows,
+            const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden,
+            double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
+            double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RW = NBW * 16;                  // rows per wave
+    constexpr int NP = RW / 8;                    // LDS-DMA pieces per wave and tile
+    constexpr int U_BYTES = RW * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the tile's 16 sample weights
+    constexpr int NW = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ks = lane & 15, ns = lane >> 4;
+    exp_table_init(smem);
+    double* xmax = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);  // [NW][TS]
+    double* xsum = xmax + NW * TS;                                     // [NF][NW][TS]
+    char* buf = smem + EXP_TABLE_BYTES + (1 + NF) * NW * TS * 8 + wave * (2 * TILE_BYTES);
+    const int64_t r0 = (int64_t)wave * RW;
+    const StageOffsets so = make_stage_offsets(ld, lane);
+    // rows this wave never requests: zero once, in both buffers
+    for (int j = 0; j < NP; ++j)
+        if (r0 + 8 * j >= rows) {
+            for (int bsel = 0; bsel < 2; ++bsel) *reinterpret_cast<double2*>(buf + bsel * TILE_BYTES + j * 1024 + lane * 16) = double2{0.0, 0.0};
+        }
+    __syncthreads();
+    // second candidate (NF == 2): aden[rows + k] holds the ratio c_k = exp(a'_k - a_k); its exponentials are the first one's
+    // times c_k (one exponential per element for both), its per-state sums are accumulated without c_k (applied by the caller)
+    double a[NBW], c[NBW], acc[NF][NBW], objl[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) objl[f] = 0.0;
+#pragma unroll
+    for (int I = 0; I < NBW; ++I) {
+        const int64_t r = r0 + 16 * I + ks;
+        a[I] = r < rows ? aden[r] : -INFINITY;
+        c[I] = (NF == 2 && r < rows) ? aden[rows + r] : 0.0;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[f][I] = 0.0;
+    }
+#pragma unroll
+    for (int I = 0; I < NBW; ++I) {
+        settle(a[I]);
+        if (NF == 2) settle(c[I]);
+    }
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = rd_base + ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    auto stage = [&](int64_t tile, char* dst) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (r0 + 8 * j < rows) stage_piece<true>(u + (r0 + 8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
+        stage_vec16<true>(cw, tile * TS, dst + U_BYTES, lane);
+    };
+    const int64_t G = gridDim.x;
+    int64_t t = blockIdx.x;
+    int cur = 0;
+    if (t < ntiles) stage(t, buf);
+    for (; t < ntiles; t += G) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        wait_vm<0>();  // this tile (requested a tile period ago) and the previous tile's logden stores
+        if (t + G < ntiles) stage(t + G, buf + (cur ^ 1) * TILE_BYTES);
+        double x[GROUPS][NBW], w[GROUPS], mloc[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            w[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) x[g][I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) x[g][I] = a[I] - x[g][I];
+            mloc[g] = row16_max(tree_max<NBW>(x[g]));
+            if (ks == 0) xmax[wave * TS + 4 * g + ns] = mloc[g];
+        }
+        __syncthreads();
+        double m2[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            double m = xmax[4 * g + ns];
+#pragma unroll
+            for (int wv = 1; wv < NW; ++wv) m = fmax(m, xmax[wv * TS + 4 * g + ns]);
+            m2[g] = m * LOG2E_S;
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) x[g][I] = fma(x[g][I], LOG2E_S, -m2[g]);
+            exp2s_batch<NBW>(x[g]);
+            double s0 = tree_sum<NBW>(x[g]), s1 = NF == 2 ? dot_sum<NBW>(x[g], c) : 0.0;
+            if constexpr (NF == 2) row16_sum2(s0, s1); else s0 = row16_sum(s0);
+            if (ks == 0) {
+                xsum[wave * TS + 4 * g + ns] = s0;
+                if constexpr (NF == 2) xsum[NW * TS + wave * TS + 4 * g + ns] = s1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            double ssum[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                ssum[f] = xsum[f * NW * TS + 4 * g + ns];
+#pragma unroll
+                for (int wv = 1; wv < NW; ++wv) ssum[f] += xsum[f * NW * TS + wv * TS + 4 * g + ns];  // (fixed order: every wave gets the same bits)
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const double r = w[g] * recip_fast(ssum[f]);
+#pragma unroll
+                for (int I = 0; I < NBW; ++I) acc[f][I] = fma(x[g][I], r, acc[f][I]);
+            }
+            if (wave == 0 && ks < NF) {  // logden_n = shift + log(sum), one lane per sample and candidate
+                const int64_t n = t * TS + 4 * g + ns;
+                if (n < N) {
+                    const double sv = ks == 0 ? ssum[0] : ssum[NF - 1];
+                    const double ldv = fma(m2[g], LN2_OVER_S, log_pos(sv));
+                    double* out = ks == 0 ? logden : logden1;
+                    if (out) out[n] = ldv;
+                    const double term = w[g] * (dn ? (ldv - dn[n]) : ldv);
+                    if (ks == 0) objl[0] += term; else objl[NF - 1] += term;
+                }
+            }
+        }
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int I = 0; I < NBW; ++I) {
+            double v = acc[f][I];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int64_t r = r0 + 16 * I + lane;
+            if (lane < 16 && r < rows) psum_part[((int64_t)blockIdx.x * NF + f) * rows + r] = v;
+        }
+    if (wave == 0) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const double o = wave_sum(objl[f]);
+            if (lane == 0) obj_part[(int64_t)blockIdx.x * NF + f] = o;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Layout-agnostic fallbacks (any K): lanes along n, one sample per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_lse_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
+              const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden,
+              const double* __restrict__ dn, double* __restrict__ obj_part) {
+    __shared__ double red[4];
+    double obj = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        double m = -INFINITY, s = 0.0;
+        for (int64_t k = 0; k < K; ++k) {
+            const double ak = aden[k];
+            if (ak == -INFINITY) continue;  // uniform: unsampled state
+            const double x = ak - u[k * ld + n];
+            if (m == -INFINITY) {
+                m = x;
+                s = 1.0;
+            } else {
+                const double d = x - m;
+                const double e = exp(-fabs(d));
+                s = d > 0.0 ? fma(s, e, 1.0) : s + e;
+                m = fmax(m, x);
+            }
+        }
+        const double ldv = m + log(s);
+        if (logden) logden[n] = ldv;
+        obj = fma(cw[n], dn ? (ldv - dn[n]) : ldv, obj);
+    }
+    obj = wave_sum(obj);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = obj;
+    __syncthreads();
+    if (threadIdx.x == 0) obj_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// psum_part[blockIdx.x][k] = sum over this block's samples of exp(anum_k - u_kn - logden_n);
+// blockIdx.y selects a group of 8 states.
+__global__ void __launch_bounds__(256)
+k_colsum_generic(const double* __restrict__ u, int64_t ld, int64_t N, int64_t K,
+                 const double* __restrict__ anum, const double* __restrict__ cw, const double* __restrict__ logden,
+                 double* __restrict__ psum_part) {
+    __shared__ double red[4][8];
+    const int64_t k0 = (int64_t)blockIdx.y * 8;
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const double ldv = logden[n], wn = cw[n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = k0 + j;
+            if (k < K) acc[j] = fma(wn, exp(anum[k] - u[k * ld + n] - ldv), acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double v = wave_sum(acc[j]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && k0 + threadIdx.x < K) {
+        const int j = threadIdx.x;
+        psum_part[(int64_t)blockIdx.x * K + k0 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+
+LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant) {
+    LaunchGeom g;
+    const size_t tile = (size_t)nb * 16 * TS * 8 + TS * 8;  // u tile + its 16 sample weights
+    const bool small_ok = (variant & 0x10) != 0;  // set by the caller when the context qualifies (pitch, staging)
+    const bool wide_ok = (variant & 0x20) != 0;   // likewise for the single-buffer wide-panel kernel
+    g.variant = 1;  // one tile stream per wave (k_lse); 4 = few-state kernel, 5 = single-buffer wide-panel kernel (below)
+    if (small_ok && nf == 1 && nb <= 2) {  // few states (a third block of 16 would spill the per-lane state arrays): one sample per lane, 64-sample tiles, 8 waves x 1 buffer
+        g.variant = 4;
+        g.waves = 8;
+        const size_t tile64 = (size_t)nb * 16 * TSS * 8 + TSS * 8;
+        g.lds_bytes = (size_t)g.waves * tile64 + EXP_TABLE_BYTES;
+        const int64_t nt64 = (ntiles * TS + TSS - 1) / TSS;
+        int64_t want = (nt64 + g.waves - 1) / g.waves;
+        int64_t cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+        if (grid_override > 0) cap = grid_override;
+        if (want < 1) want = 1;
+        g.blocks = (int)(want < cap ? want : cap);
+        g.nwaves = g.blocks;  // partial records: this kernel folds its 8 waves and writes one per workgroup
+        g.psum_records = g.nwaves;
+        return g;
+    }
+    if (wide_ok && nb > 8) {  // 129..256 states: one tile buffer per wave, four waves per CU
+        g.variant = 5;
+        g.waves = 4;
+        g.lds_bytes = (size_t)g.waves * tile + EXP_TABLE_BYTES;
+        int64_t want = (ntiles + g.waves - 1) / g.waves;
+        int64_t cap5 = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+        if (grid_override > 0) cap5 = grid_override;
+        if (want < 1) want = 1;
+        g.blocks = (int)(want < cap5 ? want : cap5);
+        g.nwaves = g.blocks * g.waves;
+        g.psum_records = g.nwaves;
+        return g;
+    }
+    g.waves = lse_waves(nb);
+    g.lds_bytes = (size_t)g.waves * 2 * tile + EXP_TABLE_BYTES;
+    int64_t want = (ntiles + g.waves - 1) / g.waves;
+    int64_t cap = (int64_t)num_cu * blocks_per_cu_for(g.lds_bytes);
+    if (grid_override > 0) cap = grid_override;
+    if (want < 1) want = 1;
+    g.blocks = (int)(want < cap ? want : cap);
+    g.nwaves = g.blocks * g.waves;
+    g.psum_records = g.nwaves;
+    return g;
+}
+
+template <typename Kern>
+static hipError_t launch_kernel_lse(Kern kern, hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                    const double* aden, const double* cw, double* l0, double* l1, const double* dn,
+                                    double* psum_part, double* obj_part, const LoopCtl& lc) {
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TS - 1) / TS;
+    if (lc.ev_start && lc.ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, u, ld, N,
+                              ntiles, aden, cw, l0, l1, dn, psum_part, obj_part, lc.ctl, lc.slot_stride);
+    else
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0,
+                           l1, dn, psum_part, obj_part, lc.ctl, lc.slot_stride);
+    return hipGetLastError();
+}
+
+template <int NB, int NF, bool DMA>
+static hipError_t launch_lse_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                               const double* aden, const double* cw, double* l0, double* l1, const double* dn,
+                               double* psum_part, double* obj_part, const LoopCtl& lc) {
+    if (stage_offsets_wide(ld))
+        return launch_kernel_lse(k_lse<NB, NF, DMA, true>, s, g, u, ld, N, aden, cw, l0, l1, dn, psum_part, obj_part, lc);
+    return launch_kernel_lse(k_lse<NB, NF, DMA, false>, s, g, u, ld, N, aden, cw, l0, l1, dn, psum_part, obj_part, lc);
+}
+
+template <int NB>
+static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeom& g, const double* u,
+                                int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
+                                const double* dn, double* pp, double* op, const LoopCtl& lc) {
+    // (LDS-DMA staging only: the register-staged instantiations of rounds 1-3 were a tuning knob, never the faster path)
+    if (g.variant != 1 || !dma) return hipErrorInvalidValue;
+    if (nf == 1) return launch_lse_t<NB, 1, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
+    return launch_lse_t<NB, 2, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
+}
+
+template <int NB>
+static hipError_t launch_lse_small_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+                                     const double* aden, const double* cw, double* l0, const double* dn,
+                                     double* psum_part, double* obj_part) {
+    auto kern = k_lse_small<NB>;
+    if (g.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t ntiles = (N + TSS - 1) / TSS;
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0, dn,
+                       psum_part, obj_part);
+    return hipGetLastError();
+}
+
+hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,
+                      int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
+                      const double* dn, double* pp, double* op, const LoopCtl& lc) {
+    if (lc.ctl && g.variant == 4) return hipErrorInvalidValue;
+    if (g.variant == 5) {  // (geometry chose the single-buffer wide-panel kernel: nb = 12 or 16, LDS-DMA staging)
+        if (!dma) return hipErrorInvalidValue;
+        auto go = [&](auto kern) -> hipError_t {
+            if (g.lds_bytes > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+                if (e != hipSuccess) return e;
+            }
+            const int64_t ntiles = (N + TS - 1) / TS;
+            if (lc.ev_start && lc.ev_stop)
+                hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, u, ld, N,
+                                      ntiles, aden, cw, l0, l1, dn, pp, op, lc.ctl, lc.slot_stride);
+            else
+                hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0, l1,
+                                   dn, pp, op, lc.ctl, lc.slot_stride);
+            return hipGetLastError();
+        };
+        if (nb == 12) return nf == 1 ? go(k_lse_wide<12, 1>) : go(k_lse_wide<12, 2>);
+        if (nb == 16) return nf == 1 ? go(k_lse_wide<16, 1>) : go(k_lse_wide<16, 2>);
+        return hipErrorInvalidValue;
+    }
+    if (g.variant == 4) {  // (geometry chose the few-state kernel: nf == 1, nb <= 3, LDS-DMA staging, pitch % 64 == 0)
+        if (nf != 1 || !dma || (ld % TSS) != 0) return hipErrorInvalidValue;
+        switch (nb) {
+            case 1: return launch_lse_small_t<1>(s, g, u, ld, N, aden, cw, l0, dn, pp, op);
+            case 2: return launch_lse_small_t<2>(s, g, u, ld, N, aden, cw, l0, dn, pp, op);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (nb) {
+#define MBAR_CASE(NB_) \
+    case NB_: return launch_lse_nb<NB_>(s, nf, dma, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
+        MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7)
+        MBAR_CASE(8) MBAR_CASE(12) MBAR_CASE(16)
+#undef MBAR_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static int stream_blocks(int num_cu, int64_t N) {
+    int64_t want = (N + 255) / 256;
+    int64_t cap = (int64_t)num_cu * 8;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+// 257 .. 512 states in one read: rows = allocated row count (a multiple of 64); returns the number of partial records.
+hipError_t launch_lse_split(hipStream_t s, int num_cu, int nf, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
+                            const double* cw, double* logden, double* logden1, const double* dn, double* psum_part, double* obj_part,
+                            int* blocks_out) {
+    const int nbw = (int)((rows + 127) / 128);
+    if (nbw < 1 || nbw > 4 || nf < 1 || nf > 2) return hipErrorInvalidValue;
+    const int64_t ntiles = (N + TS - 1) / TS;
+    const size_t tile = (size_t)nbw * 16 * TS * 8 + TS * 8;
+    const size_t lds = EXP_TABLE_BYTES + (size_t)(1 + nf) * 8 * TS * 8 + (size_t)8 * 2 * tile;
+    const int blocks = (int)(ntiles < num_cu ? (ntiles < 1 ? 1 : ntiles) : num_cu);
+    *blocks_out = blocks;
+    auto go = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, u, ld, N, ntiles, rows, aden, cw, logden, logden1, dn, psum_part,
+                           obj_part);
+        return hipGetLastError();
+    };
+    if (nf == 1) {
+        switch (nbw) {
+            case 1: return go(k_lse_split<1, 1>);
+            case 2: return go(k_lse_split<2, 1>);
+            case 3: return go(k_lse_split<3, 1>);
+            default: return go(k_lse_split<4, 1>);
+        }
+    }
+    switch (nbw) {
+        case 1: return go(k_lse_split<1, 2>);
+        case 2: return go(k_lse_split<2, 2>);
+        case 3: return go(k_lse_split<3, 2>);
+        default: return go(k_lse_split<4, 2>);
+    }
+}
+
+hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
+                              const double* aden, const double* cw, double* logden, const double* dn,
+                              double* obj_part, int* blocks_out) {
+    const int blocks = stream_blocks(num_cu, N);
+    *blocks_out = blocks;
+    hipLaunchKernelGGL(k_lse_generic, dim3(blocks), dim3(256), 0, s, u, ld, N, K, aden, cw, logden, dn, obj_part);
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
+                                 const double* anum, const double* cw, const double* logden, double* psum_part,
+                                 int* blocks_out) {
+    int blocks = stream_blocks(num_cu, N);
+    if (blocks > 512) blocks = 512;
+    *blocks_out = blocks;
+    hipLaunchKernelGGL(k_colsum_generic, dim3(blocks, (unsigned)((K + 7) / 8)), dim3(256), 0, s, u, ld, N, K,
+                       anum, cw, logden, psum_part);
+    return hipGetLastError();
+}
+
+}  // namespace mbar

@@ -336,7 +336,8 @@ class DeviceMatrix:
         """{class: (total_ms, launches)} of HIP-event timed kernels since the last reset."""
         out = {}
         for name, which in (("lse", _lib.TIMER_LSE), ("gram", _lib.TIMER_GRAM), ("reduce", _lib.TIMER_REDUCE),
-                            ("other", _lib.TIMER_OTHER), ("fused", _lib.TIMER_FUSED)):
+                            ("other", _lib.TIMER_OTHER), ("fused", _lib.TIMER_FUSED), ("newton", _lib.TIMER_NEWTON),
+                            ("comm", _lib.TIMER_COMM)):
             ms = C.c_double(0.0)
             n = C.c_int64(0)
             self._check(self._lib.mbar_ctx_timing(self._ctx, which, C.byref(ms), C.byref(n)))

@@ -72,7 +72,7 @@ def solve_cases(dm, K, c_n, tol=1e-12):
 
 
 @pytest.mark.parametrize("K,N,unsampled,nranks", [(40, 20000, (7, 23), 2), (128, 30011, (5,), 2), (64, 9000, (), 3), (5, 3000, (), 2),
-                                                  (200, 16000, (11,), 2)])
+                                                  (200, 16000, (11,), 2), (128, 30011, (5,), 4), (128, 100003, (), 8), (40, 400, (7,), 8)])
 def test_device_resident_loop_across_logical_ranks(K, N, unsampled, nranks):
     from pymbar_amd.device import DeviceMatrix, LoopbackGroup
 

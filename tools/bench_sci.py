@@ -18,7 +18,6 @@ for K, N in shapes:
     N_k[-1] += N - N_k.sum()
     with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
         dm.set_Nk(N_k)
-        dm.set_option("lse_variant", int(os.environ.get("LSE_VARIANT", "1")))
         dm.set_option("small_k_kernel", int(os.environ.get("SMALL_K", "1")))  # 0: the 16-lanes-per-sample kernel for K <= 32
         f0 = np.zeros(K)
         for timing in (1, 0):

@@ -29,11 +29,6 @@ for K, N in ((128, 1_000_003), (128, 10_000_000), (256, 400_000), (192, 300_000)
             if ref is None:
                 ref = h
             assert h == ref, f"K={K}: launch {r} differs from launch 0"
-        if K == 128:
-            dm.set_option("gram_variant", 0)
-            _, _, G0 = dm.eval(f2, gram=True)
-            d = np.max(np.abs(G0 - G)) / np.max(np.abs(G))
-            assert d < 1e-13, d
         # the device-resident loop (resident probability matrix, fused sweep with hand-placed matrix instructions, LDS-DMA three
         # quarters of an iteration ahead): the whole solve bit for bit, with and without bootstrap multiplicities
         sreps = max(4, reps // 4)
