@@ -111,6 +111,8 @@ int mbar_device_synchronize(int device);
  *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
  *                    one fused sweep instead of the build sweep (default); 0 = every solve builds (cold-solve timings)
  *   "merge_select"   1 = the selection of iteration i and the Newton solve of iteration i + 1 share a launch (default)
+ *   "sci_merged"     1 = pure self-consistent iteration, K <= 32, one rank: update + sweep of an iteration in ONE launch
+ *                    (k_sci_small; default); 0 = sweep + single-workgroup update kernel (what several ranks and K > 32 run)
  *   "graph", "sci_batch"             hipGraph batching of the solver loops
  *   "timing"         HIP-event timers (mbar_ctx_timing): 0 = off (default: an event pair per sweep costs ~10 us, a fifth of an
  *                    iteration at the problem sizes pymbar is mostly used on), 1 = event records around a launch, 2 = events

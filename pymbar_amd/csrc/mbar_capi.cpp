@@ -281,7 +281,7 @@ struct mbar_ctx {
     // options
     const int64_t opt_staging = 0;  // (tiles are staged by LDS-DMA; the register-staged kernels of rounds 1-3 are gone)
     int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_wide_pmode = 1, opt_quad_trim = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -2040,6 +2040,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "device_loop_wide") c->opt_device_loop_wide = value;
     else if (k == "pcache") c->opt_pcache = value;
     else if (k == "merge_select") c->opt_merge_select = value;
+    else if (k == "sci_merged") c->opt_sci_merged = value;
     else if (k == "wide_pmode") c->opt_wide_pmode = value;
     else if (k == "quad_trim") {
         c->opt_quad_trim = value;
@@ -2674,7 +2675,6 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     HIPCHK(c, hipMemcpyAsync(d_aden(c), ha.data(), std::max(rows, Kp) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<double> hdelta(batch);
-    int64_t it = 0;
     bool done = false;
     double last_delta = std::numeric_limits<double>::quiet_NaN();
     // geometry and buffers of the fused path are fixed for the whole solve (nothing may allocate inside a capture)
@@ -2682,16 +2682,50 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     const int nbk = (int)(rows / 16);
     const int64_t ntiles = (c->N + TS - 1) / TS;
     LaunchGeom g = fast ? lse_geometry(nbk, 1, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c)) : LaunchGeom();
+    // Few states on one rank ("sci_merged", default): update and sweep of an iteration in ONE launch (k_sci_small) -- the update of
+    // iteration i rides in the prologue of the sweep at f_i, so an iteration is one kernel instead of sweep + single-workgroup
+    // update (config 2: ~9 us of a 62 us iteration).  Records / state double-buffered by the parity of the iteration, which the
+    // captured batch bakes in: batches must be even.
+    const bool merged = fast && g.variant == 4 && c->opt_sci_merged && c->nranks <= 1 && !c->comm && !stream_transport(c) &&
+                        rows == Kp && batch % 2 == 0;
     if (fast) {
-        rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rows + 1));
+        rc = ensure(c, &c->part, &c->part_doubles, std::max((size_t)g.nwaves * (rows + 1), (size_t)2 * g.blocks * rows + g.blocks));
         if (rc) return rc;
         rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 16) * (rows + 1));
         if (rc) return rc;
     }
+    if (merged) {  // iteration 0: the plain sweep at the start point leaves its records and f in the parity-0 buffers
+        HIPCHK(c, hipMemcpyAsync(c->scratch, hf.data(), rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        ScopedTimer t(c, MBAR_TIMER_LSE);
+        HIPCHK(c, launch_lse(c->stream, nbk, 1, true, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr, nullptr, nullptr, c->part,
+                             c->part + (size_t)2 * g.blocks * rows));
+    }
+    int64_t it = 0;  // iterations accepted so far
     // one SCI iteration into history slot b: sweep -> level-1 reduction -> [all-reduce] -> update (which folds the
     // last reduction level in)
     auto enqueue_iteration = [&](int64_t b, bool timed) -> int {
         double* fh = c->f_hist + (size_t)b * Kp;
+        if (merged) {
+            SciLoopArgs q;
+            q.Nk = d_Nk(c);
+            q.lnNk = d_lnNk(c);
+            q.K = (int)K;
+            q.first = first;
+            q.tol = tol;
+            q.state = c->scratch;
+            q.rec = c->part;
+            q.nrec = g.blocks;
+            q.f_hist = fh;
+            q.delta_out = d_delta(c) + b;
+            q.parity = (int)((it + b + 1) & 1);
+            if (timed) {
+                ScopedTimer t(c, MBAR_TIMER_LSE);
+                HIPCHK(c, launch_sci_small(c->stream, nbk, g, c->u, c->ld, c->N, c->cw, q));
+            } else {
+                HIPCHK(c, launch_sci_small(c->stream, nbk, g, c->u, c->ld, c->N, c->cw, q));
+            }
+            return MBAR_OK;
+        }
         if (fast) {
             double* psum_part = c->part;
             double* obj_part = c->part + (size_t)g.nwaves * rows;
@@ -2735,7 +2769,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     // Launch-bound regime (a K=32, N=1e6 sweep is ~60 us): capture a whole batch into a hipGraph and replay it.
     const bool use_graph = fast && c->opt_graph && c->nranks <= 1 && !c->comm && maxiter >= batch;  // (no per-kernel events inside a graph)
     if (use_graph) {
-        const int64_t sig = ((int64_t)g.blocks << 32) ^ ((int64_t)g.variant << 24) ^ (c->opt_staging << 16) ^ first;
+        const int64_t sig = ((int64_t)g.blocks << 32) ^ ((int64_t)g.variant << 24) ^ (merged ? (1 << 16) : 0) ^ first;
         if (!c->sci_graph || c->sci_graph_batch != batch || c->sci_graph_sig != sig || c->sci_graph_tol != tol) {
             if (c->sci_graph) HIPCHK(c, hipGraphExecDestroy(c->sci_graph));
             c->sci_graph = nullptr;

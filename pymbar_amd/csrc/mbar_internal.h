@@ -151,6 +151,25 @@ hipError_t launch_generate_harmonic(hipStream_t s, double* u, int64_t ld, int64_
 hipError_t launch_sci_update(hipStream_t s, const double* part, int64_t nparts, int64_t rows, const double* Nk,
                              const double* lnNk, int64_t K, int64_t Kp, int first_state, double tol, double* f,
                              double* aden, double* f_hist, double* delta_out);
+// Few states (K <= 32, single rank): update + sweep of ONE self-consistent iteration in one launch (k_sci_small).  Double
+// buffers by parity p of the iteration: the launch reads rec[p ^ 1] (nrec records of 16 nb doubles: the per-state sums of the
+// previous sweep, one per workgroup of the SAME geometry) and state[p ^ 1] (the previous f), writes rec[p], state[p], the
+// history row and the relative change.
+struct SciLoopArgs {
+    const double* Nk;
+    const double* lnNk;
+    int K;
+    int first;        // gauge state
+    double tol;
+    double* state;    // [2][16 nb]
+    double* rec;      // [2][nrec][16 nb]
+    int64_t nrec;
+    double* f_hist;   // [16 nb] row of the batch history this iteration fills
+    double* delta_out;
+    int parity;
+};
+hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* cw,
+                            const SciLoopArgs& q);
 hipError_t launch_reduce_level1(hipStream_t s, const double* part, int64_t nparts, int64_t count, double* out,
                                 int64_t* nchunks);
 hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink);

@@ -146,20 +146,19 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // rows.  The tile is read into registers in one go, so its single buffer is refilled immediately (two waves per
 // SIMD, 8 per workgroup).  Requires a row pitch that is a multiple of 64 (mbar_ctx_create pads it for K <= 32).
 // ---------------------------------------------------------------------------------------------
+// (the sweep proper: shared by k_lse_small and by k_sci_small, whose prologue supplies `aden` from LDS; the look-up tables are
+// in place and the workgroup has passed a barrier when this is called)
 template <int NB>
-__global__ void __launch_bounds__(512, 2)
-k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
-            const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
-            const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void lse_small_body(char* smem, const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+                                               const double* aden, const double* __restrict__ cw, double* __restrict__ logden0,
+                                               const double* __restrict__ dn, double* __restrict__ psum_part,
+                                               double* __restrict__ obj_part) {
     constexpr int ROWS = NB * 16;
     constexpr int U_BYTES = ROWS * TSS * 8;
     constexpr int TILE_BYTES = U_BYTES + TSS * 8;  // + the 64 sample weights of the tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
-    exp_table_init(smem);
-    __syncthreads();
     char* buf = smem + EXP_TABLE_BYTES + wave * TILE_BYTES;
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
@@ -246,9 +245,103 @@ k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         for (int w = 0; w < nwv; ++w) tot += fold[w * (ROWS + 1) + threadIdx.x];
         if (threadIdx.x < ROWS)
             psum_part[(int64_t)blockIdx.x * ROWS + threadIdx.x] = tot;
-        else
+        else if (obj_part)
             obj_part[blockIdx.x] = tot;
     }
+}
+template <int NB>
+__global__ void __launch_bounds__(512, 2)
+k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
+            const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
+            const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    exp_table_init(smem);
+    __syncthreads();
+    lse_small_body<NB>(smem, u, ld, N, ntiles, aden, cw, logden0, dn, psum_part, obj_part);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One self-consistent iteration (mbar_solvers.py:231-242 in a loop) of a few-state problem in ONE launch: the update that
+// turns the previous sweep's per-state sums into the next f rides in the PROLOGUE of the sweep that evaluates it.  Every
+// workgroup sums the previous launch's partial records (one per workgroup, a few hundred) in the same fixed order -- identical
+// inputs, identical bits, no broadcast -- forms f' = f - log(psum / N) with the gauge f'[first] = 0 (:588) and a' = f' + ln N in
+// LDS, and then runs k_lse_small's sweep at a'.  Workgroup 0 also publishes f', the relative change (:627-631) and the history
+// row.  Records and the state vector are double-buffered by the parity of the iteration: a workgroup that is still in its
+// prologue reads what the previous launch wrote while an early one already writes this launch's record.
+// At config 2 (K=32, N=1e6: a 52 us sweep) the separate single-workgroup update kernel + its launch gap were ~9 us per iteration.
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__global__ void __launch_bounds__(512, 2)
+k_sci_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cw, SciLoopArgs q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = NB * 16;
+    constexpr int G = 512 / ROWS;  // groups of threads that share the record sum of one state
+    exp_table_init(smem);
+    double* scr = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);  // (the tile buffers are not in use yet)
+    double* ps = scr + 512;        // [ROWS] reduced per-state sums
+    double* a_s = ps + ROWS;       // [ROWS] a' = f' + ln N (-inf: no samples / padding)
+    double* fn_s = a_s + ROWS;     // [ROWS] f'
+    double* red = fn_s + ROWS;     // [2]: gauge shift, max relative change
+    const int tid = threadIdx.x;
+    const int par = q.parity;
+    const double* rprev = q.rec + (int64_t)(par ^ 1) * q.nrec * ROWS;
+    const double* fprev = q.state + (int64_t)(par ^ 1) * ROWS;
+    {
+        const int k = tid % ROWS, g = tid / ROWS;
+        double sm = 0.0;
+#pragma unroll 8  // (same order in every workgroup; eight record loads in flight together)
+        for (int64_t p = g; p < q.nrec; p += G) sm += rprev[p * ROWS + k];
+        scr[g * ROWS + k] = sm;
+    }
+    __syncthreads();
+    if (tid < ROWS) {
+        double tot = 0.0;
+        for (int g = 0; g < G; ++g) tot += scr[g * ROWS + tid];
+        ps[tid] = tot;
+    }
+    __syncthreads();
+    if (tid == 0) red[0] = fprev[q.first] - log(ps[q.first] / q.Nk[q.first]);
+    __syncthreads();
+    if (tid < 64) {  // one wave: states tid (and tid + 64 would not exist: ROWS <= 32)
+        const double small = q.tol < 1e-8 ? q.tol : 1e-8;
+        double d = 0.0;
+        if (tid < ROWS) {
+            const int k = tid;
+            const bool sampled = k < q.K && q.Nk[k] > 0.0;
+            const double fo = fprev[k];
+            double fnew = fo, an = -INFINITY;
+            if (sampled) {
+                fnew = fo - log(ps[k] / q.Nk[k]) - red[0];
+                an = fnew + q.lnNk[k];
+                if (k != q.first) {
+                    const double div = fabs(fnew) < small ? 1.0 : fabs(fnew);
+                    d = fabs(fnew - fo) / div;
+                }
+            }
+            fn_s[k] = fnew;
+            a_s[k] = an;
+        }
+        // NaN-propagating maximum over the wave
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const double o = __shfl_xor(d, sft);
+            d = (o > d || o != o) ? o : d;
+        }
+        if (tid == 0) red[1] = d;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < ROWS) {
+        q.state[(int64_t)par * ROWS + tid] = fn_s[tid];
+        q.f_hist[tid] = tid < q.K ? fn_s[tid] : 0.0;
+        if (tid == 0) *q.delta_out = red[1];
+    }
+    double* rec = q.rec + (int64_t)par * q.nrec * ROWS;
+    // (the body copies a' into registers before it touches the tile buffers; its first DMA lands behind the barrier below)
+    double a_loc[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) a_loc[k] = a_s[k];
+    __syncthreads();
+    lse_small_body<NB>(smem, u, ld, N, ntiles, a_loc, cw, nullptr, nullptr, rec, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -694,6 +787,23 @@ static hipError_t launch_lse_small_t(hipStream_t s, const LaunchGeom& g, const d
     hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, l0, dn,
                        psum_part, obj_part);
     return hipGetLastError();
+}
+
+hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* cw,
+                            const SciLoopArgs& q) {
+    if (g.variant != 4 || (ld % TSS) != 0 || q.nrec != g.blocks) return hipErrorInvalidValue;
+    auto go = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TSS - 1) / TSS;
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, cw, q);
+        return hipGetLastError();
+    };
+    if (nb == 1) return go(k_sci_small<1>);
+    if (nb == 2) return go(k_sci_small<2>);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,

@@ -36,6 +36,16 @@ k_rinv_weighted(const double* __restrict__ rinv, const double* __restrict__ cw, 
 // the LDS tile in place of the energies they came from and leave with coalesced 16-byte stores that mirror the DMA
 // pattern (8 lanes per 128-byte row), so the pass moves 8 K N bytes in and 8 K N out instead of the separate
 // sweep + build (8 + 16).  The reciprocal slot of the anchor point is all ones.
+// 16-byte store of two entries of P.  MBAR_P_STORE_NT (A/B build): with the non-temporal hint -- P is not read again before the
+// next sweep, so its lines need not displace the tile stream in L2.
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_p16(char* dst, const double2& v) {
+#if defined(MBAR_P_STORE_NT)
+    __builtin_nontemporal_store(v2d{v.x, v.y}, reinterpret_cast<v2d*>(dst));
+#else
+    *reinterpret_cast<double2*>(dst) = v;
+#endif
+}
 template <int NB>
 __device__ __forceinline__ void build_two_groups(char* cbuf, int rd0, int rd1, const double (&a)[NB], double (&acc)[NB],
                                                  double w0, double w1) {
@@ -142,7 +152,7 @@ k_build_sweep(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntile
         for (int j = 0; j < NDMA; ++j) {
             const double2 v = *reinterpret_cast<const double2*>(cbuf + j * 1024 + lane * 16);
             char* dst = reinterpret_cast<char*>(P + (int64_t)(8 * j) * ld + t * TS) + so.off[j & 1];
-            *reinterpret_cast<double2*>(dst) = v;
+            store_p16(dst, v);
         }
         {   // 1 / s_n = 1 at the anchor point (one store instruction per tile, like the sweeps' logden / reciprocal store)
             const int64_t n = t * TS + lane;
@@ -278,7 +288,7 @@ k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles
         for (int j = 0; j < NDMA; ++j) {
             const double2 v = *reinterpret_cast<const double2*>(cbuf + j * 1024 + lane * 16);
             char* dst = reinterpret_cast<char*>(P + (int64_t)(8 * j) * ld + t * TS) + so.off[j & 1];
-            *reinterpret_cast<double2*>(dst) = v;
+            store_p16(dst, v);
         }
         {
             const int64_t n = t * TS + lane;

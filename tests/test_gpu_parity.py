@@ -962,3 +962,43 @@ def test_call_sequence_of_the_unchanged_reference_class_on_host_arrays(golden):
     Theta = oracle.covariance_theta(W, N_k, "svd-ew")                              # mbar.py:703 (restated in the oracle)
     np.testing.assert_allclose(oracle.error_of_differences(Theta), g["dDelta_f_svd_ew"], rtol=1e-7, atol=1e-10)
     ms.drop_resident_cache()
+
+
+@pytest.mark.parametrize("K,N,unsampled", [(5, 3000, ()), (16, 70_000, (3,)), (20, 9999, (0, 19)), (32, 250_000, ()), (32, 64, ())])
+def test_sci_iteration_in_one_launch_agrees_with_sweep_plus_update(DM, K, N, unsampled):
+    """Few states, one rank: the self-consistent iteration as ONE launch per iteration (k_sci_small: the update in the prologue
+    of the sweep, records and state double-buffered by parity) against the two-kernel iteration (sweep + single-workgroup
+    update) -- fixed iteration counts (odd, even, beyond one hipGraph batch), to convergence, with draw counts, eager and
+    graph-replayed -- and against the oracle's loop."""
+    u_kn, N_k, f = random_problem(K, N, seed=7 * K + 1, unsampled=unsampled)
+    sws = np.where(N_k > 0)[0]
+    rng = np.random.default_rng(K)
+    c_n = np.zeros(N)
+    start = 0
+    for n_k in N_k:
+        if n_k > 0:
+            c_n[start:start + n_k] = np.bincount(rng.integers(0, n_k, size=n_k), minlength=n_k)
+        start += n_k
+    with DM.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        for weights in (None, c_n):
+            dm.set_sample_weights(weights)
+            for graph in (1, 0):
+                dm.set_option("graph", graph)
+                for kw in (dict(maxiter=1, check_convergence=False), dict(maxiter=7, check_convergence=False),
+                           dict(maxiter=40, check_convergence=False), dict(tol=1e-11, maxiter=5000)):
+                    out = {}
+                    for merged in (0, 1):
+                        dm.set_option("sci_merged", merged)
+                        out[merged] = dm.solve_sci(np.zeros(K), **kw)
+                    (f0, r0), (f1, r1) = out[0], out[1]
+                    assert r0["iterations"] == r1["iterations"] and r0["success"] == r1["success"], (kw, graph, r0, r1)
+                    np.testing.assert_allclose(f1[sws], f0[sws], rtol=1e-12, atol=1e-12, err_msg=str((kw, graph)))
+                    assert np.array_equal(f1[N_k == 0], np.zeros(int((N_k == 0).sum())))  # states without samples are left alone
+        dm.set_sample_weights(None)
+        dm.set_option("graph", 1)
+        dm.set_option("sci_merged", 1)
+        f_dev, r_dev = dm.solve_sci(np.zeros(K), tol=1e-11, maxiter=5000)
+    r_or = oracle.sci_solve(u_kn[sws], N_k[sws], np.zeros(len(sws)), tol=1e-11, maxiter=5000)
+    assert r_or["success"] and r_dev["success"] and abs(r_or["iterations"] - r_dev["iterations"]) <= 1
+    np.testing.assert_allclose(f_dev[sws] - f_dev[sws][0], r_or["x"] - r_or["x"][0], rtol=1e-9, atol=1e-9)

@@ -19,6 +19,7 @@ for K, N in shapes:
     with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
         dm.set_Nk(N_k)
         dm.set_option("small_k_kernel", int(os.environ.get("SMALL_K", "1")))  # 0: the 16-lanes-per-sample kernel for K <= 32
+        dm.set_option("sci_merged", int(os.environ.get("SCI_MERGED", "1")))  # 0: sweep + separate update kernel per iteration
         f0 = np.zeros(K)
         for timing in (1, 0):
             dm.set_option("timing", timing)
