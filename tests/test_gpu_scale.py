@@ -32,13 +32,15 @@ def _assert_delta_f(f, f_ref, what):
 
 
 def _assert_counts(res, g, suffix=""):
-    assert res["success"] and bool(g["adaptive_success" if not suffix else "adaptive_success"])
+    assert res["success"] and bool(g["adaptive_success"])
     assert res["iterations"] == int(g["adaptive_iters" + suffix])
-    assert res["nr_iter"] == int(g["adaptive_nr" + suffix]) and res["sci_iter"] == int(g["adaptive_sci" + suffix])
     choices = g["adaptive_choices" + suffix]
-    # (the LAST iteration of a converged solve compares two gradient norms at round-off level: noise in the reference itself)
+    # The LAST iteration of a converged solve compares two gradient norms at round-off level (both candidates ARE the fixed
+    # point): its choice is noise in the reference itself, so the Newton-Raphson / self-consistent split may differ by that one.
     n = len(choices) - 1
     assert np.array_equal(res["history"][:n, 0].astype(np.int8), choices[:n])
+    assert res["nr_iter"] + res["sci_iter"] == res["iterations"]
+    assert abs(res["nr_iter"] - int(g["adaptive_nr" + suffix])) <= 1 and abs(res["sci_iter"] - int(g["adaptive_sci" + suffix])) <= 1
 
 
 def _mbar_journey(u_kn, N_k, g):
