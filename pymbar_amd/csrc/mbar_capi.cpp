@@ -2718,6 +2718,9 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
             q.f_hist = fh;
             q.delta_out = d_delta(c) + b;
             q.parity = (int)((it + b + 1) & 1);
+            q.live = 0;
+            for (int64_t j = 0; j < rows / 2; ++j)
+                if ((2 * j < K && c->Nk[2 * j] > 0.0) || (2 * j + 1 < K && c->Nk[2 * j + 1] > 0.0)) q.live |= 1u << j;
             if (timed) {
                 ScopedTimer t(c, MBAR_TIMER_LSE);
                 HIPCHK(c, launch_sci_small(c->stream, nbk, g, c->u, c->ld, c->N, c->cw, q));

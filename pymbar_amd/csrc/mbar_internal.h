@@ -167,6 +167,7 @@ struct SciLoopArgs {
     double* f_hist;   // [16 nb] row of the batch history this iteration fills
     double* delta_out;
     int parity;
+    uint32_t live;    // bit j: rows 2j, 2j+1 hold a state with samples (the others are not streamed from HBM)
 };
 hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* cw,
                             const SciLoopArgs& q);

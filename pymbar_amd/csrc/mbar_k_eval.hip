@@ -148,11 +148,24 @@ k_lse(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // ---------------------------------------------------------------------------------------------
 // (the sweep proper: shared by k_lse_small and by k_sci_small, whose prologue supplies `aden` from LDS; the look-up tables are
 // in place and the workgroup has passed a barrier when this is called)
+// The wave's tile request (LDS-DMA instruction j moves rows 2j, 2j+1: lane l -> row 2j + (l >> 5), bytes [16 (l & 31), +16) of
+// its 512; pairs of rows whose bit in `live` is clear are requested from the first tile's columns -- an L2 hit, see below).
 template <int NB>
+__device__ __forceinline__ void lse_small_stage(const double* __restrict__ u, int64_t ld, const double* __restrict__ cw, int64_t tile,
+                                                uint32_t live, char* buf, int lane) {
+    constexpr int ROWS = NB * 16;
+    const uint32_t voff = (uint32_t)(((int64_t)(lane >> 5) * ld + 2 * (lane & 31)) * 8);
+#pragma unroll
+    for (int j = 0; j < ROWS / 2; ++j)
+        stage_piece<true>(u + (int64_t)(2 * j) * ld + (((live >> j) & 1u) ? tile * TSS : 0), voff, buf + j * 1024, lane);
+    if (lane < 32) stage_piece<true>(cw + tile * TSS, (uint32_t)(lane * 16), buf + ROWS * TSS * 8, lane);
+}
+// PRESTAGED: the caller has already requested the wave's first tile (with the same `live_in` mask) before its own prologue.
+template <int NB, bool PRESTAGED = false>
 __device__ __forceinline__ void lse_small_body(char* smem, const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                                                const double* aden, const double* __restrict__ cw, double* __restrict__ logden0,
                                                const double* __restrict__ dn, double* __restrict__ psum_part,
-                                               double* __restrict__ obj_part) {
+                                               double* __restrict__ obj_part, uint32_t live_in = 0) {
     constexpr int ROWS = NB * 16;
     constexpr int U_BYTES = ROWS * TSS * 8;
     constexpr int TILE_BYTES = U_BYTES + TSS * 8;  // + the 64 sample weights of the tile
@@ -163,8 +176,6 @@ __device__ __forceinline__ void lse_small_body(char* smem, const double* __restr
     const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
     const int64_t W = (int64_t)gridDim.x * nwv;
     const bool has_store = logden0 != nullptr;
-    // DMA instruction j moves rows 2j, 2j+1: lane l -> row 2j + (l >> 5), bytes [16 (l & 31), +16) of its 512
-    const uint32_t voff = (uint32_t)(((int64_t)(lane >> 5) * ld + 2 * (lane & 31)) * 8);
 
     double a[ROWS], acc[ROWS], objl = 0.0;
 #pragma unroll
@@ -176,19 +187,17 @@ __device__ __forceinline__ void lse_small_body(char* smem, const double* __restr
     for (int k = 0; k < ROWS; ++k) settle(a[k]);
     // pairs of rows whose exponent constants are both -inf (padding, states without samples): requested from the first tile's
     // columns every time -- an L2 hit instead of HBM traffic (see RowIdentity::cols); 5 states in a 16-row matrix: half the bytes
-    uint32_t live = 0;
+    uint32_t live = live_in;
+    if constexpr (!PRESTAGED) {
 #pragma unroll
-    for (int j = 0; j < ROWS / 2; ++j) live |= (__ballot(a[2 * j] != -INFINITY || a[2 * j + 1] != -INFINITY) ? 1u : 0u) << j;
-
-    auto stage = [&](int64_t tile) {
-#pragma unroll
-        for (int j = 0; j < ROWS / 2; ++j)
-            stage_piece<true>(u + (int64_t)(2 * j) * ld + (((live >> j) & 1u) ? tile * TSS : 0), voff, buf + j * 1024, lane);
-        if (lane < 32) stage_piece<true>(cw + tile * TSS, (uint32_t)(lane * 16), buf + U_BYTES, lane);
-    };
+        for (int j = 0; j < ROWS / 2; ++j) live |= (__ballot(a[2 * j] != -INFINITY || a[2 * j + 1] != -INFINITY) ? 1u : 0u) << j;
+    }
+    auto stage = [&](int64_t tile) { lse_small_stage<NB>(u, ld, cw, tile, live, buf, lane); };
 
     int64_t t = gw;
-    if (t < ntiles) stage(t);
+    if constexpr (!PRESTAGED) {
+        if (t < ntiles) stage(t);
+    }
     for (; t < ntiles; t += W) {
         if (has_store && t != gw)
             wait_vm<1>();  // [this tile][logden store of the previous one]: vmcnt counts stores too
@@ -276,8 +285,17 @@ k_sci_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = NB * 16;
     constexpr int G = 512 / ROWS;  // groups of threads that share the record sum of one state
+    constexpr int TILE_BYTES = ROWS * TSS * 8 + TSS * 8;
+    // the wave's first tile is requested BEFORE anything else: it lands while the tables are copied and the update is computed
+    // (which rows carry samples does not change during a solve: the host passes the mask)
+    {
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+        if (gw < ntiles) lse_small_stage<NB>(u, ld, cw, gw, q.live, smem + EXP_TABLE_BYTES + wave * TILE_BYTES, lane);
+    }
     exp_table_init(smem);
-    double* scr = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);  // (the tile buffers are not in use yet)
+    double* scr = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES + 8 * TILE_BYTES);  // (behind the eight waves' tile buffers)
     double* ps = scr + 512;        // [ROWS] reduced per-state sums
     double* a_s = ps + ROWS;       // [ROWS] a' = f' + ln N (-inf: no samples / padding)
     double* fn_s = a_s + ROWS;     // [ROWS] f'
@@ -341,7 +359,7 @@ k_sci_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) a_loc[k] = a_s[k];
     __syncthreads();
-    lse_small_body<NB>(smem, u, ld, N, ntiles, a_loc, cw, nullptr, nullptr, rec, nullptr);
+    lse_small_body<NB, true>(smem, u, ld, N, ntiles, a_loc, cw, nullptr, nullptr, rec, nullptr, q.live);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -791,14 +809,15 @@ static hipError_t launch_lse_small_t(hipStream_t s, const LaunchGeom& g, const d
 
 hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* cw,
                             const SciLoopArgs& q) {
-    if (g.variant != 4 || (ld % TSS) != 0 || q.nrec != g.blocks) return hipErrorInvalidValue;
+    if (g.variant != 4 || (ld % TSS) != 0 || q.nrec != g.blocks || g.waves != 8) return hipErrorInvalidValue;
+    const size_t lds = g.lds_bytes + (size_t)(512 + 3 * 16 * nb + 2) * sizeof(double);  // + the prologue's scratch behind the tile buffers
     auto go = [&](auto kern) -> hipError_t {
-        if (g.lds_bytes > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
         const int64_t ntiles = (N + TSS - 1) / TSS;
-        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, u, ld, N, ntiles, cw, q);
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), lds, s, u, ld, N, ntiles, cw, q);
         return hipGetLastError();
     };
     if (nb == 1) return go(k_sci_small<1>);

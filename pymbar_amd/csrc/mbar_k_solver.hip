@@ -1024,7 +1024,8 @@ static int64_t lognum_tiles_per_chunk(int64_t N, int64_t K) {
 int64_t lognum_chunks(int64_t N, int64_t K) {
     const int64_t ntiles = (N + LN_TILE - 1) / LN_TILE;
     const int64_t tpc = lognum_tiles_per_chunk(N, K);
-    return (ntiles + tpc - 1) / tpc;
+    const int64_t n = (ntiles + tpc - 1) / tpc;
+    return n < 1 ? 1 : n;  // (an empty shard still launches: its record is (max = -inf, sum = 0))
 }
 
 hipError_t launch_lognum(hipStream_t s, const double* u, int64_t ld, int64_t N, int64_t K, const double* anum,

@@ -37,9 +37,12 @@ def run_ranks(nranks, worker, timeout=400.0):
     for t in threads:
         t.join(timeout)
     assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
-    for e in err:
-        if e is not None:
-            raise e
+    errors = [(r, e) for r, e in enumerate(err) if e is not None]
+    if errors:
+        # the root cause first: a rank that fails leaves its peers waiting in a collective ("a peer did not arrive")
+        roots = [(r, e) for r, e in errors if "did not arrive" not in str(e)] or errors
+        r, e = roots[0]
+        raise AssertionError(f"rank {r} of {nranks}: {type(e).__name__}: {e} (ranks with errors: {[x for x, _ in errors]})") from e
     return out
 
 
@@ -113,7 +116,15 @@ def test_device_resident_loop_across_logical_ranks(K, N, unsampled, nranks):
     np.testing.assert_allclose(r0["lognum"], ref_lognum, rtol=1e-13, atol=1e-12)
     np.testing.assert_allclose(r0["gw"][0], ref_gw[0], rtol=1e-11, atol=1e-300)
     for case, (fa, ra), (fr, rr) in zip(CASES, r0["solves"], ref):
-        assert ra["iterations"] == rr["iterations"] and ra["success"] == rr["success"], (case, ra, rr)
+        assert ra["success"] == rr["success"], (case, ra, rr)
+        # (a relative change that lands within a factor of a few of the tolerance converges an iteration earlier or later
+        # depending on the summation order over the shards: 1.04e-12 against tol 1e-12 at 8 ranks)
+        h_all = np.concatenate([ra["history"][:, 3], rr["history"][:, 3]])
+        near_tol = bool(np.any((h_all > 0.2 * tol) & (h_all < 5.0 * tol)))
+        if near_tol and "fixed" not in case and abs(ra["iterations"] - rr["iterations"]) == 1:
+            np.testing.assert_allclose(fa[sws], fr[sws], rtol=1e-10, atol=1e-10, err_msg=str(case))
+            continue
+        assert ra["iterations"] == rr["iterations"], (case, ra["iterations"], rr["iterations"])
         # (the choice between two gradient norms at round-off level is noise, and the shards sum in another order)
         clear = np.abs(rr["history"][:, 1] - rr["history"][:, 2]) > 1e-7
         assert np.array_equal(ra["history"][clear, 0], rr["history"][clear, 0]), case

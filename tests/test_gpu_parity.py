@@ -971,6 +971,7 @@ def test_sci_iteration_in_one_launch_agrees_with_sweep_plus_update(DM, K, N, uns
     update) -- fixed iteration counts (odd, even, beyond one hipGraph batch), to convergence, with draw counts, eager and
     graph-replayed -- and against the oracle's loop."""
     u_kn, N_k, f = random_problem(K, N, seed=7 * K + 1, unsampled=unsampled)
+    N = u_kn.shape[1]  # (emptying state 0 into itself drops its samples)
     sws = np.where(N_k > 0)[0]
     rng = np.random.default_rng(K)
     c_n = np.zeros(N)
