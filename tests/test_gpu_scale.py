@@ -107,8 +107,8 @@ def test_config2_full_size_matches_the_reference(golden):
 
 def test_128_states_1e6_samples_match_the_reference(golden):
     """The headline state count at the largest N the reference's whole class journey is comfortable with (K=128, N=1e6):
-    adaptive from zeros on one context, on 2 and on 8 logical ranks (config-4-shaped sharding; N / 8 = 125 000 is not a multiple
-    of the 16-sample tile, one more run has a rank with an EMPTY shard), and MBAR() -> Delta_f / dDelta_f."""
+    adaptive from zeros on one context, on 2 and on 8 logical ranks (config-4-shaped sharding; one more run with ragged shards:
+    an EMPTY one, one of 17 columns, one of a single column, nothing tile-aligned), and MBAR() -> Delta_f / dDelta_f."""
     from pymbar_amd.device import DeviceMatrix
 
     g = golden("scale_K128_N1e6.npz")
@@ -128,8 +128,9 @@ def test_128_states_1e6_samples_match_the_reference(golden):
     _mbar_journey(u_kn, N_k, g)
     _logical_ranks(u_kn, N_k, 2, g)
     _logical_ranks(u_kn, N_k, 8, g)
-    ragged = [(0, 100_003), (100_003, 100_003), (100_003, 333_329), (333_329, 600_000), (600_000, 600_017), (600_017, 777_777),
-              (777_777, 999_999), (999_999, N)]  # (an empty shard, shards of 14 and 1 columns, nothing tile-aligned)
+    assert N == 999_936  # (128 x 7812: the generator rounds N / K down)
+    cuts = [0, 100_003, 100_003, 333_329, 600_000, 600_017, 777_777, N - 1, N]  # an empty shard, shards of 17 and 1 columns,
+    ragged = list(zip(cuts[:-1], cuts[1:]))                                       # nothing tile-aligned
     _logical_ranks(u_kn, N_k, 8, g, shards=ragged)
 
 
