@@ -25,19 +25,12 @@ namespace mbar {
 //     accumulators only then).
 // wsq: sqrt of the per-sample multiplicities (= cw itself for plain 0 / 1 weights).
 // ---------------------------------------------------------------------------------------------
-// Diagonal 16 x 16 blocks of the full panel as 4 x 4 sub-blocks (MBAR_FUSED_DIAG4, A/B build): with A = the block's operand and
-// B = the same states, v_mfma_f64_4x4x4_4b_f64 gives the four sub-blocks (b, b) at once; with B the states ROTATED by 4 (8) inside
-// each 16-state block the sub-blocks (b, b + 1) ((b, b + 2)): three instructions of 16 cycles cover the block (the wrapped
-// sub-blocks are transposes of wanted ones) where the 16x16x4 instruction spends 64 cycles, half of them below the diagonal --
-// 512 of a tile's 9216 matrix-pipe cycles.  Round 2 built this with DPP-rotated copies of the scaled operand and measured it 1 %
-// SLOWER (64 DPP moves per tile on the pipe the matrix instructions share: profiles/r2_fused_sweep_anatomy.txt, section 5).
-// Here the rotated operand costs no vector instruction at all: the per-sample scale goes on ONE side only,
-//     G' = sum_n (P_n w_n / s_n^2) P_n^T,
-// so every B operand -- rotated or not -- is the RAW tile entry, read from LDS through a rotated lane map (an LDS read issues
-// in the shadow of a running matrix instruction).
-#ifndef MBAR_FUSED_DIAG4
-#define MBAR_FUSED_DIAG4 0
-#endif
+// (Measured dead end, twice: the diagonal 16 x 16 blocks of the full panel as three v_mfma_f64_4x4x4_4b_f64 each -- 48 matrix-pipe
+// cycles instead of 64, half of the 16x16x4 block lies below the diagonal.  Round 2, with DPP-rotated copies of the scaled operand:
+// 1 % SLOWER (profiles/r2_fused_sweep_anatomy.txt, section 5).  Round 4, with NO vector instruction for it -- the per-sample scale
+// on the A side only, G' = sum_n (P_n w_n / s_n^2) P_n^T, every B operand the raw tile entry, the rotated ones read from LDS through a
+// rotated lane map -- parity-green and within +-1 % of the 16x16x4 blocks in three alternations on one box
+// (profiles/r4_ab_fused_diag_subblocks_from_lds.txt): a 4x4x4 instruction costs the wave more than its 16 pipe cycles.)
 // Schedule of the 2 NB 4x4x4 steps a group carries (k_fused): how many have been issued once row I of the group's Gram blocks
 // is out.  Narrow panels: two per row, the rest after the last-but-one row.  NB >= 4: the first NB (one operand batch) two per
 // row, the second batch spread over the rows that remain before the last.
@@ -113,23 +106,11 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
     v4d G[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) G[b] = v4d{0.0, 0.0, 0.0, 0.0};
-    constexpr bool DIAG4 = PINNED && (MBAR_FUSED_DIAG4 != 0);
-    double Dg[DIAG4 ? NB : 1][3];
-#pragma unroll
-    for (int I = 0; I < (DIAG4 ? NB : 1); ++I) Dg[I][0] = Dg[I][1] = Dg[I][2] = 0.0;
 
     const int rd_base = ks * (TS * 8);
     int pos[GROUPS];
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
-    // rotated lane maps of the diagonal sub-blocks: this lane reads state (ks + 4) & 15 / (ks + 8) & 15 of the block, same sample
-    int rot4[GROUPS], rot8[GROUPS];
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g) {
-        const int k4 = (ks + 4) & 15, k8 = (ks + 8) & 15;
-        rot4[g] = k4 * (TS * 8) + ((4 * g + ns + (k4 & 14)) & 15) * 8;
-        rot8[g] = k8 * (TS * 8) + ((4 * g + ns + (k8 & 14)) & 15) * 8;
-    }
     const int sq = ns + 4 * ((lane >> 2) & 3);  // the lane's sample and candidate in the layout the 4x4x4 blocks leave
     const int fq = lane & 3;
 
@@ -236,8 +217,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                 if constexpr (ACC1) settle(acc[1][I]);
             }
             // (a padded sample needs no mask: its multiplicity and the root of it are stored as zeros)
-            // operand scale of the speculated candidate's Gram matrix: sqrt(w) / s on both sides, or (DIAG4) w / s^2 on the A side only
-            const double rin = DIAG4 ? (r1 * r1) * w[gc] : r1 * sw[gc];
+            const double rin = r1 * sw[gc];  // operand of the Newton-Raphson candidate's Gram matrix
             double p[NB];
 #pragma unroll
             for (int I = 0; I < NB; ++I) p[I] = uv[gc][I] * rin;
@@ -269,7 +249,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
             }
             auto mfma = [&](int b, double x, double y) {
                 if constexpr (PINNED) {
-                    if (DIAG4 || b < GRAM_AGPR_BLOCKS)  // (without the diagonal blocks all 28 fit the AGPRs)
+                    if (b < GRAM_AGPR_BLOCKS)
                         asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(G[b]) : "v"(x), "v"(y));
                     else
                         asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(G[b]) : "v"(x), "v"(y));
@@ -277,22 +257,11 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                     G[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, G[b], 0, 0, 0);
                 }
             };
-            // raw tile entries through the rotated lane maps, three rows in flight: row 0's here, row I + 1's behind the first
-            // 16x16x4 block of row I (the last row's one row earlier: row NB - 2 has a single off-diagonal block)
-            double rot[3][2];
-            auto request_rot = [&](int I) {
-                rot[I % 3][0] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rot4[g]);
-                rot[I % 3][1] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + rot8[g]);
-            };
-            auto diag4 = [&](double& d, double x, double y) {
-                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
-            };
-            if constexpr (DIAG4) request_rot(0);
             if constexpr (PINNED) {  // (asm MFMAs are opaque to the scheduler and the hazard recogniser: see k_gram)
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 7");
             }
-            constexpr int NM = DIAG4 ? NBLK - NB : NBLK;  // 16x16x4 instructions per group
+            constexpr int NM = NBLK;  // 16x16x4 instructions per group
             int b = 0, nm = 0;
 #pragma unroll
             for (int I = 0; I < NB; ++I) {
@@ -302,20 +271,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                 }
 #pragma unroll
                 for (int J = I; J < NB; ++J) {
-                    if (DIAG4 && J == I) {  // (the diagonal block follows its row's off-diagonal ones: its rotated operands have landed)
-                        ++b;
-                        continue;
-                    }
-                    // DIAG4: the scale sits on the A side only, B is the raw tile entry
-                    mfma(b, p[I], DIAG4 ? uv[gc][J] : p[J]);
-                    if constexpr (DIAG4) {
-                        const int nxt = (J == I + 1 && I + 1 < NB - 1) ? I + 1 : ((I == NB - 3 && J == NB - 1) ? NB - 1 : -1);
-                        if (nxt > 0) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            request_rot(nxt);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
+                    mfma(b, p[I], p[J]);
                     if constexpr (PINNED) {
                         if (nm == 0 || nm == 1) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -336,11 +292,6 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
                     }
                     ++b;
                     ++nm;
-                }
-                if constexpr (DIAG4) {
-                    diag4(Dg[I][0], p[I], uv[gc][I]);
-                    diag4(Dg[I][1], p[I], rot[I % 3][0]);
-                    diag4(Dg[I][2], p[I], rot[I % 3][1]);
                 }
                 // 4x4x4 steps of the next tile after every row of blocks but the last (so that the accumulators are long
                 // complete when the VALU reads them): fused_steps_done(I) of the group's 2 NB steps are issued by row I
@@ -381,26 +332,9 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
         for (int I = 0; I < NB; ++I)
 #pragma unroll
             for (int J = I; J < NB; ++J, ++b) {
-                if (DIAG4 && J == I) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = G[b][r];
             }
-    }
-    if constexpr (DIAG4) {
-        // the 4 x 4 sub-blocks into the row-major 16 x 16 record the 16x16x4 instruction would have left: lane j + 4 b + 16 i holds
-        // element (4 b + i, 4 b' + j), b' = b, b + 1, b + 2 (mod 4) for the three accumulators; (b, b + 1) also lands transposed, so
-        // all 16 sub-blocks of the record are written.
-        const int jj = lane & 3, bb = (lane >> 2) & 3, ii = lane >> 4;
-        const int b1 = (bb + 1) & 3, b2 = (bb + 2) & 3;
-        const int row = 4 * bb + ii;
-#pragma unroll
-        for (int I = 0; I < NB; ++I) {
-            double* rec = gram_part + (gw * NBLK + (I * NB - (I * (I - 1)) / 2)) * 256;
-            rec[row * 16 + 4 * bb + jj] = Dg[I][0];
-            rec[row * 16 + 4 * b1 + jj] = Dg[I][1];
-            rec[(4 * b1 + jj) * 16 + row] = Dg[I][1];
-            rec[row * 16 + 4 * b2 + jj] = Dg[I][2];
-        }
     }
 }
 
