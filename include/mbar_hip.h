@@ -176,6 +176,14 @@ int mbar_ctx_set_Nk(mbar_ctx* ctx, const double* N_k);
  * state) is the vector of draw counts, so replicates re-use the resident matrix instead of a gathered copy. */
 int mbar_ctx_set_sample_weights(mbar_ctx* ctx, const double* c_n);
 
+/* Per-sample weights c_n = (A_n - shift)^power from the observable mbar_ctx_vec_logshift left in the staging vector (as
+ * log(A_n - shift)), formed on the device: no upload, no host pass over N doubles.  What it is for: ONE observable evaluated at
+ * the resident states (compute_expectations(A_n), mbar.py:1039-1312) needs no augmented matrix at all -- the weight column of
+ * "A at state l" is A'_n W_nl up to a constant, so the observable rows' normalisers are mbar_lognum with weights A' and the
+ * covariance input of mbar.py:886-903 is the three weighted Gram matrices sum_n A'^p W W^T, p = 0, 1, 2, of the RESIDENT matrix
+ * (mbar_gram_w with these weights).  mbar_ctx_set_sample_weights(ctx, NULL) restores c_n = 1. */
+int mbar_ctx_weights_from_vec(mbar_ctx* ctx, double power);
+
 /* ---- multi-GPU (one process per GPU; N sharded; one small all-reduce per pass) ------------- */
 int mbar_comm_unique_id(void* id128);                 /* rank 0: ncclGetUniqueId (128 bytes)     */
 int mbar_ctx_comm_init(mbar_ctx* ctx, const void* id128, int rank, int nranks); /* RCCL over xGMI */

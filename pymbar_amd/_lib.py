@@ -76,6 +76,7 @@ SIGNATURES = {
     "mbar_ctx_generate_harmonic": (C.c_int, [_ctx, C.c_uint64, _dp, _dp, _ip, C.c_int64]),
     "mbar_ctx_set_Nk": (C.c_int, [_ctx, _dp]),
     "mbar_ctx_set_sample_weights": (C.c_int, [_ctx, _dp]),
+    "mbar_ctx_weights_from_vec": (C.c_int, [_ctx, C.c_double]),
     "mbar_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mbar_ctx_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "mbar_ctx_set_host_allreduce": (C.c_int, [_ctx, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]),

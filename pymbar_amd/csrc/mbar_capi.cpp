@@ -2295,6 +2295,26 @@ int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
     return MBAR_OK;
 }
 
+int mbar_ctx_weights_from_vec(mbar_ctx* c, double power) {
+    if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (!c->vec_tmp) return fail(c, MBAR_ERR_STATE, "mbar_ctx_weights_from_vec: no observable in the staging vector (mbar_ctx_vec_logshift first)");
+    if (!(std::fabs(power) <= 8.0)) return fail(c, MBAR_ERR_ARG, "mbar_ctx_weights_from_vec: |power| must be <= 8");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->lden_eff) {
+        HIPCHK(c, cache_malloc((void**)&c->lden_eff, (size_t)c->ld * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->lden_eff, 0, (size_t)c->ld * sizeof(double), c->stream));
+    }
+    if (!c->cwsq) {
+        HIPCHK(c, cache_malloc((void**)&c->cwsq, (size_t)c->ld * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->cwsq, 0, (size_t)c->ld * sizeof(double), c->stream));
+    }
+    HIPCHK(c, launch_weights_from_log(c->stream, c->vec_tmp, power, c->N, c->cw, c->cwsq));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->weighted = true;
+    c->last_psum.clear();
+    return MBAR_OK;
+}
+
 int mbar_comm_unique_id(void* id128) {
     if (!id128) return fail(nullptr, MBAR_ERR_ARG, "id128 is NULL");
     std::string err;

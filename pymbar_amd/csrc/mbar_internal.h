@@ -171,6 +171,7 @@ struct SciLoopArgs {
 };
 hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* cw,
                             const SciLoopArgs& q);
+hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int64_t n, double* cw, double* cwsq);
 hipError_t launch_reduce_level1(hipStream_t s, const double* part, int64_t nparts, int64_t count, double* out,
                                 int64_t* nchunks);
 hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink);

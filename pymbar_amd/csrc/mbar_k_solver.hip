@@ -1279,6 +1279,22 @@ hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld,
     hipLaunchKernelGGL(k_make_p, dim3((unsigned)(num_cu * 8)), dim3(256), 0, s, u, ld, N, rows, aden, logden, P);
     return hipGetLastError();
 }
+// cw[n] = exp(p v[n]), cwsq[n] = exp(p v[n] / 2) for n < N: per-sample weights A'^p from the staging vector log A' of an observable
+// (mbar_ctx_weights_from_vec; the padding behind N keeps its zeros)
+__global__ void __launch_bounds__(256)
+k_weights_from_log(const double* __restrict__ v, double p, int64_t n, double* __restrict__ cw, double* __restrict__ cwsq) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = p * v[i];
+        cw[i] = exp(x);
+        cwsq[i] = exp(0.5 * x);
+    }
+}
+hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int64_t n, double* cw, double* cwsq) {
+    int64_t bx = (n + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_weights_from_log, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, v, p, n, cw, cwsq);
+    return hipGetLastError();
+}
 hipError_t launch_fill(hipStream_t s, double* v, double value, int64_t n) {
     int64_t bx = (n + 255) / 256;
     if (bx > 2048) bx = 2048;

@@ -201,6 +201,11 @@ class DeviceMatrix:
             raise ValueError(f"sample weights must have shape ({self.N_local},)")
         self._check(self._lib.mbar_ctx_set_sample_weights(self._ctx, _dptr(c_n)))
 
+    def weights_from_vec(self, power):
+        """Per-sample weights ``(A_n - shift)**power`` from the observable ``vec_logshift`` left on the device (no upload, no host
+        pass): the weighted sums of a single observable at the resident states.  ``set_sample_weights(None)`` restores 1."""
+        self._check(self._lib.mbar_ctx_weights_from_vec(self._ctx, float(power)))
+
     # ---- multi-GPU --------------------------------------------------------------------------------
     def comm_init_rccl(self, unique_id, rank, nranks):
         buf = C.create_string_buffer(bytes(unique_id), 128)

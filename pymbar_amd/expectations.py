@@ -147,6 +147,12 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
         A_i_bootstrap = np.zeros([mbar.n_bootstraps, S])
         f_bootstrap = np.zeros([mbar.n_bootstraps, len(state_list)])
     Theta_ij = None
+    # ONE observable at resident states, no bootstrap replicates: no augmented matrix at all (see _single_observable_moments)
+    if (dedup and not bootstrap and S > 0 and np.all(obs_list == obs_list[0]) and len(state_list) == S
+            and len(np.unique(state_list)) == S and getattr(mbar, "_dm", None) is not None
+            and hasattr(mbar._dm, "weights_from_vec") and getattr(mbar._dm, "nranks", 1) == 1):
+        return _single_observable_moments(mbar, A_n[int(obs_list[0])], state_list, int(obs_list[0]), len(A_n), col_of_state,
+                                          L_list, uncertainty_method, return_theta)
     # The augmented matrix goes to the device once.  A bootstrap replicate (mbar.py:905-912 gathers
     # u_kn[:, bootstrap_rints[n]]) is the same matrix with per-sample multiplicities = draw counts.
     # (observables are made strictly positive so that they can live in log space, mbar.py:858-867: shift[i] is the reference's
@@ -174,14 +180,14 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
                     G, wsum = dm.gram_w(f_full)
                     if dedup:
                         # the reference's layout [K sampled | NL state copies | S observables] from the rows on the device:
-                        # copy l is row l scaled by exp(f_l - f_k[l]), f_l = -lognum[l] its normaliser as an unsampled state
+                        # copy l is row l scaled by c_l = exp(f_l - f_k[l]), f_l = -lognum[l] its normaliser as an unsampled state
+                        # (N = 0).  Theta = W^T (I - W N W^T)^+ W (Eq. D6) is bilinear in the weight columns, so Theta of the
+                        # (K + S) DISTINCT columns is computed (an eigendecomposition of that order) and the copies' rows /
+                        # columns are those of column l times c_l.
                         src = np.concatenate((np.arange(K), L_list.astype(int), K + np.arange(S))).astype(int)
                         scale = np.concatenate((np.ones(K), np.exp(-lognum[L_list.astype(int)] - f_k[L_list.astype(int)]), np.ones(S)))
-                        G = (scale[:, None] * G[np.ix_(src, src)]) * scale[None, :]
-                        wsum = scale * wsum[src]
-                        N_full = np.zeros(K + NL + S, dtype=np.int64)
-                        N_full[:K] = mbar.N_k
-                        Theta_ij = mbar._theta_from_gram(G, N_full, uncertainty_method, wsum=wsum)
+                        Theta_red = mbar._theta_from_gram(G, N_dm.astype(np.int64), uncertainty_method, wsum=wsum)
+                        Theta_ij = (scale[:, None] * Theta_red[np.ix_(src, src)]) * scale[None, :]
                     else:
                         Theta_ij = mbar._theta_from_gram(G, N_dm.astype(np.int64), uncertainty_method, wsum=wsum, dm=dm,
                                                          f_full=f_full)
@@ -201,6 +207,77 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
         result_vals["Theta"] = Theta_ij[np.ix_(idx, idx)]
         if S > 0:
             result_vals["Amin"] = shift[obs_list]
+    return result_vals
+
+
+def _single_observable_moments(mbar, A_row, state_list, obs_index, n_obs, col_of_state, L_list, uncertainty_method, return_theta):
+    """``compute_expectations_inner`` for ONE observable evaluated at S distinct RESIDENT states (``compute_expectations(A_n)``,
+    mbar.py:1039-1312, the common call) WITHOUT an augmented matrix.  The weight column of "A at state l" is
+    ``W_s = A'_n W_nl exp(f_s - f_l)`` with ``A' = A - shift > 0`` (mbar.py:858-867), so
+
+    * its normaliser is ``f_s = -log sum_n A'_n exp(-u_ln - logden_n)``: the log-space reduction of the RESIDENT matrix with the
+      per-sample weights ``A'`` (``mbar_lognum`` after ``mbar_ctx_weights_from_vec(1)``), one read;
+    * the covariance input ``W^T W`` of the reference's N x (K + NL + S) matrix (mbar.py:886-903) is made of the three weighted
+      Gram matrices ``G_p = sum_n A'^p W W^T`` (p = 0, 1, 2) of the resident matrix: ``[G_0 | G_1 d ; d G_1 | d G_2 d]`` with
+      ``d_s = exp(f_s - f_l(s))`` -- three sweeps of K rows on the matrix cores instead of a device-to-device copy of the
+      resident rows, a rewrite of S observable rows and sweeps over K + S rows (at 128 states: 256-row kernels, twice the
+      blocks of three 128-row sweeps; config 3: 20 GB less device memory and half the sweep time).
+
+    Same result keys as the general path."""
+    K, N = mbar.K, mbar.N
+    dm = mbar._dm
+    S = len(state_list)
+    NL = len(L_list)
+    states = np.asarray(state_list, dtype=int)
+    f_k = mbar.f_k
+    result_vals = dict()
+    shift = np.zeros(n_obs, dtype=np.float64)
+    try:
+        dm.set_sample_weights(None)
+        lognum0 = dm.lognum(f_k)                       # resident rows as states: -f_l
+        shift[obs_index] = dm.vec_logshift(A_row)       # log(A - shift) stays on the device
+        dm.weights_from_vec(1.0)
+        lognum1 = dm.lognum(f_k)                       # log sum_n A'_n exp(-u_ln - logden_n)
+        f_states = -lognum0[states]
+        A_i = np.exp(lognum1[states] - lognum0[states])
+        result_vals["observables"] = A_i + shift[obs_index]
+        result_vals["f"] = f_states
+        if return_theta:
+            G1, ws1 = dm.gram_w(f_k)
+            dm.weights_from_vec(2.0)
+            G2, _ = dm.gram_w(f_k)
+            dm.set_sample_weights(None)
+            G0, ws0 = dm.gram_w(f_k)
+            # Theta on the (K + S) DISTINCT weight columns [K resident | S observables], observable s = A' W_l(s) scaled by
+            # d_s = exp(f_s - f_k[l(s)]), f_s = -lognum1[l(s)].  The reference's layout [K sampled | NL state copies | S observables]
+            # (mbar.py:886-903) holds, besides these, NL columns that are exact multiples c_l W_l of resident ones, c_l =
+            # exp(f_l - f_k[l]), with N = 0: Theta = W^T (I - W N W^T)^+ W (Eq. D6; what the eigen-form of mbar.py:1838-1858
+            # evaluates) is bilinear in the columns, so their rows / columns of Theta are those of column l times c_l -- an
+            # eigendecomposition of order K + S instead of K + NL + S (256 instead of 384 at 128 states: 7 ms instead of 23).
+            Ls = L_list.astype(int)
+            c_l = np.exp(-lognum0[Ls] - f_k[Ls])
+            d_s = np.exp(-lognum1[states] - f_k[states])
+            n_red = K + S
+            G = np.empty((n_red, n_red), dtype=np.float64)
+            G[:K, :K] = G0
+            G[:K, K:] = G1[:, states] * d_s[None, :]
+            G[K:, K:] = (d_s[:, None] * G2[np.ix_(states, states)]) * d_s[None, :]
+            iu = np.triu_indices(n_red, 1)
+            G[(iu[1], iu[0])] = G[iu]                     # (symmetric: the lower triangle from the upper)
+            wsum = np.concatenate((ws0, d_s * ws1[states]))
+            N_red = np.zeros(n_red, dtype=np.int64)
+            N_red[:K] = mbar.N_k
+            Theta_red = mbar._theta_from_gram(G, N_red, uncertainty_method, wsum=wsum)
+            src = np.concatenate((np.arange(K), Ls, K + np.arange(S))).astype(int)
+            scale = np.concatenate((np.ones(K), c_l, np.ones(S)))
+            Theta_ij = (scale[:, None] * Theta_red[np.ix_(src, src)]) * scale[None, :]
+            si = K + NL + np.arange(S)
+            li = K + np.array([col_of_state[int(l)] for l in state_list], dtype=int)
+            idx = np.concatenate((si, li)).astype(int)
+            result_vals["Theta"] = Theta_ij[np.ix_(idx, idx)]
+            result_vals["Amin"] = shift[np.full(S, obs_index, dtype=int)]
+    finally:
+        dm.set_sample_weights(None)
     return result_vals
 
 

@@ -95,12 +95,18 @@ class OracleMatrix:
         """Multiplicities are emulated by materialising the resampled matrix (column n repeated c_n times)."""
         if not hasattr(self, "u_full"):
             self.u_full = self.u
+        self._wreal = None
         if c_n is None:
             self.u = self.u_full
         else:
             c = np.asarray(c_n)
             assert np.all(c == np.round(c)) and c.shape == (self.u_full.shape[1],)
             self.u = np.repeat(self.u_full, c.astype(int), axis=1)
+
+    def weights_from_vec(self, power):
+        """Real-valued per-sample weights (A - shift)**power from the observable vec_logshift left behind (model of
+        mbar_ctx_weights_from_vec): they enter the log-space numerators and the W^T W sums."""
+        self._wreal = np.exp(float(power) * self._last_v)
 
     def _reduce(self, arr, op="sum"):
         if self.allreduce is not None:
@@ -145,6 +151,9 @@ class OracleMatrix:
         self.calls["lognum"] += 1
         f = np.asarray(f, dtype=np.float64)
         x = -self._logden(f) - self.u  # (K, n)
+        if getattr(self, "_wreal", None) is not None:
+            with np.errstate(divide="ignore"):
+                x = x + np.log(self._wreal)[None, :]
         m = np.max(x, axis=1)
         mg = self._reduce(m.copy(), "max")
         s = np.sum(np.exp(x - mg[:, None]), axis=1)
@@ -160,7 +169,11 @@ class OracleMatrix:
 
     def gram_w(self, f):
         W = np.exp(self.logw_kn(f)).T
-        buf = np.concatenate([(W.T @ W).ravel(), W.sum(0)])
+        if getattr(self, "_wreal", None) is not None:
+            Ww = W * self._wreal[:, None]
+            buf = np.concatenate([(Ww.T @ W).ravel(), Ww.sum(0)])
+        else:
+            buf = np.concatenate([(W.T @ W).ravel(), W.sum(0)])
         self._reduce(buf)
         return buf[: self.K * self.K].reshape(self.K, self.K).copy(), buf[self.K * self.K :].copy()
 
