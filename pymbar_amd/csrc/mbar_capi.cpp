@@ -569,9 +569,9 @@ void build_aden(const mbar_ctx* c, const double* f, double* out, int64_t rows) {
     for (int64_t k = 0; k < rows; ++k) out[k] = (k < c->K && c->Nk[k] > 0.0) ? f[k] + c->lnNk[k] : ninf;
 }
 
-// 257 .. 512 states: the one-read evaluation kernel whose eight waves split the rows of a tile
+// 257 .. 1024 states: the one-read evaluation kernel whose eight waves split the rows of a tile
 bool split_sweep_ok(const mbar_ctx* c, int64_t rows) {
-    return !use_fast(c) && !c->opt_force_generic && c->opt_staging == 0 && !wide_pitch(c) && rows <= 512 && rows % 64 == 0 && c->opt_wide;
+    return !use_fast(c) && !c->opt_force_generic && c->opt_staging == 0 && !wide_pitch(c) && rows <= 1024 && rows % 64 == 0 && c->opt_wide;
 }
 
 // Evaluation pass for nf vectors whose aden already sits in d_aden (device, row pitch `rows`).
@@ -602,7 +602,7 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
         }
         return MBAR_OK;
     }
-    // 257 .. 512 states: the rows of a tile split over the eight waves of a workgroup -- ONE read of the matrix for one or
+    // 257 .. 1024 states: the rows of a tile split over the eight waves of a workgroup -- ONE read of the matrix for one or
     // two candidates (the second through its ratio row, like the narrower kernels; the layout-agnostic kernels below read the
     // matrix twice per candidate: log-sum-exp pass + column-sum pass)
     if (split_sweep_ok(c, rows)) {

@@ -489,6 +489,9 @@ k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // meet twice per tile through two small LDS vectors: the per-sample maxima (so that every wave uses the same shift and there
 // is ONE exponential per element) and the per-sample sums.  Rows past the allocated pitch are never requested (their LDS rows
 // stay zero and their a_k is -inf).  Partial records: one per workgroup, `rows` entries + one objective term.
+// NBW > 4 (513 .. 1024 states, round 4): a wave's slice of a tile is 12-16 KB, so each wave keeps ONE buffer -- all of its
+// operands are in registers right after the loop top, and the buffer is refilled there (the exponentials of the tile hide the
+// request) -- instead of the layout-agnostic kernels' two reads of the matrix per candidate.
 // ---------------------------------------------------------------------------------------------
 template <int NBW, int NF>
 __global__ void __launch_bounds__(512, 1)
@@ -502,19 +505,20 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     constexpr int U_BYTES = RW * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the tile's 16 sample weights
     constexpr int NW = 8;
+    constexpr int NBUF = NBW <= 4 ? 2 : 1;        // tile buffers per wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ks = lane & 15, ns = lane >> 4;
     exp_table_init(smem);
     double* xmax = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);  // [NW][TS]
     double* xsum = xmax + NW * TS;                                     // [NF][NW][TS]
-    char* buf = smem + EXP_TABLE_BYTES + (1 + NF) * NW * TS * 8 + wave * (2 * TILE_BYTES);
+    char* buf = smem + EXP_TABLE_BYTES + (1 + NF) * NW * TS * 8 + wave * (NBUF * TILE_BYTES);
     const int64_t r0 = (int64_t)wave * RW;
     const StageOffsets so = make_stage_offsets(ld, lane);
     // rows this wave never requests: zero once, in both buffers
     for (int j = 0; j < NP; ++j)
         if (r0 + 8 * j >= rows) {
-            for (int bsel = 0; bsel < 2; ++bsel) *reinterpret_cast<double2*>(buf + bsel * TILE_BYTES + j * 1024 + lane * 16) = double2{0.0, 0.0};
+            for (int bsel = 0; bsel < NBUF; ++bsel) *reinterpret_cast<double2*>(buf + bsel * TILE_BYTES + j * 1024 + lane * 16) = double2{0.0, 0.0};
         }
     __syncthreads();
     // second candidate (NF == 2): aden[rows + k] holds the ratio c_k = exp(a'_k - a_k); its exponentials are the first one's
@@ -553,13 +557,19 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     for (; t < ntiles; t += G) {
         char* cbuf = buf + cur * TILE_BYTES;
         wait_vm<0>();  // this tile (requested a tile period ago) and the previous tile's logden stores
-        if (t + G < ntiles) stage(t + G, buf + (cur ^ 1) * TILE_BYTES);
+        if (NBUF == 2 && t + G < ntiles) stage(t + G, buf + (cur ^ 1) * TILE_BYTES);
         double x[GROUPS][NBW], w[GROUPS], mloc[GROUPS];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             w[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
 #pragma unroll
             for (int I = 0; I < NBW; ++I) x[g][I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g]);
+        }
+        if constexpr (NBUF == 1) {  // the wave's slice is in registers: its one buffer takes the next tile now
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + G < ntiles) stage(t + G, buf);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
@@ -614,7 +624,7 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                 }
             }
         }
-        cur ^= 1;
+        cur ^= NBUF - 1;
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -875,15 +885,16 @@ static int stream_blocks(int num_cu, int64_t N) {
     return (int)(want < cap ? want : cap);
 }
 
-// 257 .. 512 states in one read: rows = allocated row count (a multiple of 64); returns the number of partial records.
+// 257 .. 1024 states in one read: rows = allocated row count (a multiple of 64); returns the number of partial records.
 hipError_t launch_lse_split(hipStream_t s, int num_cu, int nf, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
                             const double* cw, double* logden, double* logden1, const double* dn, double* psum_part, double* obj_part,
                             int* blocks_out) {
-    const int nbw = (int)((rows + 127) / 128);
-    if (nbw < 1 || nbw > 4 || nf < 1 || nf > 2) return hipErrorInvalidValue;
+    int nbw = (int)((rows + 127) / 128);
+    if (nbw < 1 || nbw > 8 || nf < 1 || nf > 2) return hipErrorInvalidValue;
+    if (nbw > 4) nbw = nbw <= 6 ? 6 : 8;  // (513 .. 768 / 769 .. 1024 rows: rows a wave does not have are never requested)
     const int64_t ntiles = (N + TS - 1) / TS;
     const size_t tile = (size_t)nbw * 16 * TS * 8 + TS * 8;
-    const size_t lds = EXP_TABLE_BYTES + (size_t)(1 + nf) * 8 * TS * 8 + (size_t)8 * 2 * tile;
+    const size_t lds = EXP_TABLE_BYTES + (size_t)(1 + nf) * 8 * TS * 8 + (size_t)8 * (nbw <= 4 ? 2 : 1) * tile;
     const int blocks = (int)(ntiles < num_cu ? (ntiles < 1 ? 1 : ntiles) : num_cu);
     *blocks_out = blocks;
     auto go = [&](auto kern) -> hipError_t {
@@ -900,14 +911,18 @@ hipError_t launch_lse_split(hipStream_t s, int num_cu, int nf, const double* u, 
             case 1: return go(k_lse_split<1, 1>);
             case 2: return go(k_lse_split<2, 1>);
             case 3: return go(k_lse_split<3, 1>);
-            default: return go(k_lse_split<4, 1>);
+            case 4: return go(k_lse_split<4, 1>);
+            case 6: return go(k_lse_split<6, 1>);
+            default: return go(k_lse_split<8, 1>);
         }
     }
     switch (nbw) {
         case 1: return go(k_lse_split<1, 2>);
         case 2: return go(k_lse_split<2, 2>);
         case 3: return go(k_lse_split<3, 2>);
-        default: return go(k_lse_split<4, 2>);
+        case 4: return go(k_lse_split<4, 2>);
+        case 6: return go(k_lse_split<6, 2>);
+        default: return go(k_lse_split<8, 2>);
     }
 }
 

@@ -103,10 +103,11 @@ def test_l1_parity_paneled_gram(DM, K, N):
 
 
 @pytest.mark.parametrize("K,N,force", [(300, 900, 0), (321, 400, 0), (512, 700, 0), (257, 5003, 0), (300, 900, 1), (600, 300, 0),
-                                       (40, 2001, 1), (128, 640, 1)])
+                                       (40, 2001, 1), (128, 640, 1), (513, 333, 0), (700, 1000, 0), (768, 250, 0), (769, 130, 0),
+                                       (1000, 2100, 0), (1024, 97, 0), (1025, 150, 0), (1100, 100, 1)])
 def test_l1_parity_generic_path(DM, K, N, force):
-    """K > 256: the one-read evaluation kernel whose eight waves split the rows of a tile (257 .. 512 states), the
-    layout-agnostic kernels beyond (and as the forced fallback, also for small K); paneled Gram."""
+    """K > 256: the one-read evaluation kernel whose eight waves split the rows of a tile (257 .. 1024 states; from 513 on with one
+    tile buffer per wave), the layout-agnostic kernels beyond (and as the forced fallback, also for small K); paneled Gram."""
     u_kn, N_k, f = random_problem(K, N, seed=7 * K + N)
     with DM.from_host(u_kn) as dm:
         dm.set_option("force_generic", force)
