@@ -868,7 +868,11 @@ k_chol_finish(AdaptArgs q, const double* __restrict__ Aw) {
 // Choice between the candidates and convergence test, one workgroup of 256 threads (one state per thread).  The two
 // gradient norms are fixed-order tree sums (deterministic; the host loop adds the same terms serially, so a round-off
 // tie between the candidates may fall differently there), the convergence measures are maxima.
-__device__ __forceinline__ void select_body(const AdaptArgs& q) {  // (256 threads; the pointers of q may be LDS or global)
+// gram_lds: SELECT_GRAM_LDS_DOUBLES doubles of dynamic LDS (or nullptr): the reduced Gram blocks are staged there with coalesced
+// loads -- all 36 in flight -- before the matrix-vector product below reads them.
+constexpr int SELECT_GRAM_PITCH = 17;  // a 16 x 16 block's rows are stored 17 doubles apart: the column walk of a row is conflict-free
+constexpr int SELECT_GRAM_LDS_DOUBLES = 36 * 16 * SELECT_GRAM_PITCH;
+__device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds = nullptr) {  // (256 threads; the pointers of q may be LDS or global)
     __shared__ double red[4];
     int* ctl = q.ctl;
     if (ctl[CTL_DONE] != 0) return;
@@ -894,11 +898,32 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q) {  // (256 threa
         __shared__ double s_c[128], s_half[128];
         if (tid < Kp) s_c[tid] = q.aden[Kp + tid];
         __syncthreads();
-        // (two threads per state, half of the columns each: the loads are what this costs)
+        // (two threads per state, half of the columns each.  Straight from global memory this cost ~15 us -- 64 dependent-ish
+        // loads per thread, neighbouring threads 128 bytes apart; staged through LDS first it is one round of loads)
         const int k = tid & 127, h = tid >> 7, nb = Kp / 16;
         double acc = 0.0;
+        if (gram_lds) {
+            constexpr int NBLK = 36;
+            double v[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) v[b] = q.gram_red[b * 256 + tid];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) gram_lds[b * (16 * SELECT_GRAM_PITCH) + (tid >> 4) * SELECT_GRAM_PITCH + (tid & 15)] = v[b];
+            __syncthreads();
+            for (int j = h * 64; j < h * 64 + 64; ++j) {
+                int ki = k, kj = j;
+                if (ki > kj) {
+                    ki = j;
+                    kj = k;
+                }
+                const int I = ki >> 4, J = kj >> 4;
+                const int b = I * nb - (I * (I - 1)) / 2 + (J - I);
+                acc = fma(s_c[j], gram_lds[b * (16 * SELECT_GRAM_PITCH) + (ki & 15) * SELECT_GRAM_PITCH + (kj & 15)], acc);
+            }
+        } else {
 #pragma unroll 8
-        for (int j = h * 64; j < h * 64 + 64; ++j) acc = fma(s_c[j], gram_elem(q.gram_red, nb, k, j), acc);
+            for (int j = h * 64; j < h * 64 + 64; ++j) acc = fma(s_c[j], gram_elem(q.gram_red, nb, k, j), acc);
+        }
         if (h == 1) s_half[k] = acc;
         __syncthreads();
         if (h == 0) acc += s_half[k];
@@ -961,16 +986,18 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q) {  // (256 threa
     }
 }
 __global__ void __launch_bounds__(256)
-k_select(AdaptArgs q) {
-    select_body(q);
+k_select(AdaptArgs q, int gram_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
+    select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
 }
 // Fused loop: the selection of iteration i and the Newton solve of iteration i + 1 in ONE launch (a kernel boundary costs ~5 us;
 // at the sizes pymbar is mostly used at that is a tenth of an iteration).  A stop or pause flag raised by the selection makes the
 // solve return at once.
 template <int R>
 __global__ void __launch_bounds__(256)
-k_select_newton(AdaptArgs q) {
-    select_body(q);
+k_select_newton(AdaptArgs q, int gram_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
+    select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
     __syncthreads();
     newton_body<16, R>(q);
 }
@@ -1262,16 +1289,30 @@ hipError_t launch_ctl_resume(hipStream_t s, int* ctl) {
 hipError_t launch_select_newton(hipStream_t s, const AdaptArgs& a) {
     const int M = a.m - 1;
     if (M > 127 || a.Kp > 128) return hipErrorInvalidValue;
-    if (M <= 63)
-        hipLaunchKernelGGL((k_select_newton<4>), dim3(1), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((k_select_newton<8>), dim3(1), dim3(256), 0, s, a);
-    return hipGetLastError();
+    // full panel in the fused loop: the selection takes the second candidate's per-state sums from the reduced Gram blocks, staged in LDS
+    const int stage = (a.fused && a.Kp == 128) ? 1 : 0;
+    const size_t lds = stage ? (size_t)SELECT_GRAM_LDS_DOUBLES * sizeof(double) : 0;
+    auto go = [&](auto kern) -> hipError_t {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, s, a, stage);
+        return hipGetLastError();
+    };
+    if (M <= 63) return go(k_select_newton<4>);
+    return go(k_select_newton<8>);
 }
 
 hipError_t launch_select(hipStream_t s, const AdaptArgs& a) {
     if (a.Kp > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, s, a);
+    const int stage = (a.fused && a.Kp == 128) ? 1 : 0;
+    const size_t lds = stage ? (size_t)SELECT_GRAM_LDS_DOUBLES * sizeof(double) : 0;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(256), lds, s, a, stage);
     return hipGetLastError();
 }
 hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,

@@ -116,7 +116,8 @@ def trim():
 
 
 def split():
-    for K, N in ((257, 2_000_000), (300, 1_000_000), (384, 1_000_000), (512, 1_000_000), (512, 4_000_000)):
+    for K, N in ((257, 2_000_000), (300, 1_000_000), (384, 1_000_000), (512, 1_000_000), (512, 4_000_000), (600, 1_000_000),
+                 (768, 1_000_000), (1000, 1_000_000), (1024, 2_000_000)):
         O_k, K_k, N_k = ladder(K, N)
         with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
             dm.set_Nk(N_k)
