@@ -1004,3 +1004,60 @@ def test_sci_iteration_in_one_launch_agrees_with_sweep_plus_update(DM, K, N, uns
     r_or = oracle.sci_solve(u_kn[sws], N_k[sws], np.zeros(len(sws)), tol=1e-11, maxiter=5000)
     assert r_or["success"] and r_dev["success"] and abs(r_or["iterations"] - r_dev["iterations"]) <= 1
     np.testing.assert_allclose(f_dev[sws] - f_dev[sws][0], r_or["x"] - r_or["x"][0], rtol=1e-9, atol=1e-9)
+
+
+def test_log_denominators_are_not_recomputed_for_the_same_f(DM):
+    """The class methods ask for the log-space numerators, W^T W, log W at the same f_k one after the other; the evaluation sweep
+    that leaves the per-sample log-denominators behind runs once per (matrix, N_k, f) -- and again after ANYTHING that could
+    change them or the slot they live in: another f, new N_k, a changed matrix row, a solve, other sample weights (which do not
+    enter the log-denominators: no new sweep, still the right sums)."""
+    u_kn, N_k, f = random_problem(48, 40_000, seed=11, unsampled=(5,))
+    Nf = N_k.astype(float)
+    with DM.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        dm.set_option("timing", 1)
+
+        def sweeps(fn):
+            dm.timing_reset()
+            out = fn()
+            dm.synchronize()
+            return out, dm.timing()["lse"][1]
+
+        W = np.exp(oracle.mbar_log_W_nk(u_kn, Nf, f))
+        (ln, n1) = sweeps(lambda: dm.lognum(f))
+        (gw, n2) = sweeps(lambda: dm.gram_w(f))
+        (lw, n3) = sweeps(lambda: dm.logw_kn(f))
+        assert (n1, n2, n3) == (1, 0, 0)
+        np.testing.assert_allclose(gw[0], W.T @ W, rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(lw.T, np.log(W), rtol=1e-12, atol=1e-10)
+        f2 = f + 0.01
+        (_, n4) = sweeps(lambda: dm.gram_w(f2))
+        (g2, n5) = sweeps(lambda: dm.gram_w(f))
+        assert (n4, n5) == (1, 1)
+        np.testing.assert_array_equal(g2[0], gw[0])
+        dm.solve_adaptive(np.zeros(48), min_sc_iter=0)          # the solver uses the slot vectors for its own purposes
+        (g3, n6) = sweeps(lambda: dm.gram_w(f))
+        assert n6 == 1
+        np.testing.assert_array_equal(g3[0], gw[0])
+        N2 = N_k.copy()
+        N2[0] += 7
+        dm.set_Nk(N2)
+        (g4, n7) = sweeps(lambda: dm.gram_w(f))
+        assert n7 == 1
+        W2 = np.exp(oracle.mbar_log_W_nk(u_kn, N2.astype(float), f))
+        np.testing.assert_allclose(g4[0], W2.T @ W2, rtol=1e-10, atol=1e-300)
+        dm.set_Nk(N_k)
+        dm.gram_w(f)
+        row = u_kn[3] + 0.5
+        dm.upload_rows(3, row)                                      # a changed matrix
+        (g5, n8) = sweeps(lambda: dm.gram_w(f))
+        u3 = u_kn.copy()
+        u3[3] = row
+        W3 = np.exp(oracle.mbar_log_W_nk(u3, Nf, f))
+        assert n8 == 1
+        np.testing.assert_allclose(g5[0], W3.T @ W3, rtol=1e-10, atol=1e-300)
+        c_n = np.random.default_rng(1).integers(0, 3, size=u_kn.shape[1]).astype(float)
+        dm.set_sample_weights(c_n)                                  # weights do not enter the log-denominators
+        (g6, n9) = sweeps(lambda: dm.gram_w(f))
+        assert n9 == 0
+        np.testing.assert_allclose(g6[0], (W3 * c_n[:, None]).T @ W3, rtol=1e-10, atol=1e-300)
