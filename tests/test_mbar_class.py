@@ -159,3 +159,30 @@ def test_host_copy_of_u_kn_is_private_by_default(golden):
     with pytest.raises(ValueError):
         m2.u_kn[0, 0] = 1.0
     np.testing.assert_allclose(m2.f_k, m.f_k, atol=1e-12)
+
+
+def test_private_copy_and_upload_side_by_side(monkeypatch, golden):
+    """Large matrices: the constructor's private host copy and the upload both read the caller's array and run concurrently.
+    Same object as the sequential path; an argument error raised in between does not leave the started device copy behind."""
+    import pymbar_amd.mbar as mbar_mod
+
+    closed = []
+
+    class Tracking(OracleMatrix):
+        def close(self):
+            closed.append(1)
+
+    monkeypatch.setattr(pymbar_amd.device, "DeviceMatrix", Tracking)
+    g = golden("config1_ho_K5_N5000.npz")
+    u_kn, N_k = g["u_kn"], g["N_k"]
+    m_seq = pymbar_amd.MBAR(u_kn, N_k)
+    monkeypatch.setattr(mbar_mod, "_EARLY_UPLOAD_BYTES", 0)
+    m_par = pymbar_amd.MBAR(u_kn, N_k)
+    assert m_par.u_kn is not u_kn and np.array_equal(m_par.u_kn, u_kn) and m_par.u_kn.flags.writeable
+    np.testing.assert_array_equal(m_par.f_k, m_seq.f_k)
+    np.testing.assert_allclose(m_par.f_k, g["f_k"], atol=1e-9)
+    assert "upload_s" in m_par.upload_stats
+    n_closed = len(closed)
+    with pytest.raises(Exception):
+        pymbar_amd.MBAR(u_kn, N_k, initial_f_k=np.zeros(3))   # wrong length: raised after the upload thread was started
+    assert len(closed) == n_closed + 1
