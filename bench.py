@@ -322,7 +322,8 @@ def main():
     ap.add_argument("--n-total", type=int, default=0,
                     help="samples in total (default: 1e7 = config 3 for 1, 2, 4 GPUs; 1e8 = config 4 for 8 GPUs)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="columns for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1_600_000,
+                    help="columns for the CPU baseline: ~10-15 s of CPU work on the GPU host (0 = skip)")
     ap.add_argument("--api-e2e", type=int, default=1, help="also time MBAR(u_kn_host, N_k) end to end (1 GPU only; 0 = skip)")
     ap.add_argument("--small-configs", type=int, default=1,
                     help="also measure BASELINE.json configs 2 and 5 (1 GPU only, < 1 s of GPU time together; 0 = skip)")
