@@ -77,6 +77,13 @@ int mbar_cache_trim(void);
  * array); the Python binding keeps device copies of recently seen host matrices and re-uses one only when the digest of the
  * bytes now behind the address equals the digest of what it uploaded.  A change of ONE element always changes the digest. */
 int mbar_host_digest(const void* data, int64_t nbytes, int threads, uint64_t* out2);
+/* The K x K step of the adaptive iteration as the HOST-driven loop runs it (more than 256 states, host transport):
+ * x = H^+ g - (H^+ g)[0] (mbar_solvers.py:582-583: numpy.linalg.lstsq(H, g) then the gauge shift).  H (m x m, row-major) is the
+ * Hessian on the states with samples, positive semi-definite with null vector 1: the gauge-fixed (m-1) x (m-1) block is solved by
+ * Cholesky factorisation -- from 320 unknowns on in column blocks whose rows are shared out over a team of host threads, results
+ * independent of the team size -- and only if that breaks down (disconnected states) by the minimum-norm pseudo-inverse.
+ * threads = 0: what the solver loop does; threads > 0: the blocked factorisation with that team size (tests).  Host only. */
+int mbar_host_newton_direction(const double* H, const double* g, int m, int threads, double* x);
 /* hipDeviceSynchronize on `device` (every stream of every context): the bracket of a timed region. */
 int mbar_device_synchronize(int device);
 /* Tuning / test knobs.  Every key selects between code paths that are BOTH needed somewhere (a fallback when memory is short,

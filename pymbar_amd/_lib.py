@@ -62,6 +62,7 @@ SIGNATURES = {
     "mbar_device_synchronize": (C.c_int, [C.c_int]),
     "mbar_cache_trim": (C.c_int, []),
     "mbar_host_digest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]),
+    "mbar_host_newton_direction": (C.c_int, [_dp, _dp, C.c_int, C.c_int, _dp]),
     "mbar_ctx_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int64]),
     "mbar_ctx_upload_u": (C.c_int, [_ctx, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "mbar_ctx_download_u": (C.c_int, [_ctx, _dp, C.c_int64]),
@@ -139,6 +140,21 @@ def host_digest(a, threads=0):
     out = (C.c_uint64 * 2)()
     check(load_library().mbar_host_digest(C.c_void_p(a.ctypes.data), a.nbytes, int(threads), out))
     return bytes(out)
+
+
+def host_newton_direction(H, g, threads=0):
+    """``x = H^+ g - (H^+ g)[0]`` as the host-driven adaptive loop computes it (``mbar_host_newton_direction``; host only).
+    ``threads > 0`` forces the blocked, threaded Cholesky factorisation with that team size (tests)."""
+    import numpy as np
+
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    m = g.shape[0]
+    if H.shape != (m, m):
+        raise ValueError("H must be (m, m) for g of length m")
+    x = np.empty(m, dtype=np.float64)
+    check(load_library().mbar_host_newton_direction(H.ctypes.data_as(_dp), g.ctypes.data_as(_dp), m, int(threads), x.ctypes.data_as(_dp)))
+    return x
 
 
 def trim_device_cache():

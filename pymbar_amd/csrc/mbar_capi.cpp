@@ -20,8 +20,10 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -940,6 +942,11 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
     return MBAR_OK;
 }
 
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
 // ---- dense K x K helpers (host) ---------------------------------------------------------------
 // Cholesky solve of A x = b (A m x m SPD, row-major, destroyed).  Returns false on breakdown.
 bool chol_solve(std::vector<double>& A, std::vector<double>& b, int m) {
@@ -989,6 +996,160 @@ bool chol_solve(std::vector<double>& A, std::vector<double>& b, int m) {
         double s = b[i];
         for (int k = i + 1; k < m; ++k) s -= A[(size_t)k * m + i] * b[k];
         b[i] = s / A[(size_t)i * m + i];
+    }
+    for (int i = 0; i < m; ++i)
+        if (!std::isfinite(b[i])) return false;
+    return true;
+}
+
+// The same factorisation for the state counts whose K x K solve stays on the host (more than 256 states): blocks of CHOL_BLOCK
+// columns, the rows below the diagonal block shared out over a team of host threads in chunks of eight (one cache line of a block
+// column).  A row below the block depends on the block's own factor only (phase 1: its entries in the block's columns -- a
+// triangular solve against the diagonal block) and then on the finished block columns of the rows above it (phase 2: the
+// rank-CHOL_BLOCK update of its trailing entries).  Phase 2 of one block and phase 1 of the next touch the same rows, so a thread
+// runs them back to back and a block costs ONE barrier; the caller's thread updates and factors the next diagonal block first and
+// publishes it while the others are still in phase 2.  Every entry receives the same operations in the same order whatever the
+// number of threads: results do not depend on it.  (The rank-8 row update is where the flops are: compiled a second and third time
+// for AVX2 + FMA and AVX-512 and chosen at run time -- the library itself is built for baseline x86-64.)
+#define MBAR_ROW_UPDATE8_BODY                                                                                                  \
+    const double *c0 = cb, *c1 = cb + ms, *c2 = cb + 2 * ms, *c3 = cb + 3 * ms, *c4 = cb + 4 * ms, *c5 = cb + 5 * ms,         \
+                 *c6 = cb + 6 * ms, *c7 = cb + 7 * ms;                                                                         \
+    const double l0 = c0[i], l1 = c1[i], l2 = c2[i], l3 = c3[i], l4 = c4[i], l5 = c5[i], l6 = c6[i], l7 = c7[i];               \
+    for (int k = k0; k <= k1; ++k)                                                                                             \
+        row[k] -= ((l0 * c0[k] + l1 * c1[k]) + (l2 * c2[k] + l3 * c3[k])) + ((l4 * c4[k] + l5 * c5[k]) + (l6 * c6[k] + l7 * c7[k]));
+void row_update8_base(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
+    MBAR_ROW_UPDATE8_BODY
+}
+__attribute__((target("avx2,fma")))
+void row_update8_avx2(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
+    MBAR_ROW_UPDATE8_BODY
+}
+__attribute__((target("avx512f")))
+void row_update8_avx512(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
+    MBAR_ROW_UPDATE8_BODY
+}
+#undef MBAR_ROW_UPDATE8_BODY
+constexpr int CHOL_BLOCK = 32;
+constexpr int CHOL_BLOCKED_MIN = 320;   // unknowns from which the blocked form is used ...
+constexpr int CHOL_THREADED_MIN = 448;  // ... and from which it is worth a team (below: one thread, same code)
+int host_team_size(int m) {
+    if (m < CHOL_THREADED_MIN) return 1;
+    int t = (int)std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("MBAR_HOST_THREADS")) t = std::atoi(e);
+    t = std::max(1, std::min(t, 16));
+    return std::min(t, std::max(1, m / 96));
+}
+bool chol_solve_blocked(std::vector<double>& A, std::vector<double>& b, int m, int threads) {
+    double dmax = 0.0;
+    for (int j = 0; j < m; ++j) dmax = std::max(dmax, A[(size_t)j * m + j]);
+    const double thr = dmax * std::numeric_limits<double>::epsilon() * m;
+    constexpr int B = CHOL_BLOCK;
+    const size_t ms = ((size_t)m + 7) & ~(size_t)7;  // padded length of a block column: chunks of 8 rows = whole cache lines
+    struct Free { void operator()(void* q) const { std::free(q); } };
+    std::unique_ptr<double, Free> colmem((double*)std::aligned_alloc(64, 2 * (size_t)B * ms * sizeof(double)));
+    if (!colmem) return false;
+    double* const colbuf[2] = {colmem.get(), colmem.get() + (size_t)B * ms};  // colbuf[block & 1][c * ms + i] = L[i][j0 + c]
+    double Lt[B * B];  // the current diagonal block's factor, transposed: Lt[c * B + k] = L[j0 + k][j0 + c]
+    const auto update8 = __builtin_cpu_supports("avx512f") ? row_update8_avx512
+                         : (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? row_update8_avx2 : row_update8_base;
+    const int T = std::max(1, threads);
+    const int nblk = (m + B - 1) / B;
+    std::atomic<int> diag_ready{-1}, arrived{0}, failed{0};
+    auto spin_until = [&](auto&& cond) {
+        int spins = 0;
+        while (!cond())
+            if (++spins > 8192) std::this_thread::yield();
+    };
+    // rows [i_lo, i_hi) owned by thread t: chunks of eight by absolute row index, dealt round-robin
+    auto for_my_rows = [&](int t, int i_lo, auto&& fn) {
+        for (int q = i_lo / 8; q * 8 < m; ++q) {
+            if (q % T != t) continue;
+            for (int i = std::max(q * 8, i_lo); i < std::min(q * 8 + 8, m); ++i) fn(i);
+        }
+    };
+    auto phase2_row = [&](int i, int bi_prev) {  // trailing entries of row i: columns j1(prev) .. i
+        const int k0 = (bi_prev + 1) * B;
+        double* row = A.data() + (size_t)i * m;
+        const double* cb = colbuf[bi_prev & 1];
+        for (int c = 0; c < B; c += 8) update8(row, cb + (size_t)c * ms, ms, i, k0, i);
+    };
+    auto phase1_row = [&](int i, int bi) {  // row i of the triangular solve x L_block^T = A[i, block], column by column
+        const int j0 = bi * B, jb = std::min(B, m - j0);
+        double* rb = A.data() + (size_t)i * m + j0;
+        double* cb = colbuf[bi & 1];
+        for (int c = 0; c < jb; ++c) {
+            const double v = rb[c] / Lt[c * B + c];
+            rb[c] = v;
+            cb[(size_t)c * ms + i] = v;
+            const double* lt = Lt + c * B;  // lt[k] = L[j0 + k][j0 + c]
+            for (int k = c + 1; k < jb; ++k) rb[k] -= v * lt[k];
+        }
+    };
+    auto factor_diag = [&](int bi) -> bool {  // plain column Cholesky of the B x B block, then its transpose for phase 1
+        const int j0 = bi * B, j1 = std::min(j0 + B, m);
+        for (int c = j0; c < j1; ++c) {
+            double* rc_ = A.data() + (size_t)c * m;
+            double d = rc_[c];
+            for (int k = j0; k < c; ++k) d -= rc_[k] * rc_[k];
+            if (!(d > thr) || !std::isfinite(d)) return false;
+            d = std::sqrt(d);
+            rc_[c] = d;
+            for (int i = c + 1; i < j1; ++i) {
+                double* ri = A.data() + (size_t)i * m;
+                double v = ri[c];
+                for (int k = j0; k < c; ++k) v -= ri[k] * rc_[k];
+                ri[c] = v / d;
+            }
+        }
+        for (int c = 0; c < j1 - j0; ++c)
+            for (int k = c; k < j1 - j0; ++k) Lt[c * B + k] = A[(size_t)(j0 + k) * m + j0 + c];
+        return true;
+    };
+    auto run = [&](int t) {
+        for (int bi = 0; bi < nblk; ++bi) {
+            const int j1 = std::min((bi + 1) * B, m);
+            if (t == 0) {
+                if (bi > 0)
+                    for (int i = bi * B; i < j1; ++i) phase2_row(i, bi - 1);  // the next diagonal block's rows first
+                if (!factor_diag(bi)) {
+                    failed.store(1, std::memory_order_release);
+                    return;
+                }
+                diag_ready.store(bi, std::memory_order_release);
+            }
+            if (j1 >= m) return;  // (the last block has no rows below it)
+            if (bi > 0) for_my_rows(t, j1, [&](int i) { phase2_row(i, bi - 1); });
+            if (t != 0) {
+                spin_until([&]() { return diag_ready.load(std::memory_order_acquire) >= bi || failed.load(std::memory_order_acquire); });
+                if (failed.load(std::memory_order_acquire)) return;
+            }
+            for_my_rows(t, j1, [&](int i) { phase1_row(i, bi); });
+            arrived.fetch_add(1, std::memory_order_acq_rel);
+            spin_until([&]() { return arrived.load(std::memory_order_acquire) >= T * (bi + 1) || failed.load(std::memory_order_acquire); });
+            if (failed.load(std::memory_order_acquire)) return;
+        }
+    };
+    const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
+    const double t_begin = dbg ? now_ms() : 0.0;
+    {
+        std::vector<std::thread> team;
+        for (int t = 1; t < T; ++t) team.emplace_back(run, t);
+        run(0);
+        for (auto& th : team) th.join();
+    }
+    if (dbg) std::fprintf(stderr, "[mbar] blocked Cholesky m=%d, %d threads: factorisation %.3f ms\n", m, T, now_ms() - t_begin);
+    if (failed.load()) return false;
+    for (int i = 0; i < m; ++i) {  // L y = b
+        double s = b[i];
+        const double* row = A.data() + (size_t)i * m;
+        for (int k = 0; k < i; ++k) s -= row[k] * b[k];
+        b[i] = s / row[i];
+    }
+    for (int i = m - 1; i >= 0; --i) {  // L^T x = y, along the rows of L
+        const double* row = A.data() + (size_t)i * m;
+        const double xi = b[i] / row[i];
+        b[i] = xi;
+        for (int k = 0; k < i; ++k) b[k] -= row[k] * xi;
     }
     for (int i = 0; i < m; ++i)
         if (!std::isfinite(b[i])) return false;
@@ -1047,7 +1208,7 @@ void newton_direction(const std::vector<double>& H, const std::vector<double>& g
         b[i] = g[i + 1];
         for (int j = 0; j < r; ++j) A[(size_t)i * r + j] = H[(size_t)(i + 1) * m + (j + 1)];
     }
-    if (chol_solve(A, b, r)) {
+    if (r >= CHOL_BLOCKED_MIN ? chol_solve_blocked(A, b, r, host_team_size(r)) : chol_solve(A, b, r)) {
         for (int i = 0; i < r; ++i) x[i + 1] = b[i];
         return;
     }
@@ -1067,10 +1228,6 @@ void newton_direction(const std::vector<double>& H, const std::vector<double>& g
     for (int k = 0; k < m; ++k) x[k] = y[k] - y[0];
 }
 
-double now_ms() {
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
 
 // ---- adaptive loop -------------------------------------------------------------------------------
 // Host-driven loop (mbar_solvers.py:575-640): the K x K solve, the candidate construction and the convergence test run
@@ -2027,6 +2184,27 @@ int mbar_host_digest(const void* data, int64_t nbytes, int threads, uint64_t* ou
     }
     out2[0] = h0 ^ (h0 >> 32);
     out2[1] = h1 ^ (h1 >> 29);
+    return MBAR_OK;
+}
+
+int mbar_host_newton_direction(const double* H, const double* g, int m, int threads, double* x) {
+    if (!H || !g || !x || m < 1) return fail(nullptr, MBAR_ERR_ARG, "mbar_host_newton_direction: bad argument");
+    std::vector<double> Hv(H, H + (size_t)m * m), gv(g, g + m), xv;
+    if (threads != 0) {  // (test hook: the blocked factorisation with a given team size, whatever m; < 0: the panels-of-4 form)
+        const int r = m - 1;
+        std::vector<double> A((size_t)r * r), b(r);
+        for (int i = 0; i < r; ++i) {
+            b[i] = gv[i + 1];
+            for (int j = 0; j < r; ++j) A[(size_t)i * r + j] = Hv[(size_t)(i + 1) * m + (j + 1)];
+        }
+        if (r > 0 && (threads > 0 ? chol_solve_blocked(A, b, r, threads) : chol_solve(A, b, r))) {
+            x[0] = 0.0;
+            for (int i = 0; i < r; ++i) x[i + 1] = b[i];
+            return MBAR_OK;
+        }
+    }
+    newton_direction(Hv, gv, m, xv);
+    std::copy(xv.begin(), xv.end(), x);
     return MBAR_OK;
 }
 

@@ -399,3 +399,61 @@ def test_label_samples_paths_agree():
     lab, grid = fes.label_samples(x12, e12)
     nl, ng = naive(x12, e12)
     assert np.array_equal(lab, nl) and grid == ng
+
+
+def _mbar_like_hessian(m, rng, disconnected=False):
+    """H = diag(W^T 1) - W^T W for normalised weights: positive semi-definite, null vector 1 (mbar_solvers.py:395-411)."""
+    W = rng.random((4 * m, m))
+    if disconnected:  # two groups of states that share no sample: a second null vector
+        W[: 2 * m, m // 2:] = 0.0
+        W[2 * m:, : m // 2] = 0.0
+    W /= W.sum(1, keepdims=True)
+    return np.diag(W.sum(0)) - W.T @ W
+
+
+@pytest.mark.parametrize("m", [2, 5, 40, 130, 330, 401])
+def test_host_newton_direction_matches_lstsq(m):
+    """The K x K step of the host-driven loop (``mbar_host_newton_direction``): lstsq(H, g) minus its first component
+    (mbar_solvers.py:582-583) -- plain Cholesky below 320 unknowns, column blocks shared out over host threads above; the
+    blocked form gives the SAME bits for every team size."""
+    from pymbar_amd import _lib
+
+    rng = np.random.default_rng(m)
+    H = _mbar_like_hessian(m, rng)
+    g = rng.normal(size=m) * 1e-2
+    g -= g.mean()  # (the gradient of MBAR sums to zero: g is in the range of H)
+    ref = np.linalg.lstsq(H, g, rcond=-1)[0]
+    ref -= ref[0]
+    scale = np.abs(ref).max()
+    x = _lib.host_newton_direction(H, g)
+    assert x[0] == 0.0 and np.abs(x - ref).max() <= 1e-10 * scale
+    teams = [_lib.host_newton_direction(H, g, threads=t) for t in (1, 2, 5)]
+    for xt in teams:
+        assert np.array_equal(xt, teams[0]) and np.abs(xt - ref).max() <= 1e-10 * scale
+    x_old = _lib.host_newton_direction(H, g, threads=-1)  # the panels-of-4 factorisation
+    assert np.abs(x_old - ref).max() <= 1e-10 * scale
+
+
+def test_host_newton_direction_falls_back_to_the_pseudo_inverse():
+    """Disconnected groups of states: the gauge-fixed block is singular, the Cholesky factorisations (both forms) report the
+    breakdown and the minimum-norm solution of lstsq is returned instead."""
+    from pymbar_amd import _lib
+
+    rng = np.random.default_rng(7)
+    for m in (24, 340):
+        H = _mbar_like_hessian(m, rng, disconnected=True)
+        g = rng.normal(size=m) * 1e-2
+        g[: m // 2] -= g[: m // 2].mean()
+        g[m // 2:] -= g[m // 2:].mean()
+        ref = np.linalg.lstsq(H, g, rcond=-1)[0]
+        ref -= ref[0]
+        for threads in (0, 3):
+            x = _lib.host_newton_direction(H, g, threads=threads)
+            assert x[0] == 0.0 and np.all(np.isfinite(x))
+            assert np.abs(H @ x - g).max() <= 1e-12
+            # (each group's constant is a null direction of H: whether LAPACK keeps or drops a singular value of 1e-15 decides it in
+            # the reference itself -- compare what H determines)
+            d = x - ref
+            d[: m // 2] -= d[: m // 2].mean()
+            d[m // 2:] -= d[m // 2:].mean()
+            assert np.abs(d).max() <= 1e-10 * np.abs(ref).max()

@@ -9,9 +9,12 @@
           evaluation sweep), and ONE fused sweep on the resident probability matrix (k_fused_quad); cold and warm solves;
   split   evaluation sweep at 257 ... 512 states: one and two candidates, row-split kernel against the layout-agnostic path.
 
+  large   one adaptive iteration above 256 states (host-driven loop: paneled Gram sweep, one-read two-candidate evaluation, K x K
+          solve on the host): wall clock per iteration, the device timers behind it, the Gram sweep as a fraction of the fp64 matrix peak;
+
   trim    129 ... 160 / 193 ... 224 states: the one-read sweeps without the two padding blocks of their panel.
 
-Usage: python tools/bench_wide.py [gram] [loop] [split] [trim]   (default: the first three)"""
+Usage: python tools/bench_wide.py [gram] [loop] [split] [trim] [large]   (default: the first three)"""
 import os
 import sys
 import time
@@ -138,7 +141,32 @@ def split():
             print(f"eval K={K} N={N}: " + " | ".join(out), flush=True)
 
 
+def large():
+    for K, N in ((320, 1_000_000), (384, 1_000_000), (512, 1_000_000), (512, 4_000_000), (768, 1_000_000), (1024, 1_000_000)):
+        O_k, K_k, N_k = ladder(K, N)
+        with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
+            dm.set_Nk(N_k)
+            dm.set_option("timing", 1)
+            dm.solve_adaptive(np.zeros(K), maxiter=2, min_sc_iter=0, check_convergence=False)
+            dm.timing_reset()
+            dm.synchronize()
+            n = 6
+            t0 = time.perf_counter()
+            dm.solve_adaptive(np.zeros(K), maxiter=n, min_sc_iter=0, check_convergence=False)
+            dt = (time.perf_counter() - t0) / n
+            tm = dm.timing()
+            per = {k: (tm[k][0] / max(1, tm[k][1]), tm[k][1]) for k in ("gram", "lse", "other")}
+            flop = float(N) * K * (K + 1)
+            t1 = time.perf_counter()
+            fc, rc = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
+            dtc = time.perf_counter() - t1
+            print(f"adaptive K={K} N={N}: {1e3 * dt:8.3f} ms per iteration; Gram sweep {per['gram'][0]:7.3f} ms x{per['gram'][1]} = "
+                  f"{flop / (per['gram'][0] * 1e-3) * 1e-12 / PEAK:5.3f} of the fp64 matrix peak, evaluation sweep {per['lse'][0]:7.3f} ms x{per['lse'][1]} "
+                  f"({8.0 * K * N / (per['lse'][0] * 1e-3) * 1e-12:4.2f} TB/s of one read), other {per['other'][0]:7.3f} ms x{per['other'][1]}; device time per iteration "
+                  f"{sum(tm[k][0] for k in ('gram', 'lse', 'other')) / n:8.3f} ms; solve from f=0: {rc['iterations']} iterations {1e3 * dtc:8.2f} ms success={rc['success']}", flush=True)
+
+
 if __name__ == "__main__":
     want = sys.argv[1:] or ["gram", "loop", "split"]
     for w in want:
-        {"gram": gram, "loop": loop, "split": split, "trim": trim}[w]()
+        {"gram": gram, "loop": loop, "split": split, "trim": trim, "large": large}[w]()
