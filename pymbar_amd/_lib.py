@@ -40,6 +40,8 @@ class SolveResult(C.Structure):
         ("wall_ms", C.c_double),
         ("warm_starts", C.c_int32),
         ("builds", C.c_int32),
+        ("light_sweeps", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

@@ -288,7 +288,7 @@ struct mbar_ctx {
     // options
     const int64_t opt_staging = 0;  // (tiles are staged by LDS-DMA; the register-staged kernels of rounds 1-3 are gone)
     int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -1475,6 +1475,12 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     if (!arc && pmode && !c->pm_vec && cache_malloc((void**)&c->pm_vec, (size_t)3 * Kp * sizeof(double)) != hipSuccess)
         arc = fail(c, MBAR_ERR_HIP, "allocation of the P-mode vectors failed");
     const bool fused = pmode && c->opt_fused;
+    // Last iteration without its Gram matrix (CTL_LIGHT, mbar_internal.h): an idle launch per iteration against ONE lighter sweep per
+    // solve.  Worth it where the fused sweep is bound by the matrix cores and the plain one by HBM -- 96 states and more (K = 128:
+    // 1.9 ms against 3.1 at config 3; at 64 states and fewer both are HBM-bound and nothing is gained) -- and from ~5e7 matrix
+    // entries per rank on (a sweep of ~0.13 ms); option light_last = 2 drops both bounds.
+    bool light = fused && !wide && check_convergence && c->opt_light_last != 0 &&
+                 (c->opt_light_last >= 2 || (nb >= 6 && (double)Kp * (double)c->N >= 5.0e7));
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     LaunchGeom gg = wide ? gram_quad_geometry(nb, c->num_cu, ntiles, c->opt_grid)
                          : gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid);
@@ -1485,6 +1491,20 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     if (fused) {  // the separate Gram sweep (when it runs) leaves its partial records where the fused sweep leaves them
         gg.blocks = gl.blocks;
         gg.nwaves = gl.nwaves;
+    }
+    // the plain sweep that stands in for the fused one leaves ITS per-state records where the fused sweep leaves them too: as many
+    // waves as the fused grid has, in workgroups of the plain sweep's size
+    LaunchGeom gp = psweep_geometry(wide ? 8 : nb, c->num_cu, ntiles, 0);
+    if (light && gl.nwaves % gp.waves != 0) light = false;
+    if (light) {
+        gp.blocks = gl.nwaves / gp.waves;
+        gp.nwaves = gp.psum_records = gl.nwaves;
+    }
+    {
+        bool l_ok = light;  // (every rank derives it from its own shard length: agree, like every decision that changes what is launched)
+        int rcl = agree_all_ok(c, l_ok);
+        if (rcl) return rcl;
+        light = light && l_ok;
     }
     // build sweep of P mode: with the fused loop it also accumulates the Gram matrix at the anchor (grid of the fused sweep)
     const LaunchGeom gb = fused ? build_gram_geometry(nb, c->num_cu, ntiles, c->opt_grid)
@@ -1698,6 +1718,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     q.ccur = pmode ? c->pm_vec + Kp : nullptr;
     q.fused = fused ? 1 : 0;
     q.cgram = fused ? c->pm_vec + 2 * Kp : nullptr;
+    q.light_ok = light ? 1 : 0;
 
     // Gram sweep at the current f with the known logden (the slot of the accepted candidate; P mode: the slots hold the
     // reciprocals 1 / s_n instead), reduced and all-reduced into the blocks k_newton reads.  Two-sweep loops: once per
@@ -1786,10 +1807,15 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             LoopCtl lcb = lc_slot;
             if (ext) { lcb.ev_start = tp.a; lcb.ev_stop = tp.b; }
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.a, c->stream);
-            if (fused)
+            if (fused) {
                 HIPCHK(c, launch_fused(c->stream, nb, gl, c->P, c->ld, c->N, d_aden(c), c->cw, c->weighted ? c->cwsq : c->cw,
                                        c->logden[0], gram_part, psum_part, lcb));
-            else if (pmode)
+                if (light) {  // (idle unless k_newton found that this iteration is the last: then the fused sweep is the idle one)
+                    LoopCtl lcl = lc_slot;
+                    lcl.light_only = true;
+                    HIPCHK(c, launch_psweep(c->stream, nb, 2, gp, c->P, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, psum_part, lcl));
+                }
+            } else if (pmode)
                 HIPCHK(c, launch_psweep(c->stream, nb, 2, gl, c->P, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, psum_part,
                                         lcb));
             else
@@ -1836,7 +1862,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const bool use_graph = c->opt_graph && !stream_transport(c);
     auto prepare_graph = [&]() -> int {
         const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 12) ^ (pmode ? 128 : 0) ^ (fused ? 256 : 0) ^
-                            (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (lc_slot.unclamped ? 512 : 0) ^ (merged ? 1024 : 0) ^ (int64_t)nb;
+                            (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (lc_slot.unclamped ? 512 : 0) ^ (merged ? 1024 : 0) ^ (light ? 2048 : 0) ^ (int64_t)nb;
         if (!c->ad_graph || c->ad_graph_batch != batch || c->ad_graph_sig != sig) {
             // (the captured iterations are the steady-state ones: no Newton solve of their own when it rides with the selection)
             const bool need_saved = need_newton;
@@ -1939,6 +1965,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     res.sci_iter = c->h_ctl[CTL_SCI];
     res.nr_iter = c->h_ctl[CTL_NR];
     res.gram_sweeps += fused ? gram_sweeps : (int32_t)(it - it_start);
+    res.light_sweeps += c->h_ctl[CTL_LIGHTS];
     if (handed_back) {
         c->P_valid = false;  // (the continuation re-anchors: a state whose weights underflow at this anchor has a zero row in P)
         static const char* why[] = {"", "the Newton system is not positive definite", "a candidate is too far from the point the sweeps are anchored at",
@@ -2233,6 +2260,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "device_loop_wide") c->opt_device_loop_wide = value;
     else if (k == "pcache") c->opt_pcache = value;
     else if (k == "merge_select") c->opt_merge_select = value;
+    else if (k == "light_last") c->opt_light_last = value;
     else if (k == "sci_merged") c->opt_sci_merged = value;
     else if (k == "wide_pmode") c->opt_wide_pmode = value;
     else if (k == "quad_trim") {

@@ -43,6 +43,11 @@ enum : int {
     CTL_SPEC = 8,    // fused sweep: candidate whose Gram matrix the sweep accumulates (always the SECOND multiplier row it is
                      // handed): 1 = Newton-Raphson (default), 0 = self-consistent (while self-consistent steps are forced,
                      // mbar_solvers.py:607 `sci_iter < min_sc_iter`: k_newton then hands the two rows over in swapped order)
+    CTL_LIGHT = 9,   // fused loop: 1 = BOTH candidates of the coming sweep already satisfy the stop test (mbar_solvers.py:636) against
+                     // the current f, so this iteration is the last whichever of them wins and nobody will need the Gram
+                     // matrix the fused sweep would accumulate: the fused sweep returns at once and the plain two-candidate
+                     // sweep on P (k_psweep, launched right behind it and idle otherwise) evaluates the candidates instead
+    CTL_LIGHTS = 10,  // iterations evaluated that way
     CTL_WORDS = 12
 };
 struct LoopCtl {
@@ -57,6 +62,8 @@ struct LoopCtl {
     bool pmode = false;
     // the Gram launch is conditional: the kernel exits at once unless CTL_NEEDGRAM is set (fused-sweep loop)
     bool cond_needgram = false;
+    // the evaluation sweep on P is conditional: it exits at once unless CTL_LIGHT is set (last iteration of the fused loop)
+    bool light_only = false;
 };
 
 struct LaunchGeom {
@@ -216,6 +223,9 @@ struct AdaptArgs {
     // candidate's, or the current f's after a separate Gram sweep)
     int fused;
     double* cgram;           // [Kp]
+    // fused loop: the last iteration may run without its Gram matrix (CTL_LIGHT); 0 = never (small problems: an idle launch
+    // per iteration would cost more than the one lighter sweep saves)
+    int light_ok;
 };
 // ---- P mode: resident probability matrix P = exp(a0 - u - logden(a0)) (see k_psweep) ----------------------------------
 LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);

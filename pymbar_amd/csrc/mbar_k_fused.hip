@@ -52,7 +52,7 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
         const int* __restrict__ ctl, int64_t slot_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (ctl) {
-        if (ctl[CTL_DONE] != 0) return;
+        if (ctl[CTL_DONE] != 0 || ctl[CTL_LIGHT] != 0) return;  // (CTL_LIGHT: the last iteration needs no Gram matrix, see k_psweep)
         const int s = ctl[CTL_SLOT];
         rinv1 = rinv0 + (int64_t)((s + 2) % 3) * slot_stride;
         rinv0 = rinv0 + (int64_t)((s + 1) % 3) * slot_stride;

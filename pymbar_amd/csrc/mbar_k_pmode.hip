@@ -344,10 +344,11 @@ template <int NB, int NF, bool WIDE>
 __global__ void __launch_bounds__(64 * lse_waves(NB))
 k_psweep(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cmul,
          const double* __restrict__ cw, double* __restrict__ rinv0, double* __restrict__ rinv1,
-         double* __restrict__ psum_part, const int* __restrict__ ctl, int64_t slot_stride) {
+         double* __restrict__ psum_part, const int* __restrict__ ctl, int64_t slot_stride, int light_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (ctl) {
         if (ctl[CTL_DONE] != 0) return;
+        if (light_only && ctl[CTL_LIGHT] == 0) return;  // (fused loop: this sweep stands in for the fused one in the last iteration only)
         const int s = ctl[CTL_SLOT];
         rinv1 = rinv0 + (int64_t)((s + 2) % 3) * slot_stride;
         rinv0 = rinv0 + (int64_t)((s + 1) % 3) * slot_stride;
@@ -482,10 +483,10 @@ static hipError_t launch_psweep_nb(hipStream_t s, int nf, const LaunchGeom& g, c
         const int64_t ntiles = (N + TS - 1) / TS;
         if (lc.ev_start && lc.ev_stop)
             hipExtLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, lc.ev_start, lc.ev_stop, 0, P, ld, N,
-                                  ntiles, cmul, cw, rinv0, rinv1, pp, lc.ctl, lc.slot_stride);
+                                  ntiles, cmul, cw, rinv0, rinv1, pp, lc.ctl, lc.slot_stride, lc.light_only ? 1 : 0);
         else
             hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), g.lds_bytes, s, P, ld, N, ntiles, cmul, cw, rinv0,
-                               rinv1, pp, lc.ctl, lc.slot_stride);
+                               rinv1, pp, lc.ctl, lc.slot_stride, lc.light_only ? 1 : 0);
         return hipGetLastError();
     };
     const bool wide = stage_offsets_wide(ld);

@@ -403,6 +403,10 @@ __device__ __forceinline__ void newton_tail(const AdaptArgs& q, const double* xs
     const bool swap = q.fused && q.ctl[CTL_SCI] < (int)q.prm[2];
     const int o_sci = swap ? q.Kp : 0, o_nr = swap ? 0 : q.Kp;
     if (tid == 0) q.ctl[CTL_SPEC] = swap ? 0 : 1;
+    // Last iteration without its Gram matrix (CTL_LIGHT): the stop test of mbar_solvers.py:627-636 compares the ACCEPTED candidate
+    // with the current f and the two candidates with each other.  If it holds for BOTH candidates, the coming iteration is the
+    // last whichever wins, and the sweep only has to say which one does: flags bit 3 collects "some state fails it".
+    const double tol = q.prm[1], tol_small = tol < 1e-8 ? tol : 1e-8, tol_diff = sqrt(tol);
     for (int k = tid; k < q.Kp; k += NT) {
         const bool sampled = k < q.K && s_nk[k] > 0.0;
         const double fk = s_f[k];
@@ -425,6 +429,11 @@ __device__ __forceinline__ void newton_tail(const AdaptArgs& q, const double* xs
                 if (!(fabs(d) < 300.0)) flags |= 2;
             }
             if (!isfinite(fs) || !isfinite(fn)) flags |= 4;
+            if (k != first) {
+                const double ds = fabs(fs) < tol_small ? 1.0 : fabs(fs), dn = fabs(fn) < tol_small ? 1.0 : fabs(fn);
+                const double gap = fabs(fs - fn);
+                if (!(fabs(fs - fk) / ds < tol) || !(fabs(fn - fk) / dn < tol) || !(gap / ds < tol_diff) || !(gap / dn < tol_diff)) flags |= 8;
+            }
         } else if (q.pmode) {
             a0 = 0.0;
             rt = 0.0;
@@ -435,11 +444,19 @@ __device__ __forceinline__ void newton_tail(const AdaptArgs& q, const double* xs
         q.aden[o_sci + k] = a0;
         q.aden[o_nr + k] = rt;
     }
-    flags = __syncthreads_or(flags);
-    if (flags != 0 && tid == 0) {
+    {   // bitwise OR over the workgroup (__syncthreads_or is a logical one)
+        __shared__ int s_flags;
+        if (tid == 0) s_flags = 0;
+        __syncthreads();
+        if (flags) atomicOr(&s_flags, flags);
+        __syncthreads();
+        flags = s_flags;
+    }
+    if ((flags & 7) != 0 && tid == 0) {
         q.ctl[CTL_REASON] = (flags & 1) ? 1 : ((flags & 4) ? 3 : 2);
         q.ctl[CTL_DONE] = 2;
     }
+    if (tid == 0) q.ctl[CTL_LIGHT] = (q.light_ok && q.fused && flags == 0 && q.prm[3] != 0.0) ? 1 : 0;
 }
 
 // Newton direction + both candidates, ONE workgroup of T x T threads with an R x R tile each (up to R T - 1 unknowns:
@@ -888,11 +905,12 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds
     // (classic: ratio c_k of the second candidate only; P mode: exp(a - a0) of both, kept in aden).  Index 0 = the
     // self-consistent candidate, 1 = Newton-Raphson; the fused sweep may have been handed them in swapped order (CTL_SPEC).
     const bool swap = q.fused && ctl[CTL_SPEC] == 0;
+    const bool light = q.fused && q.light_ok && ctl[CTL_LIGHT] != 0;  // this iteration's sweep was the plain one: no Gram matrix
     const int o_sci = swap ? Kp : 0, o_nr = swap ? 0 : Kp;
     const double m0 = (in && q.pmode) ? q.aden[o_sci + tid] : 1.0;
     const double m1 = in ? (q.pmode ? q.aden[o_nr + tid] : q.ratio[tid]) : 0.0;
     double raw0 = in ? q.lse_red[o_sci + tid] : 0.0, raw1 = in ? q.lse_red[o_nr + tid] : 0.0;
-    if (q.fused && Kp == 128 && FUSED_PSUM1_FROM_GRAM_NB <= 8) {  // (k_fused<8> only: narrower panels and k_fused_quad accumulate both rows)
+    if (q.fused && !light && Kp == 128 && FUSED_PSUM1_FROM_GRAM_NB <= 8) {  // (k_fused<8> only: narrower panels and k_fused_quad accumulate both rows)
         // the fused sweep of a full panel left the unscaled sums of its SECOND multiplier row c to be taken from the Gram matrix
         // it accumulated for that candidate: sum_n w_n P_kn / s_n = sum_j c_j G'_kj (rows of p sum to one)
         __shared__ double s_c[128], s_half[128];
@@ -959,7 +977,7 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds
     // that candidate was accepted -- or when the two candidates coincide to 1e-10 (at the fixed point the choice is
     // round-off noise; the Hessian of one is the Hessian of the other far below any tolerance it is used at).
     const int spec = swap ? 0 : 1;  // the candidate the sweep speculated on
-    const bool reuse = q.fused && (ch == spec || max_diff <= 1e-10);
+    const bool reuse = q.fused && !light && (ch == spec || max_diff <= 1e-10);
     if (q.fused && in) q.cgram[tid] = (reuse ? spec : ch) == 0 ? m0 : m1;
     if (tid == 0) {
         const int it = ctl[CTL_ITER];
@@ -972,6 +990,10 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds
         q.state[0] = max_delta;
         const bool stop = check && (max_delta != max_delta || (max_delta < tol && max_diff < sqrt(tol)));  // :636
         ctl[CTL_ITER] = it + 1;
+        if (light) {
+            ctl[CTL_LIGHTS] += 1;
+            ctl[CTL_LIGHT] = 0;  // (the next Newton solve -- if there is one: this iteration was to be the last -- decides afresh)
+        }
         if (ch == 0) ctl[CTL_SCI] += 1; else ctl[CTL_NR] += 1;
         // (the sweep wrote the reciprocals of its first multiplier row to slot + 1, of its second to slot + 2)
         ctl[CTL_SLOT] = (ctl[CTL_SLOT] + ((ch == 0) != swap ? 1 : 2)) % 3;

@@ -319,7 +319,7 @@ class DeviceMatrix:
         self._check(self._lib.mbar_solve_adaptive(self._ctx, _dptr(f), tol, int(maxiter), int(min_sc_iter),
                                                   float(gamma), 1 if check_convergence else 0, _dptr(hist),
                                                   int(history_rows), C.byref(res)))
-        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_}
+        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_ if not k.endswith("_")}
         out["success"] = bool(res.success)
         out["history"] = hist[: min(history_rows, res.iterations)]
         # per-state sums at the returned f (the solver has them anyway): gradient norm and all-state update without another sweep
@@ -332,7 +332,7 @@ class DeviceMatrix:
         res = _lib.SolveResult()
         self._check(self._lib.mbar_solve_sci(self._ctx, _dptr(f), tol, int(maxiter),
                                              1 if check_convergence else 0, C.byref(res)))
-        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_}
+        out = {k: getattr(res, k) for k, _ in _lib.SolveResult._fields_ if not k.endswith("_")}
         out["success"] = bool(res.success)
         return f, out
 

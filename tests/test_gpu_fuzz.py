@@ -46,6 +46,9 @@ def draw_case(i):
     f = ts.harmonic_free_energies(K_k) + 0.2 * rng.standard_normal(K)
     f -= f[0]
     opts = {name: int(rng.choice(vals)) for name, vals in OPTIONS if rng.random() < 0.35}
+    # (added in round 4, drawn from a stream of its own so that the cases of the earlier logs stay what they were: the last
+    # iteration without its Gram matrix at every size / never / by the library's size bound)
+    opts["light_last"] = int(np.random.default_rng(810_000 + i).choice([0, 1, 2, 2]))
     c_n = None
     if rng.random() < 0.35:
         c_n, first = np.zeros(N), 0
