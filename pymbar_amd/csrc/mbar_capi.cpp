@@ -1762,7 +1762,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // of both, k_select} -- the Gram matrix the next k_newton needs comes out of the same sweep as the gradients.  Two-sweep
     // loops: the Gram sweep first.
     // (fused loop: the Newton solve of an iteration rides in the launch of the previous iteration's selection -- k_select_newton --
-    // so the loop proper is four launches per iteration; a solve of its own is needed at the start and after a pause)
+    // so the loop proper is four launches per iteration (+ the idle stand-in sweep of light_last); a solve of its own is needed at
+    // the start and after a pause)
     const bool merged = fused && !wide && c->opt_merge_select;
     bool need_newton = true;
     // timing level 3: event pairs around the non-sweep sections too (the split that explains a multi-GPU iteration)
