@@ -628,6 +628,8 @@ def main():
                        "ms_per_iteration": 1e3 * t / max(1, int(r["iterations"])),
                        "iterations_per_s": int(r["iterations"]) / t,
                        "separate_gram_sweeps": int(r.get("gram_sweeps", -1)),
+                       # (the last iteration's sweep when both candidates already met the stop test: no Hessian accumulated, none needed)
+                       "sweeps_without_gram_matrix": int(r.get("light_sweeps", -1)),
                        "build_sweeps": int(r.get("builds", -1)), "warm_starts": int(r.get("warm_starts", -1)),
                        "frac": int(r["iterations"]) * flops * world / t * 1e-12 / (FP64_MFMA_PEAK_TFLOPS * world)}
                 for name, msc, r, t in (("adaptive_min_sc_iter_0", 0, conv, t_conv), ("adaptive_min_sc_iter_2", 2, conv2, t_conv2),
