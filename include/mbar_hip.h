@@ -72,6 +72,11 @@ int mbar_ctx_synchronize(mbar_ctx* ctx);
  * bounded by MBAR_CACHE_MB (environment; default an eighth of the device's memory; 0 = off); an allocation that fails empties
  * the cache and is tried again.  This returns every parked block to the driver. */
 int mbar_cache_trim(void);
+/* Environment variables read by the library (diagnostics; none changes a result):
+ *   MBAR_CACHE_MB        bound of the block cache above
+ *   MBAR_HOST_THREADS    team size of the host-side K x K factorisation (default: all cores, at most 16)
+ *   MBAR_DEBUG_TIMING    per-iteration wall-clock split of the host-driven loops and of the host factorisation on stderr
+ *   MBAR_DEBUG_STAMPS    shader-clock stamps of the phases of k_select_newton (selection / set-up / elimination / candidates) on stderr */
 /* 128-bit content digest of a HOST buffer, computed at memory speed on `threads` host threads (0 = all cores).  The reference's
  * module-level functions are pure functions of the u_kn they are handed (mbar_solvers.py:260-292: every call reads the current
  * array); the Python binding keeps device copies of recently seen host matrices and re-uses one only when the digest of the

@@ -280,6 +280,7 @@ struct mbar_ctx {
     size_t part_g_doubles = 0;
     double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
     double* chol = nullptr;         // workspace of the blocked Cholesky Newton solve (129 .. 256 states)
+    long long* stamps = nullptr;    // MBAR_DEBUG_STAMPS: phase stamps of k_select_newton (64 launches x 8)
     // P outlives the solve that built it: a later solve on the same matrix whose start lies within the window of the anchor
     // (bootstrap replicates, protocol stages, continuation) starts with ONE fused sweep instead of the build sweep
     std::vector<double> last_psum;  // per-state sums at the f the last adaptive solve returned (empty: none)
@@ -1719,6 +1720,12 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     q.fused = fused ? 1 : 0;
     q.cgram = fused ? c->pm_vec + 2 * Kp : nullptr;
     q.light_ok = light ? 1 : 0;
+    q.stamps = nullptr;
+    if (std::getenv("MBAR_DEBUG_STAMPS")) {
+        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 64 * 8 * sizeof(long long)));
+        HIPCHK(c, hipMemsetAsync(c->stamps, 0, 64 * 8 * sizeof(long long), c->stream));
+        q.stamps = c->stamps;
+    }
 
     // Gram sweep at the current f with the known logden (the slot of the accepted candidate; P mode: the slots hold the
     // reciprocals 1 / s_n instead), reduced and all-reduced into the blocks k_newton reads.  Two-sweep loops: once per
@@ -1961,6 +1968,16 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             psum[k] = h[ad_off_psum(c) + k];
         }
         if (it > res.iterations) max_delta = h[ad_off_state(c)];
+    }
+    if (q.stamps) {
+        std::vector<long long> st(64 * 8);
+        HIPCHK(c, hipMemcpy(st.data(), c->stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 64; ++i) {
+            const long long* p = st.data() + 8 * i;
+            if (!p[0] || !p[5]) continue;
+            std::fprintf(stderr, "[mbar] k_select_newton launch %d (shader clocks): select %lld, set-up %lld, elimination %lld, solution %lld, candidates %lld, total %lld\n",
+                         i, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[5] - p[0]);
+        }
     }
     res.iterations = it;
     res.sci_iter = c->h_ctl[CTL_SCI];

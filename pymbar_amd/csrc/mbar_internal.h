@@ -226,6 +226,8 @@ struct AdaptArgs {
     // fused loop: the last iteration may run without its Gram matrix (CTL_LIGHT); 0 = never (small problems: an idle launch
     // per iteration would cost more than the one lighter sweep saves)
     int light_ok;
+    // MBAR_DEBUG_STAMPS=1: shader-clock stamps of the phases of k_select_newton (thread 0; [8] per launch slot, 64 slots)
+    long long* stamps;
 };
 // ---- P mode: resident probability matrix P = exp(a0 - u - logden(a0)) (see k_psweep) ----------------------------------
 LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);

@@ -459,6 +459,104 @@ __device__ __forceinline__ void newton_tail(const AdaptArgs& q, const double* xs
     if (tid == 0) q.ctl[CTL_LIGHT] = (q.light_ok && q.fused && flags == 0 && q.prm[3] != 0.0) ? 1 : 0;
 }
 
+// The elimination proper: publish the pivot columns, barrier, read them back, update -- a step's latency chain (LDS round trip,
+// barrier, reciprocals, multipliers) and its fused multiply-adds one after the other.  Instrumented (MBAR_DEBUG_STAMPS, shader
+// clocks): 1770 per two-pivot step at 127 unknowns (~900 of them the chain), 1300 at 39.  Measured dead end (round 4): running the
+// NEXT step's chain under THIS step's arithmetic -- the owners of the next pivot columns bring those entries up to date first and
+// publish them, barrier, everybody reads the next columns and starts the reciprocals, then the rest of the tile is updated;
+// bit-identical to this form (every entry keeps its order of updates), but 2.2x SLOWER as compiled: the priority update is a
+// latency chain of its own (LDS read, two FMAs, LDS write, barrier) and the in-order wave does not start the bulk FMAs while
+// the reciprocals are in flight unless every stage is interleaved by hand.
+template <int T, int R>
+__device__ __forceinline__ bool eliminate_serial(double (&A)[R][R], double (&colbuf)[2][2][R * T], double* pv, int M, double piv_thr,
+                                                 int tid, int ty, int tx) {
+    constexpr int NC = R * T;
+    bool bad = false;
+#pragma unroll
+    for (int jc = 0; jc < R; ++jc) {
+        const int jend = M < T * (jc + 1) ? M : T * (jc + 1);
+        int j = T * jc;
+        // Two pivots per barrier (the step is a latency chain, not arithmetic): columns j and j + 1 are published as they
+        // stand, every thread forms the multiplier l = A[j+1][j] / p1 of row j + 1, the second pivot p2 = A[j+1][j+1] - l A[j+1][j]
+        // and, for its rows and columns, what the second elimination step would have read:
+        //   column j + 1 after step j: c2_i = A[i][j+1] - m1_i A[j][j+1],   row j + 1 after step j: r2_k = A[j+1][k] - l A[j][k]
+        // and then applies both rank-1 updates at once.  Pivot rows: m1_j = 0, m2_{j+1} = 0 (row j is still cleared of its
+        // (j + 1) entry by the second pivot, row j + 1 of its j entry by the first).
+        for (; j + 1 < jend; j += 2) {
+            const int jt = j - T * jc;
+            double* ca = colbuf[(j >> 1) & 1][0];
+            double* cb = colbuf[(j >> 1) & 1][1];
+            if (tx == jt || tx == jt + 1) {  // owners of columns j and j + 1
+                double* cx = tx == jt ? ca : cb;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r < R - 1 || ty != T - 1) cx[ty + T * r] = A[r][jc];  // (slot NC-1 belongs to b)
+            }
+            if (tx == T - 1) {
+                if (ty == jt) ca[NC - 1] = A[jc][R - 1];      // b_j
+                if (ty == jt + 1) cb[NC - 1] = A[jc][R - 1];  // b_{j+1}
+            }
+            __syncthreads();
+            const double p1 = ca[j], a12 = ca[j + 1], a22 = cb[j + 1];
+            // (the two reciprocals side by side instead of one after the other: 1 / p2 = p1 / (a22 p1 - a12^2); the pivot p2 itself
+            // -- recorded, and compared with the threshold -- as before)
+            const double det = fma(a22, p1, -a12 * a12);
+            const double inv1 = recip_fast(p1);
+            const double invdet = recip_fast(det);
+            const double l = a12 * inv1;
+            const double p2 = fma(-l, a12, a22);
+            const double inv2 = p1 * invdet;
+            if (tid == 0) {
+                pv[j] = p1;
+                pv[j + 1] = p2;
+            }
+            if (!(p1 > piv_thr) || !isfinite(p1) || !(p2 > piv_thr) || !isfinite(p2)) bad = true;  // the same in every thread
+            double m1[R], m2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double x1 = ca[ty + T * r], x2 = cb[ty + T * r];
+                m1[r] = x1 * inv1;
+                if (ty == jt && r == jc) m1[r] = 0.0;  // pivot row j
+                m2[r] = fma(-m1[r], a12, x2) * inv2;
+                if (ty == jt + 1 && r == jc) m2[r] = 0.0;  // pivot row j + 1
+            }
+#pragma unroll
+            for (int c = jc; c < R; ++c) {
+                const double r1 = ca[tx + T * c];
+                const double r2 = fma(-l, r1, cb[tx + T * c]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) A[r][c] = fma(-m2[r], r2, fma(-m1[r], r1, A[r][c]));
+            }
+        }
+        for (; j < jend; ++j) {  // (an odd pivot left over in this tile column)
+            const int jt = j - T * jc;
+            double* cb = colbuf[(j >> 1) & 1][0];
+            if (tx == jt) {  // owners of column j
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r < R - 1 || ty != T - 1) cb[ty + T * r] = A[r][jc];  // (slot NC-1 belongs to b_j)
+            }
+            if (ty == jt && tx == T - 1) cb[NC - 1] = A[jc][R - 1];  // b_j
+            __syncthreads();
+            const double piv = cb[j];
+            if (tid == 0) pv[j] = piv;
+            if (!(piv > piv_thr) || !isfinite(piv)) bad = true;  // the same value in every thread
+            const double inv = recip_fast(piv);
+            double mr[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) mr[r] = cb[ty + T * r] * inv;
+            if (ty == jt) mr[jc] = 0.0;  // the pivot row itself
+#pragma unroll
+            for (int c = jc; c < R; ++c) {
+                const double rv = cb[tx + T * c];
+#pragma unroll
+                for (int r = 0; r < R; ++r) A[r][c] = fma(-mr[r], rv, A[r][c]);
+            }
+        }
+    }
+    return bad;
+}
+
 // Newton direction + both candidates, ONE workgroup of T x T threads with an R x R tile each (up to R T - 1 unknowns:
 // 8 x 8 threads x 4 x 4 -> 31, 16 x 16 x 4 x 4 -> 63, 16 x 16 x 8 x 8 -> 127).
 //   H = diag(psum) - G on the sampled states, g = psum - N_k (:581, :284-292); gauge x[first] = 0, so the system is the
@@ -484,7 +582,7 @@ __device__ __forceinline__ void newton_tail(const AdaptArgs& q, const double* xs
 // non-finite candidate hand the solve back to the host loop (CTL_DONE = 2).
 // Outputs: cand = (f_sci, f_nr), ratio = exp(aden_nr - aden_sci), aden = (aden_sci, ratio) for the sweep.
 template <int T, int R>
-__device__ __forceinline__ void newton_body(const AdaptArgs& q) {  // (T * T threads; the pointers of q may be LDS or global)
+__device__ __forceinline__ void newton_body(const AdaptArgs& q, long long* st = nullptr) {  // (T * T threads; the pointers of q may be LDS or global)
     constexpr int NC = R * T, NT = T * T;
     __shared__ double colbuf[2][2][NC];  // [parity of the step][column j, column j + 1]
     __shared__ double pv[NC], rh[NC], xs[NC + 1];
@@ -548,87 +646,20 @@ __device__ __forceinline__ void newton_body(const AdaptArgs& q) {  // (T * T thr
     // pivots below eps * M * (largest per-state sum, which bounds the diagonal of H) count as zero like the singular values
     // numpy.linalg.lstsq drops (:582): the host path then takes the pseudo-inverse
     double pmax = 0.0;
-    for (int i = 0; i < q.m; ++i) pmax = fmax(pmax, s_ps[smp[i]]);
-    const double piv_thr = pmax * 2.220446049250313e-16 * (double)(M > 0 ? M : 1);
-    bool bad = false;
+    {   // (a maximum over the workgroup: the serial loop over the sampled states was ~2 us of dependent LDS reads)
+        __shared__ double s_pmax[NT / 64];
+        double v = 0.0;
+        for (int i = tid; i < q.m; i += NT) v = fmax(v, s_ps[smp[i]]);
+        v = wave_max(v);
+        if ((tid & 63) == 0) s_pmax[tid >> 6] = v;
+        __syncthreads();
 #pragma unroll
-    for (int jc = 0; jc < R; ++jc) {
-        const int jend = M < T * (jc + 1) ? M : T * (jc + 1);
-        int j = T * jc;
-        // Two pivots per barrier (the step is a latency chain, not arithmetic): columns j and j + 1 are published as they
-        // stand, every thread forms the multiplier l = A[j+1][j] / p1 of row j + 1, the second pivot p2 = A[j+1][j+1] - l A[j+1][j]
-        // and, for its rows and columns, what the second elimination step would have read:
-        //   column j + 1 after step j: c2_i = A[i][j+1] - m1_i A[j][j+1],   row j + 1 after step j: r2_k = A[j+1][k] - l A[j][k]
-        // and then applies both rank-1 updates at once.  Pivot rows: m1_j = 0, m2_{j+1} = 0 (row j is still cleared of its
-        // (j + 1) entry by the second pivot, row j + 1 of its j entry by the first).
-        for (; j + 1 < jend; j += 2) {
-            const int jt = j - T * jc;
-            double* ca = colbuf[(j >> 1) & 1][0];
-            double* cb = colbuf[(j >> 1) & 1][1];
-            if (tx == jt || tx == jt + 1) {  // owners of columns j and j + 1
-                double* cx = tx == jt ? ca : cb;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (r < R - 1 || ty != T - 1) cx[ty + T * r] = A[r][jc];  // (slot NC-1 belongs to b)
-            }
-            if (tx == T - 1) {
-                if (ty == jt) ca[NC - 1] = A[jc][R - 1];      // b_j
-                if (ty == jt + 1) cb[NC - 1] = A[jc][R - 1];  // b_{j+1}
-            }
-            __syncthreads();
-            const double p1 = ca[j], a12 = ca[j + 1], a22 = cb[j + 1];
-            const double inv1 = recip_fast(p1);
-            const double l = a12 * inv1;
-            const double p2 = fma(-l, a12, a22);
-            const double inv2 = recip_fast(p2);
-            if (tid == 0) {
-                pv[j] = p1;
-                pv[j + 1] = p2;
-            }
-            if (!(p1 > piv_thr) || !isfinite(p1) || !(p2 > piv_thr) || !isfinite(p2)) bad = true;  // the same in every thread
-            double m1[R], m2[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const double x1 = ca[ty + T * r], x2 = cb[ty + T * r];
-                m1[r] = x1 * inv1;
-                if (ty == jt && r == jc) m1[r] = 0.0;  // pivot row j
-                m2[r] = fma(-m1[r], a12, x2) * inv2;
-                if (ty == jt + 1 && r == jc) m2[r] = 0.0;  // pivot row j + 1
-            }
-#pragma unroll
-            for (int c = jc; c < R; ++c) {
-                const double r1 = ca[tx + T * c];
-                const double r2 = fma(-l, r1, cb[tx + T * c]);
-#pragma unroll
-                for (int r = 0; r < R; ++r) A[r][c] = fma(-m2[r], r2, fma(-m1[r], r1, A[r][c]));
-            }
-        }
-        for (; j < jend; ++j) {  // (an odd pivot left over in this tile column)
-            const int jt = j - T * jc;
-            double* cb = colbuf[(j >> 1) & 1][0];
-            if (tx == jt) {  // owners of column j
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (r < R - 1 || ty != T - 1) cb[ty + T * r] = A[r][jc];  // (slot NC-1 belongs to b_j)
-            }
-            if (ty == jt && tx == T - 1) cb[NC - 1] = A[jc][R - 1];  // b_j
-            __syncthreads();
-            const double piv = cb[j];
-            if (tid == 0) pv[j] = piv;
-            if (!(piv > piv_thr) || !isfinite(piv)) bad = true;  // the same value in every thread
-            const double inv = recip_fast(piv);
-            double mr[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) mr[r] = cb[ty + T * r] * inv;
-            if (ty == jt) mr[jc] = 0.0;  // the pivot row itself
-#pragma unroll
-            for (int c = jc; c < R; ++c) {
-                const double rv = cb[tx + T * c];
-#pragma unroll
-                for (int r = 0; r < R; ++r) A[r][c] = fma(-mr[r], rv, A[r][c]);
-            }
-        }
+        for (int w = 0; w < NT / 64; ++w) pmax = fmax(pmax, s_pmax[w]);
     }
+    const double piv_thr = pmax * 2.220446049250313e-16 * (double)(M > 0 ? M : 1);
+    if (st && tid == 0) st[2] = clock64();
+    const bool bad = eliminate_serial<T, R>(A, colbuf, pv, M, piv_thr, tid, ty, tx);
+    if (st && tid == 0) st[3] = clock64();
     if (tx == T - 1) {
 #pragma unroll
         for (int r = 0; r < R; ++r) rh[ty + T * r] = A[r][R - 1];
@@ -637,6 +668,7 @@ __device__ __forceinline__ void newton_body(const AdaptArgs& q) {  // (T * T thr
     if (tid == 0) xs[0] = 0.0;
     if (tid < M) xs[tid + 1] = rh[tid] / pv[tid];
     __syncthreads();
+    if (st && tid == 0) st[4] = clock64();
 
     newton_tail<NT>(q, xs, bad, s_f, s_ps, s_nk, s_ln, s_a0, smp, pos, tid);
 }
@@ -1019,9 +1051,13 @@ template <int R>
 __global__ void __launch_bounds__(256)
 k_select_newton(AdaptArgs q, int gram_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
+    long long* st = q.stamps ? q.stamps + 8 * (q.ctl[CTL_ITER] & 63) : nullptr;  // (debug: one slot per iteration)
+    if (st && threadIdx.x == 0) st[0] = clock64();
     select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
     __syncthreads();
-    newton_body<16, R>(q);
+    if (st && threadIdx.x == 0) st[1] = clock64();
+    newton_body<16, R>(q, st);
+    if (st && threadIdx.x == 0) st[5] = clock64();
 }
 
 __global__ void __launch_bounds__(256)
