@@ -151,10 +151,13 @@ def test_config3_itself_matches_the_reference(golden):
         _assert_counts(res, g)
         _assert_delta_f(f, g["f_adaptive"], "config 3, one context")
         assert res["builds"] == 1 and res["gram_sweeps"] == 0
+        # (the last iteration found both candidates inside the stop test before its sweep: that sweep ran without the Gram matrix)
+        assert res["light_sweeps"] == 1
         # the same answer from the classic sweeps on u (no resident probability matrix) and from a warm start
         dm.set_option("pmode", 0)
         f0, res0 = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
         _assert_counts(res0, g)
         _assert_delta_f(f0, g["f_adaptive"], "config 3, classic sweeps")
+        assert res0["light_sweeps"] == 0
         dm.set_option("pmode", 1)
     _logical_ranks(u_kn, N_k, 8, g)
