@@ -11,7 +11,7 @@ import sys, os
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import mbar_oracle as orc  # noqa: E402  (test infrastructure: used here as the CPU checker only)
+from scipy.special import logsumexp  # noqa: E402
 from pymbar_amd import testsystems as ts  # noqa: E402
 
 
@@ -50,8 +50,9 @@ def main():
     O_k, K_k, N_k = ts.config3_params(K, N)
     x_n, u_kn, N_k, s_n = ts.harmonic_u_kn(O_k, K_k, N_k, seed=0)
     f = 0.5 * np.log(K_k / K_k[0])  # analytic free energies of the harmonic ladder: near the solution, as in the last iterations
-    logW = orc.mbar_log_W_nk(u_kn, N_k, f).T  # (K, N)
-    p = np.exp(logW + np.log(N_k)[:, None])   # probabilities: columns sum to one
+    a = f + np.log(N_k)                                   # a_k = f_k + ln N_k
+    logden = logsumexp(a[:, None] - u_kn, axis=0)          # mbar_solvers.py:238
+    p = np.exp(a[:, None] - u_kn - logden[None, :])        # probabilities N_k W_nk: columns sum to one
     print(f"K={K} N={u_kn.shape[1]}  column sums within {np.abs(p.sum(0) - 1).max():.1e}; max p {p.max():.3f}")
     G64 = p @ p.T
     Gx, _ = gram_sliced(p, 9, 99)
