@@ -33,15 +33,21 @@ def main():
     sel = [it for it in its if tuple(n for n, _, _ in it) == seq and max(d for _, d, _ in it) > 100.0]
     if not sel:
         sel = [it for it in its if tuple(n for n, _, _ in it) == seq]
-    print(f"{len(sel)} iterations with the sequence below (of {len(its)}); microseconds, mean over those iterations")
-    tot_d = tot_g = 0.0
-    for i, n in enumerate(seq):
-        d = sum(it[i][1] for it in sel) / len(sel)
-        g = sum(it[i][2] for it in sel) / len(sel)
-        tot_d += d
-        tot_g += g
-        print(f"  gap {g:8.1f}   {n:44s} {d:9.1f}")
-    print(f"  sum of gaps {tot_g:.1f} us, sum of kernels {tot_d:.1f} us, iteration {tot_d + tot_g:.1f} us")
+    # iterations of one launch sequence can still be of different kinds (the last iteration of a solve runs its plain sweep and
+    # leaves the fused one idle): one table per LONGEST kernel
+    kinds = collections.OrderedDict()
+    for it in sel:
+        kinds.setdefault(max(it, key=lambda e: e[1])[0], []).append(it)
+    for longest, group in kinds.items():
+        print(f"{len(group)} iterations whose longest kernel is {longest} (of {len(its)} with any sequence); microseconds, mean over those iterations")
+        tot_d = tot_g = 0.0
+        for i, n in enumerate(seq):
+            d = sum(it[i][1] for it in group) / len(group)
+            g = sum(it[i][2] for it in group) / len(group)
+            tot_d += d
+            tot_g += g
+            print(f"  gap {g:8.1f}   {n:44s} {d:9.1f}")
+        print(f"  sum of gaps {tot_g:.1f} us, sum of kernels {tot_d:.1f} us, iteration {tot_d + tot_g:.1f} us")
 
 
 if __name__ == "__main__":
