@@ -1459,8 +1459,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
                 c->P = nullptr;
                 c->P_failed = true;
                 pmode = false;
-            } else if (hipMemsetAsync(c->P, 0, (size_t)Kp * c->ld * sizeof(double), c->stream) != hipSuccess) {
-                arc = fail(c, MBAR_ERR_HIP, "hipMemsetAsync(P) failed");
+            } else if (launch_zero(c->stream, c->P, (size_t)Kp * c->ld * sizeof(double)) != hipSuccess) {
+                arc = fail(c, MBAR_ERR_HIP, "zero fill of P failed");
             }
         }
     }
@@ -2087,19 +2087,15 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
     if (!c->stream) CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t ubytes = (size_t)c->Kp * c->ld * sizeof(double);
     CRT(cache_malloc((void**)&c->u, ubytes));
-    CRT(hipMemsetAsync(c->u, 0, ubytes, c->stream));
+    CRT(launch_zero(c->stream, c->u, ubytes));
     // three logden vectors in ONE allocation: the device-resident loop addresses them as base + slot * ld
     CRT(cache_malloc((void**)&c->logden[0], (size_t)3 * c->ld * sizeof(double)));
-    CRT(hipMemsetAsync(c->logden[0], 0, (size_t)3 * c->ld * sizeof(double), c->stream));
+    CRT(launch_zero(c->stream, c->logden[0], (size_t)3 * c->ld * sizeof(double)));
     c->logden[1] = c->logden[0] + c->ld;
     c->logden[2] = c->logden[0] + 2 * c->ld;
     CRT(cache_malloc((void**)&c->cw, (size_t)c->ld * sizeof(double)));
-    CRT(hipMemsetAsync(c->cw, 0, (size_t)c->ld * sizeof(double), c->stream));
-    {
-        std::vector<double> ones((size_t)c->N, 1.0);
-        CRT(hipMemcpyAsync(c->cw, ones.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        CRT(hipStreamSynchronize(c->stream));
-    }
+    CRT(launch_zero(c->stream, c->cw, (size_t)c->ld * sizeof(double)));
+    if (c->N > 0) CRT(launch_fill(c->stream, c->cw, 1.0, c->N));  // (unit multiplicities, 0 on the padding: filled on the device)
     CRT(cache_malloc((void**)&c->small, small_doubles(c->Kp) * sizeof(double)));
     CRT(cache_host_malloc((void**)&c->hstage, (size_t)4 * c->Kp * sizeof(double)));
     CRT(hipMemsetAsync(c->small, 0, small_doubles(c->Kp) * sizeof(double), c->stream));

@@ -254,6 +254,8 @@ hipError_t launch_build_gram(hipStream_t s, int nb, const LaunchGeom& g, const d
 hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
                          const double* logden, double* P);
 hipError_t launch_fill(hipStream_t s, double* v, double value, int64_t n);
+// zero fill at HBM write speed (hipMemsetAsync below 64 KB or for unaligned ranges)
+hipError_t launch_zero(hipStream_t s, void* p, size_t bytes);
 hipError_t launch_sqrt_vec(hipStream_t s, double* dst, const double* src, int64_t n);  // dst[i] = sqrt(src[i])
 hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,
                                 const LoopCtl& lc = LoopCtl());

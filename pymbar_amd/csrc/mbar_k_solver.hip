@@ -328,6 +328,12 @@ k_make_p(const double* __restrict__ u, int64_t ld, int64_t N, int64_t rows, cons
 __global__ void __launch_bounds__(256) k_fill(double* __restrict__ v, double value, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = value;
 }
+// zero fill at HBM write speed (16 bytes per lane and store; hipMemsetAsync's fill kernel runs at ~1 TB/s: 20 ms for the 20 GB of an
+// augmented matrix of the expectation family, 10 ms for config 3's matrix in front of its upload)
+__global__ void __launch_bounds__(256) k_zero16(uint4* __restrict__ p, size_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+}
 // dst = sqrt(src): the roots of the sample multiplicities for the matrix-core operands of the weighted sweeps
 __global__ void __launch_bounds__(256) k_sqrt_vec(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = sqrt(src[i]);
@@ -1392,6 +1398,15 @@ hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int
     int64_t bx = (n + 255) / 256;
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(k_weights_from_log, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, v, p, n, cw, cwsq);
+    return hipGetLastError();
+}
+hipError_t launch_zero(hipStream_t s, void* p, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 15) != 0 || ((uintptr_t)p & 15) != 0 || bytes < (size_t)1 << 16) return hipMemsetAsync(p, 0, bytes, s);
+    const size_t n16 = bytes / 16;
+    size_t bx = (n16 + 255) / 256;
+    if (bx > 8192) bx = 8192;
+    hipLaunchKernelGGL(k_zero16, dim3((unsigned)bx), dim3(256), 0, s, (uint4*)p, n16);
     return hipGetLastError();
 }
 hipError_t launch_fill(hipStream_t s, double* v, double value, int64_t n) {
