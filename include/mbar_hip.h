@@ -127,7 +127,7 @@ int mbar_device_synchronize(int device);
  *                    mbar_solvers.py:627-636 against the current f, the iteration is the last whichever of them wins and the Gram
  *                    matrix the fused sweep would accumulate is never used: the plain two-candidate sweep on P evaluates them
  *                    instead (k_psweep, launched behind the fused sweep every iteration and idle otherwise; at config 3 1.9 ms
- *                    in place of 3.1).  1 = at 96 .. 128 states and from 5e7 matrix entries per rank on (default: elsewhere the
+ *                    in place of 3.1).  1 = at 65 .. 128 states and from 5e7 matrix entries per rank on (default: elsewhere the
  *                    idle launch per iteration costs more than the lighter sweep saves -- with 64 states and fewer both sweeps
  *                    are HBM-bound), 2 = always, 0 = never
  *   "sci_merged"     1 = pure self-consistent iteration, K <= 32, one rank: update + sweep of an iteration in ONE launch

@@ -1477,11 +1477,11 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         arc = fail(c, MBAR_ERR_HIP, "allocation of the P-mode vectors failed");
     const bool fused = pmode && c->opt_fused;
     // Last iteration without its Gram matrix (CTL_LIGHT, mbar_internal.h): an idle launch per iteration against ONE lighter sweep per
-    // solve.  Worth it where the fused sweep is bound by the matrix cores and the plain one by HBM -- 96 states and more (K = 128:
+    // solve.  Worth it where the fused sweep is bound by the matrix cores and the plain one by HBM -- 65 states and more (K = 128:
     // 1.9 ms against 3.1 at config 3; at 64 states and fewer both are HBM-bound and nothing is gained) -- and from ~5e7 matrix
     // entries per rank on (a sweep of ~0.13 ms); option light_last = 2 drops both bounds.
     bool light = fused && !wide && check_convergence && c->opt_light_last != 0 &&
-                 (c->opt_light_last >= 2 || (nb >= 6 && (double)Kp * (double)c->N >= 5.0e7));
+                 (c->opt_light_last >= 2 || (nb >= 5 && (double)Kp * (double)c->N >= 5.0e7));
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     LaunchGeom gg = wide ? gram_quad_geometry(nb, c->num_cu, ntiles, c->opt_grid)
                          : gram_geometry(nb * 16, true, c->num_cu, ntiles, c->opt_grid);

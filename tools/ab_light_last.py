@@ -14,7 +14,10 @@ from pymbar_amd.device import DeviceMatrix  # noqa: E402
 
 
 def main():
-    for K, N in ((128, 10_000_000), (128, 1_000_000), (64, 2_000_000), (32, 4_000_000), (40, 95_000)):
+    cases = ((128, 10_000_000), (128, 1_000_000), (64, 2_000_000), (32, 4_000_000), (40, 95_000))
+    if len(sys.argv) > 1:
+        cases = tuple(tuple(int(v) for v in a.split("x")) for a in sys.argv[1:])
+    for K, N in cases:
         O_k, K_k, N_k = ts.config3_params(K=K, N=N)
         with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
             dm.set_Nk(N_k)
