@@ -108,9 +108,18 @@ def check_case(DM, case):
             # the noise floor of the criterion, not a wrong answer: accepted iff the change is within 10 x tol and f is the oracle's.
             noise_floor = (ra["max_delta"] < 10.0 * tol
                            and np.max(np.abs((fa[sws] - fa[sws][0]) - ro["x"])) < 1e-11 * max(1.0, np.max(np.abs(ro["x"]))))
-        assert ra["success"] == ro["success"] or noise_floor, (ra, ro["iterations"])
         g_dev = oracle.mbar_gradient(u_or[sws], Nf[sws], fa[sws] - fa[sws][0])
         g_or = oracle.mbar_gradient(u_or[sws], Nf[sws], ro["x"])
+        # The opposite corner: states that do not overlap IN fp64 (case 13204: two states 7.5 apart, cross weights ~1e-37).  Every
+        # sample then belongs to its own state with p = 1 exactly, the sums equal N_k to the last bit and the device loop stops at
+        # once with a zero gradient -- while the reference's log-space arithmetic leaves round-off of 1e-11 in BOTH the gradient
+        # and the Hessian, takes "Newton steps" that are noise over noise and never meets its own stop test.  Any f solves such a
+        # problem; accepted iff the oracle's own gradient at OUR f is at its round-off level too.
+        disconnected = (ra["success"] and not ro["success"] and np.abs(g_dev).max() <= 1e-8 * scale
+                        and np.abs(g_or).max() <= 1e-8 * scale)
+        assert ra["success"] == ro["success"] or noise_floor or disconnected, (ra, ro["iterations"])
+        if disconnected:
+            return f"{ra['iterations']} iterations; states without overlap in fp64: the reference does not converge ({ro['iterations']})"
         assert np.abs(g_dev).max() <= 10.0 * np.abs(g_or).max() + 1e-8 * scale, (np.abs(g_dev).max(), np.abs(g_or).max())
         if ra.get("psum") is not None:
             # (mbar_gradient = psum - N_k; non-zero where the reference's loop itself runs out of iterations -- case 4089)
