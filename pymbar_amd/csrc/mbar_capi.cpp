@@ -9,6 +9,7 @@
 #include "mbar_internal.h"
 
 #include <dlfcn.h>
+#include <sched.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -1036,6 +1037,12 @@ constexpr int CHOL_THREADED_MIN = 448;  // ... and from which it is worth a team
 int host_team_size(int m) {
     if (m < CHOL_THREADED_MIN) return 1;
     int t = (int)std::thread::hardware_concurrency();
+    {   // (the cores this process may actually run on: a container or taskset may leave it fewer than the machine has, and a
+        // spinning team larger than that only takes turns)
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) t = std::min(t > 0 ? t : 1 << 20, (int)CPU_COUNT(&set));
+    }
     if (const char* e = std::getenv("MBAR_HOST_THREADS")) t = std::atoi(e);
     t = std::max(1, std::min(t, 16));
     return std::min(t, std::max(1, m / 96));
