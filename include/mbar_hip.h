@@ -123,11 +123,12 @@ int mbar_device_synchronize(int device);
  *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
  *                    one fused sweep instead of the build sweep (default); 0 = every solve builds (cold-solve timings)
  *   "merge_select"   1 = the selection of iteration i and the Newton solve of iteration i + 1 share a launch (default)
- *   "light_last"     fused loop, up to 128 states: when BOTH candidates of the coming sweep already meet the stop test of
+ *   "light_last"     fused loop: when BOTH candidates of the coming sweep already meet the stop test of
  *                    mbar_solvers.py:627-636 against the current f, the iteration is the last whichever of them wins and the Gram
  *                    matrix the fused sweep would accumulate is never used: the plain two-candidate sweep on P evaluates them
  *                    instead (k_psweep, launched behind the fused sweep every iteration and idle otherwise; at config 3 1.9 ms
- *                    in place of 3.1).  1 = at 65 .. 128 states and from 5e7 matrix entries per rank on (default: elsewhere the
+ *                    in place of 3.1; 129 .. 256 states: an evaluation-only body of k_fused_quad, no extra launch).  1 = from 65
+ *                    states and 5e7 matrix entries per rank on (default: elsewhere the
  *                    idle launch per iteration costs more than the lighter sweep saves -- with 64 states and fewer both sweeps
  *                    are HBM-bound), 2 = always, 0 = never
  *   "sci_merged"     1 = pure self-consistent iteration, K <= 32, one rank: update + sweep of an iteration in ONE launch

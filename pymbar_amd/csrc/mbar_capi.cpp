@@ -1487,7 +1487,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // solve.  Worth it where the fused sweep is bound by the matrix cores and the plain one by HBM -- 65 states and more (K = 128:
     // 1.9 ms against 3.1 at config 3; at 64 states and fewer both are HBM-bound and nothing is gained) -- and from ~5e7 matrix
     // entries per rank on (a sweep of ~0.13 ms); option light_last = 2 drops both bounds.
-    bool light = fused && !wide && check_convergence && c->opt_light_last != 0 &&
+    // (129 .. 256 states: the one-read fused sweep has an evaluation-only body of its own and needs no stand-in launch)
+    bool light = fused && check_convergence && c->opt_light_last != 0 &&
                  (c->opt_light_last >= 2 || (nb >= 5 && (double)Kp * (double)c->N >= 5.0e7));
     // geometry and buffers are fixed for the whole solve (nothing may allocate inside a capture)
     LaunchGeom gg = wide ? gram_quad_geometry(nb, c->num_cu, ntiles, c->opt_grid)
@@ -1503,8 +1504,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // the plain sweep that stands in for the fused one leaves ITS per-state records where the fused sweep leaves them too: as many
     // waves as the fused grid has, in workgroups of the plain sweep's size
     LaunchGeom gp = psweep_geometry(wide ? 8 : nb, c->num_cu, ntiles, 0);
-    if (light && gl.nwaves % gp.waves != 0) light = false;
-    if (light) {
+    if (light && !wide && gl.nwaves % gp.waves != 0) light = false;
+    if (light && !wide) {
         gp.blocks = gl.nwaves / gp.waves;
         gp.nwaves = gp.psum_records = gl.nwaves;
     }
@@ -1825,7 +1826,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             if (fused) {
                 HIPCHK(c, launch_fused(c->stream, nb, gl, c->P, c->ld, c->N, d_aden(c), c->cw, c->weighted ? c->cwsq : c->cw,
                                        c->logden[0], gram_part, psum_part, lcb));
-                if (light) {  // (idle unless k_newton found that this iteration is the last: then the fused sweep is the idle one)
+                if (light && !wide) {  // (idle unless k_newton found that this iteration is the last: then the fused sweep is the idle one)
                     LoopCtl lcl = lc_slot;
                     lcl.light_only = true;
                     HIPCHK(c, launch_psweep(c->stream, nb, 2, gp, c->P, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, psum_part, lcl));

@@ -46,7 +46,8 @@ enum : int {
     CTL_LIGHT = 9,   // fused loop: 1 = BOTH candidates of the coming sweep already satisfy the stop test (mbar_solvers.py:636) against
                      // the current f, so this iteration is the last whichever of them wins and nobody will need the Gram
                      // matrix the fused sweep would accumulate: the fused sweep returns at once and the plain two-candidate
-                     // sweep on P (k_psweep, launched right behind it and idle otherwise) evaluates the candidates instead
+                     // sweep on P (k_psweep, launched right behind it and idle otherwise) evaluates the candidates instead; the
+                     // one-read fused sweep of 129 .. 256 states switches to an evaluation-only body of its own
     CTL_LIGHTS = 10,  // iterations evaluated that way
     CTL_WORDS = 12
 };

@@ -447,6 +447,114 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
     quad_store_blocks<NBT, NBM, WV>(gram_part + (int64_t)blockIdx.x * NBLK * 256, acc, lane);
 }
 
+// The last iteration of a converging solve (CTL_LIGHT, mbar_internal.h): nobody will read the Gram matrix, so the sweep is the
+// evaluation half of fused_quad_body alone -- normalisers, reciprocals and per-state sums of both candidates, same tile stream,
+// same partial records -- and HBM-bound (one 24- / 32-KB tile in flight per CU) instead of matrix-bound.  A body of its own: the
+// full one keeps its hand-placed instruction stream untouched.
+template <int NBT, int WV, bool WIDE, int NBM = NBT>
+__device__ __forceinline__ void fused_quad_light_body(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles,
+                                                      const double* __restrict__ cmul, const double* __restrict__ cw,
+                                                      const double* __restrict__ wsq, double* __restrict__ rinv0,
+                                                      double* __restrict__ rinv1, double* __restrict__ psum_part, char* smem, int lane) {
+    constexpr int ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + 4 * 1024;
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem;
+    double* xs = reinterpret_cast<double*>(smem + 2 * TILE_BYTES);  // [wave][candidate][16 samples]
+    RowIdentity rows{0};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+    const int64_t G = gridDim.x;
+    double c0[NQ], c1[NQ], acc0[NQ], acc1[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        c0[i] = WV * NQ + i < NBM ? cmul[16 * (WV * NQ + i) + ks] : 0.0;
+        c1[i] = WV * NQ + i < NBM ? cmul[ROWS + 16 * (WV * NQ + i) + ks] : 0.0;
+        acc0[i] = acc1[i] = 0.0;
+    }
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+    const char* wsrc = reinterpret_cast<const char*>(((lane >> 3) & 1) ? wsq : cw) + (lane & 7) * 16;
+    auto stage = [&](int64_t tile, char* dst) {  // this wave's quarter of the rows + its copy of the multiplicities
+#pragma unroll
+        for (int j = WV * QDMA; j < (WV + 1) * QDMA; ++j)
+            if (j < 2 * NBM) stage_piece<true>(P + rows(8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + tile * (TS * 8)),
+                                         (__attribute__((address_space(3))) void*)(dst + U_BYTES + WV * 1024), 16, 0, 0);
+    };
+    double x[GROUPS * NQ], w[GROUPS];
+    auto read_own = [&](const char* tb) {
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            w[g] = *reinterpret_cast<const double*>(tb + U_BYTES + WV * 1024 + (4 * g + ns) * 8);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                x[g * NQ + i] = WV * NQ + i < NBM ? *reinterpret_cast<const double*>(tb + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) : 0.0;
+        }
+    };
+    int64_t t = blockIdx.x;
+    int cur = 0;
+    if (t < ntiles) {
+        stage(t, buf);
+        wait_vm<0>();
+        read_own(buf);
+    }
+    for (; t < ntiles; t += G) {
+        char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+        const int64_t tnext = t + G < ntiles ? t + G : t;
+        stage(tnext, nbuf);  // (this wave's rows of the other buffer: read last at the end of the previous iteration, by this wave)
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                d0 = fma(x[g * NQ + i], c0[i], d0);
+                d1 = fma(x[g * NQ + i], c1[i], d1);
+            }
+            row16_sum2(d0, d1);
+            if (ks < 2) xs[(WV * 2 + ks) * TS + 4 * g + ns] = ks == 0 ? d0 : d1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const int sidx = 4 * g + ns;
+            const double s0 = (xs[(0 * 2 + 0) * TS + sidx] + xs[(1 * 2 + 0) * TS + sidx]) + (xs[(2 * 2 + 0) * TS + sidx] + xs[(3 * 2 + 0) * TS + sidx]);
+            const double s1 = (xs[(0 * 2 + 1) * TS + sidx] + xs[(1 * 2 + 1) * TS + sidx]) + (xs[(2 * 2 + 1) * TS + sidx] + xs[(3 * 2 + 1) * TS + sidx]);
+            const double r0 = recip_fast(fmax(s0, 1e-300)), r1 = recip_fast(fmax(s1, 1e-300));
+            const double q0 = w[g] * r0, q1 = w[g] * r1;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (WV * NQ + i >= NBM) continue;
+                acc0[i] = fma(x[g * NQ + i], q0, acc0[i]);
+                acc1[i] = fma(x[g * NQ + i], q1, acc1[i]);
+            }
+            if (g == WV) {
+                const int64_t n = t * TS + sidx;
+                if (n < N && ks < 2) (ks == 0 ? rinv0 : rinv1)[n] = ks == 0 ? r0 : r1;
+            }
+        }
+        __syncthreads();  // (the table of partial normalisers is free again)
+        wait_vm<0>();
+        read_own(nbuf);
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        double v0 = acc0[i], v1 = acc1[i];
+        v0 += __shfl_xor(v0, 16);
+        v0 += __shfl_xor(v0, 32);
+        v1 += __shfl_xor(v1, 16);
+        v1 += __shfl_xor(v1, 32);
+        if (lane < 16) {
+            psum_part[((int64_t)blockIdx.x * 2 + 0) * ROWS + 16 * (WV * NQ + i) + lane] = v0;
+            psum_part[((int64_t)blockIdx.x * 2 + 1) * ROWS + 16 * (WV * NQ + i) + lane] = v1;
+        }
+    }
+}
+
+
 template <int NBT, bool WIDE, int NBM = NBT>
 __global__ void __launch_bounds__(256, 1)
 k_fused_quad(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ cmul,
@@ -459,6 +567,15 @@ k_fused_quad(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles
     rinv0 = rinv0 + (int64_t)((s + 1) % 3) * slot_stride;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (ctl[CTL_LIGHT] != 0) {  // the last iteration of a converging solve: no Gram matrix (its records are left alone)
+        switch (wave) {
+            case 0: fused_quad_light_body<NBT, 0, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, psum_part, smem, lane); break;
+            case 1: fused_quad_light_body<NBT, 1, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, psum_part, smem, lane); break;
+            case 2: fused_quad_light_body<NBT, 2, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, psum_part, smem, lane); break;
+            default: fused_quad_light_body<NBT, 3, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, psum_part, smem, lane); break;
+        }
+        return;
+    }
     switch (wave) {
         case 0: fused_quad_body<NBT, 0, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
         case 1: fused_quad_body<NBT, 1, WIDE, NBM>(P, ld, N, ntiles, cmul, cw, wsq, rinv0, rinv1, gram_part, psum_part, smem, lane); break;
