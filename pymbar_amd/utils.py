@@ -170,18 +170,25 @@ def _host_threads(nrows):
     return max(1, min(16, int(nrows), (_os.cpu_count() or 1)))
 
 
+# (glibc serves blocks up to 32 MB from its heap -- pages that have been touched before -- and maps larger ones afresh: above that
+# size a copy is bound by the first touch of its pages on ONE thread (15 GB/s on the GPU box's host against 75 GB/s below it),
+# which several threads take in parallel; below it numpy's own copy is the fastest: 30 MB in 0.42 ms against 0.58 ms threaded)
+_THREADED_COPY_BYTES = 32 << 20
+
+
 def private_copy(src):
-    """``np.array(src)`` of a float64 C-contiguous matrix; from 64 MB on the rows are copied by several threads (numpy releases
+    """``np.array(src)`` of a float64 C-contiguous matrix; from 32 MB on the rows are copied by several threads (numpy releases
     the GIL in ``copyto``): a fresh multi-GB array is bound by the first touch of its pages on one thread (14 GB/s on the GPU
     box's host), which several threads take in parallel (120-145 GB/s)."""
     import numpy as _np
 
-    if src.nbytes < (64 << 20) or src.ndim != 2 or src.shape[0] < 2:
+    if src.nbytes < _THREADED_COPY_BYTES or src.ndim != 2 or src.shape[0] < 2:
         return _np.array(src, dtype=_np.float64)
     from concurrent.futures import ThreadPoolExecutor
 
     out = _np.empty_like(src)
-    chunks = _row_chunks(src.shape[0], _host_threads(src.shape[0]))
+    # (at least ~4 MB per thread)
+    chunks = _row_chunks(src.shape[0], min(_host_threads(src.shape[0]), max(2, src.nbytes >> 22)))
     with ThreadPoolExecutor(len(chunks)) as ex:
         list(ex.map(lambda c: _np.copyto(out[c[0]:c[1]], src[c[0]:c[1]]), chunks))
     return out
