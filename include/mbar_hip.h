@@ -131,6 +131,8 @@ int mbar_device_synchronize(int device);
  *                    states and 5e7 matrix entries per rank on (default: elsewhere the
  *                    idle launch per iteration costs more than the lighter sweep saves -- with 64 states and fewer both sweeps
  *                    are HBM-bound), 2 = always, 0 = never
+ *   "direct_results" 1 = mbar_eval on one rank without the Gram matrix: the last reduction level writes the sums into pinned host
+ *                    memory itself instead of a device buffer + a copy (default); 0 = always through the device buffer
  *   "sci_merged"     1 = pure self-consistent iteration, K <= 32, one rank: update + sweep of an iteration in ONE launch
  *                    (k_sci_small; default); 0 = sweep + single-workgroup update kernel (what several ranks and K > 32 run)
  *   "graph", "sci_batch"             hipGraph batching of the solver loops

@@ -290,7 +290,7 @@ struct mbar_ctx {
     // options
     const int64_t opt_staging = 0;  // (tiles are staged by LDS-DMA; the register-staged kernels of rounds 1-3 are gone)
     int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1, opt_direct_results = 1;
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -902,7 +902,19 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
     // the sweep's results have been read back, so no synchronisation is needed here)
     std::copy(h.begin(), h.end(), c->hstage);
     HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    rc = run_lse(c, nf, rows, ld0, ld1, use_off);
+    // One rank, sums only: the last level of the reduction writes into the pinned host buffer itself (it is mapped into the
+    // device's address space) -- one copy kernel less per evaluation; the scipy-driven protocol stages call this thirty times
+    // per solve and at the sizes pymbar is mostly used at an evaluation IS its launches.
+    const bool direct = c->opt_direct_results && c->nranks <= 1 && !c->comm && !stream_transport(c) && use_fast(c) && !want_gram;
+    struct RedSwap {
+        mbar_ctx* c; double* saved;
+        RedSwap(mbar_ctx* c_, bool on) : c(c_), saved(nullptr) { if (on) { saved = c->red; c->red = c->hred; } }
+        ~RedSwap() { if (saved) c->red = saved; }
+    };
+    {
+        RedSwap swap(c, direct);
+        rc = run_lse(c, nf, rows, ld0, ld1, use_off);
+    }
     if (rc) return rc;
     if (want_gram) {
         // p-mode operand: anum = aden of f[0] (Kp entries)
@@ -913,9 +925,11 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
         rc = run_gram(c, d_anum(c), ld0, off_gram, plan);
         if (rc) return rc;
     }
-    rc = allreduce_dev(c, c->red, (int64_t)total, 0);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (!direct) {
+        rc = allreduce_dev(c, c->red, (int64_t)total, 0);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     rc = sync_stream(c);
     if (rc) return rc;
     if (!ratio.empty())  // the fused sweep accumulates sum_n e_nk / s'_n for the second candidate: times c_k = its psum
@@ -2283,6 +2297,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "pcache") c->opt_pcache = value;
     else if (k == "merge_select") c->opt_merge_select = value;
     else if (k == "light_last") c->opt_light_last = value;
+    else if (k == "direct_results") c->opt_direct_results = value;
     else if (k == "sci_merged") c->opt_sci_merged = value;
     else if (k == "wide_pmode") c->opt_wide_pmode = value;
     else if (k == "quad_trim") {
