@@ -4,10 +4,12 @@
     pymbar.mbar.mbar_solvers = pymbar_amd.mbar_solvers
 
 and compared, in the same process, with the reference running on its own numpy solver module.  The device behind the
-drop-in is the CPU stand-in (tests/cpu_standin.py): this runs in the build container, where the reference tree is
-mounted and there is no GPU.  Prints one JSON line with the largest deviations; exits non-zero on a mismatch.
-Run by tests/test_reference_boundary.py (PYTHONPATH = tests/refshim : /root/reference : repo root)."""
+drop-in is the CPU stand-in (tests/cpu_standin.py) in the build container, where the reference tree is mounted and there
+is no GPU (tests/test_reference_boundary.py; PYTHONPATH = tests/refshim : /root/reference : repo root) -- or, with
+``MBAR_REFSHIM_DEVICE=hip`` and ``MBAR_REFERENCE_TREE=<staged copy>``, the REAL device on an MI355X box
+(tools/reference_on_gpu_box.sh).  Prints one JSON line with the largest deviations; exits non-zero on a mismatch."""
 import json
+import os
 import sys
 
 import numpy as np
@@ -17,15 +19,23 @@ def main():
     import pymbar  # the reference
     import pymbar.mbar
 
-    assert pymbar.__file__.startswith("/root/reference"), pymbar.__file__
+    REF = os.path.realpath(os.environ.get("MBAR_REFERENCE_TREE", "/root/reference"))
+    ON_HIP = os.environ.get("MBAR_REFSHIM_DEVICE", "standin") == "hip"
+    assert os.path.realpath(pymbar.__file__).startswith(REF), pymbar.__file__
     import pymbar_amd.device
     import pymbar_amd.mbar_solvers as amd_solvers
     from pymbar_amd import testsystems as ts
-    from tests.cpu_standin import OracleMatrix
+    if ON_HIP:  # an MI355X box with a staged reference tree: the real device behind the drop-in
+        from pymbar_amd import _lib
 
-    pymbar_amd.device.DeviceMatrix = OracleMatrix  # the drop-in's device -> numpy oracle (no GPU here)
+        _lib.require_device()
+        OracleMatrix = pymbar_amd.device.DeviceMatrix
+    else:
+        from tests.cpu_standin import OracleMatrix
+
+        pymbar_amd.device.DeviceMatrix = OracleMatrix  # the drop-in's device -> numpy oracle (no GPU here)
     ref_solvers = pymbar.mbar.mbar_solvers
-    assert ref_solvers.__file__.startswith("/root/reference")
+    assert os.path.realpath(ref_solvers.__file__).startswith(REF)
     assert pymbar.MBAR.__module__ == "pymbar.mbar"
 
     worst = {}
@@ -118,7 +128,10 @@ def main():
     if (n_ctor, n_after, n_boot) != (1, 1, 4):
         print(json.dumps({"mismatch": "uploads per pymbar.MBAR construction", "uploads": [n_ctor, n_after, n_boot]}))
         sys.exit(1)
-    print(json.dumps({"ok": True, "worst_deviation": max(worst.values()), "checks": len(worst),
+    with open("/proc/self/maps") as fh:
+        mapped = sorted({ln.split()[-1] for ln in fh if "libmbar_hip" in ln})
+    print(json.dumps({"ok": True, "device": "hip" if ON_HIP else "cpu stand-in", "mapped_native_code": mapped,
+                      "reference_tree": REF, "worst_deviation": max(worst.values()), "checks": len(worst),
                       "uploads_per_construction": n_ctor, "uploads_per_construction_with_3_bootstraps": n_boot,
                       "worst": sorted(worst.items(), key=lambda kv: -kv[1])[:5]}))
 

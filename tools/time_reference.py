@@ -29,12 +29,30 @@ import time
 import numpy as np
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--K", type=int, default=128)
     ap.add_argument("--N", type=int, nargs="+", default=[1_000_000, 2_000_000, 4_000_000])
     ap.add_argument("--full-solve-N", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions per quantity (the best is kept) after one warm-up call")
+    ap.add_argument("--iteration-only-N", type=int, nargs="*", default=[],
+                    help="sizes at which ONLY one adaptive iteration is timed, once, without a warm-up call (bounded host time "
+                         "on a GPU box whose minutes are metered); said so in the row")
+    ap.add_argument("--solve-only-N", type=int, nargs="*", default=[],
+                    help="sizes at which ONLY the full adaptive solve from f = 0 is run (once): wall clock to converge and "
+                         "iteration count of the reference itself at that size -- config 3 is --solve-only-N 10000000 (~50 GB)")
+    ap.add_argument("--host-label", default="build container", help="which host this is (goes into the record)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
@@ -42,14 +60,15 @@ def main():
     from pymbar import mbar_solvers as ref
     from pymbar.testsystems import harmonic_oscillators
 
-    assert os.path.realpath(pymbar.__file__).startswith("/root/reference"), pymbar.__file__
+    ref_tree = os.path.realpath(os.environ.get("MBAR_REFERENCE_TREE", "/root/reference"))
+    assert os.path.realpath(pymbar.__file__).startswith(ref_tree), pymbar.__file__
     import scipy
 
     K = args.K
     O_k = np.linspace(0.0, 4.0, K)
     K_k = np.linspace(1.0, 3.0, K)
     rows = []
-    for N in args.N:
+    for N in sorted(set(args.N) | set(args.iteration_only_N) | set(args.solve_only_N)):
         N_k = np.full(K, N // K, dtype=np.int64)
         tc = harmonic_oscillators.HarmonicOscillatorsTestCase(O_k, K_k)
         x_n, u_kn, N_k_out, s_n = tc.sample(N_k, mode="u_kn", seed=0)
@@ -80,6 +99,38 @@ def main():
             g_nr = ref.mbar_gradient(u_kn, Nf, f_nr)
             return np.dot(g_sci, g_sci) < np.dot(g_nr, g_nr)
 
+        if N in args.solve_only_N and N not in args.N:
+            import io
+            import logging
+
+            log = io.StringIO()
+            handler = logging.StreamHandler(log)
+            logging.getLogger("pymbar.mbar_solvers").addHandler(handler)
+            logging.getLogger("pymbar.mbar_solvers").setLevel(logging.INFO)
+            t0 = time.perf_counter()
+            f_out, res = ref.solve_mbar_once(u_kn, Nf, np.zeros(K), method="adaptive", tol=1e-12,
+                                             options=dict(min_sc_iter=0, maxiter=10000, verbose=True))
+            wall = time.perf_counter() - t0
+            logging.getLogger("pymbar.mbar_solvers").removeHandler(handler)
+            text = log.getvalue()
+            iters = text.count("Newton-Raphson gradient norm is")  # one such line per iteration (mbar_solvers.py:599-603)
+            row = dict(N=N, full_solve_s=wall, full_solve_iterations=iters, full_solve_success=bool(res["success"]),
+                       adaptive_iteration_s=wall / max(1, iters), timing="ONE cold solve from f = 0, tol 1e-12, min_sc_iter 0; "
+                       "adaptive_iteration_s = wall / iterations",
+                       f_k=[float(v) for v in (f_out - f_out[0])])
+            print(json.dumps({k: v for k, v in row.items() if k != "f_k"}), flush=True)
+            rows.append(row)
+            del u_kn, x_n
+            continue
+        if N not in args.N:  # iteration only, one cold run
+            g = ref.mbar_gradient(u_kn, Nf, f)
+            t0 = time.perf_counter()
+            one_iteration(g)
+            row = dict(N=N, adaptive_iteration_s=time.perf_counter() - t0, timing="ONE run, no warm-up call")
+            print(json.dumps(row), flush=True)
+            rows.append(row)
+            del u_kn, x_n
+            continue
         g, t_grad = best_of(ref.mbar_gradient, u_kn, Nf, f)
         H, t_hess = best_of(ref.mbar_hessian, u_kn, Nf, f)
         fs, t_sci = best_of(ref.self_consistent_update, u_kn, Nf, f)
@@ -108,7 +159,8 @@ def main():
     except Exception:
         pass
     out = {
-        "what": "UNMODIFIED reference pymbar (numpy backend, scipy logsumexp) timed on the build container",
+        "what": "UNMODIFIED reference pymbar (numpy backend, scipy logsumexp) timed on: " + args.host_label,
+        "host_label": args.host_label,
         "K": K,
         "rows": rows,
         "adaptive_iteration_seconds_per_sample_by_row": per_sample_rows,
@@ -119,7 +171,8 @@ def main():
         "unit": "iter/s",
         "kind": "reference",
         "cores": os.cpu_count(),
-        "host": platform.processor() or platform.machine(),
+        "host": platform.processor() or platform.machine(), "cpu_model": cpu_model(),
+        "cores_this_process_may_use": len(os.sched_getaffinity(0)),
         "python": sys.version.split()[0], "numpy": np.__version__, "scipy": scipy.__version__,
         "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS", os.environ.get("OMP_NUM_THREADS", "default (all cores)")),
         "extrapolation": "linear in N from the largest N timed (every sweep is O(K N))",
