@@ -291,6 +291,8 @@ struct mbar_ctx {
     const int64_t opt_staging = 0;  // (tiles are staged by LDS-DMA; the register-staged kernels of rounds 1-3 are gone)
     int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1, opt_direct_results = 1;
+    int64_t opt_small_balanced = 1, opt_newton_mfma = 0, opt_sci_pingpong = 1;
+
     // comm
     ncclComm_t comm = nullptr;
     mbar_loopback* loop = nullptr;  // in-process transport (tests): like comm, a collective on the compute stream
@@ -592,6 +594,7 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
         const int nb = (int)(rows / 16);
         const int64_t ntiles = (c->N + TS - 1) / TS;
         LaunchGeom g = lse_geometry(nb, nf, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c));
+        g.balanced = c->opt_small_balanced ? 1 : 0;
         const size_t rec = (size_t)nf * rows;
         int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * (rec + nf));
         if (rc) return rc;
@@ -1743,6 +1746,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     q.cgram = fused ? c->pm_vec + 2 * Kp : nullptr;
     q.light_ok = light ? 1 : 0;
     q.stamps = nullptr;
+    q.newton_mfma = c->opt_newton_mfma ? 1 : 0;
     if (std::getenv("MBAR_DEBUG_STAMPS")) {
         if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 64 * 8 * sizeof(long long)));
         HIPCHK(c, hipMemsetAsync(c->stamps, 0, 64 * 8 * sizeof(long long), c->stream));
@@ -2159,6 +2163,7 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->f_hist) (void)cache_free(c->f_hist);
     if (c->hstage) (void)cache_host_free(c->hstage);
     if (c->vec_tmp) (void)cache_free(c->vec_tmp);
+    if (c->stamps) (void)hipFree(c->stamps);
     if (c->sci_graph) (void)hipGraphExecDestroy(c->sci_graph);
     if (c->stream) {  // (idle: synchronised above) kept for the next context on this device
         std::lock_guard<std::mutex> lock(g_dev_mu);
@@ -2299,6 +2304,18 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "light_last") c->opt_light_last = value;
     else if (k == "direct_results") c->opt_direct_results = value;
     else if (k == "sci_merged") c->opt_sci_merged = value;
+    else if (k == "sci_pingpong") {
+        c->opt_sci_pingpong = value;
+        (void)drop_graphs(c);
+    }
+    else if (k == "newton_mfma") {
+        c->opt_newton_mfma = value;
+        (void)drop_graphs(c);
+    }
+    else if (k == "small_balanced") {
+        c->opt_small_balanced = value;
+        (void)drop_graphs(c);
+    }
     else if (k == "wide_pmode") c->opt_wide_pmode = value;
     else if (k == "quad_trim") {
         c->opt_quad_trim = value;
@@ -2861,7 +2878,13 @@ int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxite
     std::vector<double> f(f_inout, f_inout + K), psum;
     mbar_solve_result res;
     std::memset(&res, 0, sizeof(res));
-    c->ld0_valid = false;  // (the solver loops use the slot vectors for their own purposes)
+    // (the solver loops use the slot vectors for their own purposes -- and an evaluation inside them marks slot 0 valid again
+    // before the loop overwrites it: cleared on EVERY way out, error returns included)
+    struct Ld0Guard {
+        mbar_ctx* c;
+        ~Ld0Guard() { c->ld0_valid = false; }
+    } ld0_guard{c};
+    c->ld0_valid = false;
     double max_delta = std::numeric_limits<double>::quiet_NaN();
     int rc = refresh_poison(c);
     if (rc) return rc;
@@ -2931,6 +2954,10 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     const int first = c->sampled[0];
     mbar_solve_result res;
     std::memset(&res, 0, sizeof(res));
+    struct Ld0Guard {
+        mbar_ctx* c;
+        ~Ld0Guard() { c->ld0_valid = false; }
+    } ld0_guard{c};
     c->ld0_valid = false;
     {
         int prc = refresh_poison(c);
@@ -2956,7 +2983,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     HIPCHK(c, hipMemcpyAsync(d_f(c), hf.data(), Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_aden(c), ha.data(), std::max(rows, Kp) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<double> hdelta(batch);
+    std::vector<double> hdelta(256);
     bool done = false;
     double last_delta = std::numeric_limits<double>::quiet_NaN();
     // geometry and buffers of the fused path are fixed for the whole solve (nothing may allocate inside a capture)
@@ -2964,6 +2991,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     const int nbk = (int)(rows / 16);
     const int64_t ntiles = (c->N + TS - 1) / TS;
     LaunchGeom g = fast ? lse_geometry(nbk, 1, c->num_cu, ntiles, c->opt_grid, lse_variant_for(c)) : LaunchGeom();
+    g.balanced = c->opt_small_balanced ? 1 : 0;
     // Few states on one rank ("sci_merged", default): update and sweep of an iteration in ONE launch (k_sci_small) -- the update of
     // iteration i rides in the prologue of the sweep at f_i, so an iteration is one kernel instead of sweep + single-workgroup
     // update (config 2: ~9 us of a 62 us iteration).  Records / state double-buffered by the parity of the iteration, which the
@@ -2976,33 +3004,52 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
         rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 16) * (rows + 1));
         if (rc) return rc;
     }
-    if (merged) {  // iteration 0: the plain sweep at the start point leaves its records and f in the parity-0 buffers
+    // iteration 0 of the merged loop: the plain sweep at the start point leaves its records and f in the parity-0 buffers
+    auto prime_merged = [&]() -> int {
         HIPCHK(c, hipMemcpyAsync(c->scratch, hf.data(), rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
         ScopedTimer t(c, MBAR_TIMER_LSE);
         HIPCHK(c, launch_lse(c->stream, nbk, 1, true, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr, nullptr, nullptr, c->part,
                              c->part + (size_t)2 * g.blocks * rows));
+        return MBAR_OK;
+    };
+    if (merged) {
+        rc = prime_merged();
+        if (rc) return rc;
     }
     int64_t it = 0;  // iterations accepted so far
+    long long* sci_stamps = nullptr;
+    if (merged && std::getenv("MBAR_DEBUG_STAMPS")) {
+        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 64 * 8 * sizeof(long long)));
+        HIPCHK(c, hipMemsetAsync(c->stamps, 0, 64 * 8 * sizeof(long long), c->stream));
+        sci_stamps = c->stamps;
+    }
+    auto merged_args = [&](int64_t b) {
+        SciLoopArgs q;
+        q.Nk = d_Nk(c);
+        q.lnNk = d_lnNk(c);
+        q.K = (int)K;
+        q.first = first;
+        q.tol = tol;
+        q.state = c->scratch;
+        q.rec = c->part;
+        q.nrec = g.blocks;
+        q.f_hist = c->f_hist + (size_t)b * Kp;
+        q.delta_out = d_delta(c) + b;
+        q.parity = (int)((it + b + 1) & 1);
+        q.live = 0;
+        for (int64_t j = 0; j < rows / 2; ++j)
+            if ((2 * j < K && c->Nk[2 * j] > 0.0) || (2 * j + 1 < K && c->Nk[2 * j + 1] > 0.0)) q.live |= 1u << j;
+        q.balanced = g.balanced;
+        q.pingpong = c->opt_sci_pingpong ? 1 : 0;
+        q.stamps = sci_stamps;
+        return q;
+    };
     // one SCI iteration into history slot b: sweep -> level-1 reduction -> [all-reduce] -> update (which folds the
     // last reduction level in)
     auto enqueue_iteration = [&](int64_t b, bool timed) -> int {
         double* fh = c->f_hist + (size_t)b * Kp;
         if (merged) {
-            SciLoopArgs q;
-            q.Nk = d_Nk(c);
-            q.lnNk = d_lnNk(c);
-            q.K = (int)K;
-            q.first = first;
-            q.tol = tol;
-            q.state = c->scratch;
-            q.rec = c->part;
-            q.nrec = g.blocks;
-            q.f_hist = fh;
-            q.delta_out = d_delta(c) + b;
-            q.parity = (int)((it + b + 1) & 1);
-            q.live = 0;
-            for (int64_t j = 0; j < rows / 2; ++j)
-                if ((2 * j < K && c->Nk[2 * j] > 0.0) || (2 * j + 1 < K && c->Nk[2 * j + 1] > 0.0)) q.live |= 1u << j;
+            const SciLoopArgs q = merged_args(b);
             if (timed) {
                 ScopedTimer t(c, MBAR_TIMER_LSE);
                 HIPCHK(c, launch_sci_small(c->stream, nbk, g, c->u, c->ld, c->N, c->cw, q));
@@ -3054,7 +3101,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     // Launch-bound regime (a K=32, N=1e6 sweep is ~60 us): capture a whole batch into a hipGraph and replay it.
     const bool use_graph = fast && c->opt_graph && c->nranks <= 1 && !c->comm && maxiter >= batch;  // (no per-kernel events inside a graph)
     if (use_graph) {
-        const int64_t sig = ((int64_t)g.blocks << 32) ^ ((int64_t)g.variant << 24) ^ (merged ? (1 << 16) : 0) ^ first;
+        const int64_t sig = ((int64_t)g.blocks << 32) ^ ((int64_t)g.variant << 24) ^ (merged ? (1 << 16) : 0) ^ (g.balanced ? (1 << 17) : 0) ^ (c->opt_sci_pingpong ? (1 << 18) : 0) ^ first;
         if (!c->sci_graph || c->sci_graph_batch != batch || c->sci_graph_sig != sig || c->sci_graph_tol != tol) {
             if (c->sci_graph) HIPCHK(c, hipGraphExecDestroy(c->sci_graph));
             c->sci_graph = nullptr;
@@ -3079,8 +3126,15 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
             c->sci_graph_tol = tol;
         }
     }
+    // Batches between two looks at the host.  Nothing to look at without the convergence test: the batches go out back to back and
+    // only the last one is read.  With it: the first batch has the standard size (a captured graph), every later one the number of
+    // iterations the relative change -- it decays geometrically -- still needs to reach `tol`, from its last two values (rows
+    // and changes of up to 256 iterations are kept, the first one below `tol` is the answer whatever was enqueued behind it).
+    // A look costs ~70 us of idle device (config 2: 92 iterations in two looks instead of six).
+    std::vector<double> hrows;
+    int64_t next_nb = batch;
     while (it < maxiter && !done) {
-        const int64_t nb = std::min(batch, maxiter - it);
+        const int64_t nb = std::min(next_nb, maxiter - it);
         if (use_graph && nb == batch) {
             HIPCHK(c, hipGraphLaunch(c->sci_graph, c->stream));
         } else {
@@ -3089,7 +3143,13 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
                 if (rc) return rc;
             }
         }
+        if (!check_convergence && it + nb < maxiter) {
+            it += nb;
+            continue;
+        }
+        hrows.resize((size_t)nb * Kp);
         HIPCHK(c, hipMemcpyAsync(hdelta.data(), d_delta(c), nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hrows.data(), c->f_hist, (size_t)nb * Kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         rc = sync_stream(c);
         if (rc) return rc;
         int64_t stop = nb;  // index within the batch of the accepted iterate
@@ -3100,18 +3160,39 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
                     done = true;
                     break;
                 }
-            double ctl[2] = {(double)stop, done ? 1.0 : 0.0};
-            rc = agree_with_rank0(c, ctl, 2);
+            int64_t want = batch;
+            if (!done && nb >= 2) {
+                const double d1 = hdelta[nb - 1], d0 = hdelta[nb - 2];
+                if (d1 > tol && d0 > d1 && d1 > 0.0) {
+                    const double left = std::log(d1 / tol) / std::log(d0 / d1);
+                    if (left == left) want = (int64_t)std::min(254.0, std::ceil(left)) + 2;
+                }
+            }
+            want = std::max<int64_t>(2, std::min<int64_t>(256, want + (want & 1)));  // (even: records and state alternate by parity)
+            double ctl[3] = {(double)stop, done ? 1.0 : 0.0, (double)want};
+            rc = agree_with_rank0(c, ctl, 3);
             if (rc) return rc;
             stop = (int64_t)(ctl[0] + 0.5);
             done = ctl[1] > 0.5;
+            next_nb = (int64_t)(ctl[2] + 0.5);
             if (done) res.success = 1;
         }
         it += stop;
         last_delta = hdelta[stop - 1];
-        HIPCHK(c, hipMemcpyAsync(hf.data(), c->f_hist + (size_t)(stop - 1) * Kp, Kp * sizeof(double),
-                                 hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::copy(hrows.begin() + (size_t)(stop - 1) * Kp, hrows.begin() + (size_t)stop * Kp, hf.begin());
+    }
+    if (sci_stamps) {  // (the last launch's stamps: 10 ns units relative to the workgroup's first stamp)
+        long long st[24];
+        HIPCHK(c, hipMemcpy(st, c->stamps, sizeof(st), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[mbar] k_sci_small workgroup 0, end of the tile loop per wave (us):");
+        for (int w = 0; w < 8; ++w) std::fprintf(stderr, " %.2f", (st[16 + w] - st[0]) * 0.01);
+        std::fprintf(stderr, "\n");
+        for (int w = 0; w < 2; ++w) {
+            const long long* p = st + 8 * w;
+            std::fprintf(stderr, "[mbar] k_sci_small workgroup %s (us since its start; start offset to workgroup 0: %.2f): tables %.2f, update done %.2f, first tile in %.2f, "
+                         "sweep done %.2f, barrier %.2f, record written %.2f\n", w ? "mid" : "0", (p[0] - st[0]) * 0.01, (p[1] - p[0]) * 0.01, (p[2] - p[0]) * 0.01,
+                         (p[3] - p[0]) * 0.01, (p[4] - p[0]) * 0.01, (p[5] - p[0]) * 0.01, (p[6] - p[0]) * 0.01);
+        }
     }
     for (int64_t k = 0; k < K; ++k)
         if (c->Nk[k] > 0.0) f_inout[k] = hf[k];

@@ -90,6 +90,7 @@ constexpr double EXP2_CLAMP = -1100.0 * EXP2_S;
 constexpr int EXP2_TABLE_BYTES = (1 << EXP2_BITS) * 8;
 constexpr int LOG_TABLE_BYTES = 256 * 8;
 constexpr int EXP_TABLE_BYTES = EXP2_TABLE_BYTES + LOG_TABLE_BYTES;  // LDS reserved for both look-up tables
+constexpr int EXP_TABLE_DMA_PER_WAVE = (EXP_TABLE_BYTES / 1024 + 7) / 8;  // requests per wave of exp_table_init_dma in an 8-wave workgroup
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 // Every thread block copies the table to LDS offset 0 (its dynamic LDS starts there: the kernels have no static
 // __shared__), so a look-up address is just the masked integer -- no base add.  Callers barrier afterwards.
@@ -98,6 +99,25 @@ __device__ __forceinline__ void exp_table_init(char* smem) {
     for (int i = threadIdx.x; i < (1 << EXP2_BITS); i += blockDim.x) reinterpret_cast<double*>(smem)[i] = EXP2_TABLE[i];
     for (int i = threadIdx.x; i < 256; i += blockDim.x)
         reinterpret_cast<double*>(smem + EXP2_TABLE_BYTES)[i] = LOG_TABLE[i];
+}
+// The same copy as LDS-DMA requests (1 KB per instruction, 18 in all, shared out over the waves): asynchronous, nothing passes
+// through registers, and -- issued BEFORE a kernel's first tile request -- it does not queue behind it.  The caller waits for
+// its own requests (s_waitcnt vmcnt(0)) and passes a workgroup barrier before the first look-up.
+__device__ __forceinline__ void exp_table_init_dma(char* smem) {
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
+    constexpr int NCH = EXP_TABLE_BYTES / 1024, NCH_EXP = EXP2_TABLE_BYTES / 1024;
+    // (every wave issues the same number of requests, EXP_TABLE_DMA_PER_WAVE for eight waves -- a chunk requested twice lands
+    // twice with the same bytes -- so that a caller can count them in an s_waitcnt)
+    const int per_wave = (NCH + nwv - 1) / nwv;
+    for (int i = 0; i < per_wave; ++i) {
+        const int c = (wave + i * nwv) % NCH;
+        const char* src = c < NCH_EXP ? reinterpret_cast<const char*>(EXP2_TABLE) + c * 1024
+                                      : reinterpret_cast<const char*>(LOG_TABLE) + (c - NCH_EXP) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(smem + c * 1024), 16, 0, 0);
+    }
 }
 __device__ __forceinline__ double exp2_table_at(int si) {
     return *(lds_cdouble*)(uintptr_t)(uint32_t)((si << 3) & (EXP2_TABLE_BYTES - 8));
@@ -485,6 +505,26 @@ __device__ __forceinline__ void stage_vec16(const double* __restrict__ v, int64_
 // (before any DMA is in flight) instead of a conservative vmcnt(0) at the first use inside the loop.
 __device__ __forceinline__ void settle(double& x) { asm volatile("" : "+v"(x)); }
 
+// A global load the compiler does not know to be one: issued AHEAD of LDS-DMA requests whose number depends on control flow,
+// its result would otherwise be waited for with a conservative s_waitcnt vmcnt(0) -- i.e. for the tile behind it as well.  The
+// caller waits by hand (wait_vm_for: vmcnt(N) with N <= the requests issued after these loads) before the first use.  Only
+// safe for loads issued before every compiler-tracked memory operation of the kernel (the counter retires in order).
+__device__ __forceinline__ double load_untracked(const double* p) {
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_for(double& a, double& b, double& c, double& d, double& e, double (&r)[16]) {
+    asm volatile("s_waitcnt vmcnt(%21)"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
+                   "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+                 : "n"(N)
+                 : "memory");
+}
+// Workgroup barrier for LDS traffic only: __syncthreads() carries a release fence that also waits for every outstanding global
+// request (vmcnt(0)) -- i.e. for LDS-DMA tiles in flight that the code between two such barriers has no business waiting for.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -75,6 +75,7 @@ struct LaunchGeom {
     int variant;       // kernel variant chosen (see lse_geometry / gram_geometry)
     size_t lds_bytes;
     int live_blocks = 0;  // k_gram_quad / k_fused_quad: blocks of 16 states that hold real states (0: all of the panel's)
+    int balanced = 0;     // few-state kernels: the waves' tile streams start workgroup-major (see lse_small_first_tile)
 };
 
 // ---- evaluation pass -------------------------------------------------------------------------
@@ -176,6 +177,9 @@ struct SciLoopArgs {
     double* delta_out;
     int parity;
     uint32_t live;    // bit j: rows 2j, 2j+1 hold a state with samples (the others are not streamed from HBM)
+    int balanced;     // tile streams start workgroup-major (LaunchGeom::balanced; the previous sweep's records do not care)
+    int pingpong;     // odd iterations sweep the tiles in descending order (cache re-use between consecutive sweeps)
+    long long* stamps;  // MBAR_DEBUG_STAMPS: [2][8] phase stamps (100 MHz) of thread 0 of workgroups 0 and gridDim.x / 2, or nullptr
 };
 hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* cw,
                             const SciLoopArgs& q);
@@ -227,6 +231,8 @@ struct AdaptArgs {
     // fused loop: the last iteration may run without its Gram matrix (CTL_LIGHT); 0 = never (small problems: an idle launch
     // per iteration would cost more than the one lighter sweep saves)
     int light_ok;
+    // 64 .. 127 unknowns: the Gauss-Jordan eliminations on the fp64 matrix cores, four pivots per step (newton_body_mfma)
+    int newton_mfma;
     // MBAR_DEBUG_STAMPS=1: shader-clock stamps of the phases of k_select_newton (thread 0; [8] per launch slot, 64 slots)
     long long* stamps;
 };

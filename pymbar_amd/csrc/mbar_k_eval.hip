@@ -160,12 +160,64 @@ __device__ __forceinline__ void lse_small_stage(const double* __restrict__ u, in
         stage_piece<true>(u + (int64_t)(2 * j) * ld + (((live >> j) & 1u) ? tile * TSS : 0), voff, buf + j * 1024, lane);
     if (lane < 32) stage_piece<true>(cw + tile * TSS, (uint32_t)(lane * 16), buf + ROWS * TSS * 8, lane);
 }
+__device__ __forceinline__ int64_t lse_small_first_tile(int balanced /*0 or 1*/, int wave, int nwv) {
+    // (wave-uniform: it enters the scalar base of every DMA address)
+    const int mb = nwv - balanced * (nwv - 1), mw = 1 + balanced * ((int)gridDim.x - 1);
+    int first = __builtin_amdgcn_readfirstlane((int)blockIdx.x * mb + wave * mw);
+    asm volatile("" : "+s"(first));
+    return (int64_t)first;
+}
+// One partial record per WORKGROUP from the per-lane sums of its eight waves, in a FIXED order: every wave writes its registers
+// into its own (now idle) tile buffer, [state][lane]; after one barrier thread (k, s) = (tid / 16, tid % 16) adds the 32 values of
+// state k in lanes 32 (s & 1) .. + 31 of wave s / 2 (the start rotated by the thread index: every bank busy, the order still a
+// function of the thread alone), and a 16-lane DPP reduction finishes the state.  (Until round 5 every wave reduced each of its
+// 33 registers by a six-step ds_bpermute butterfly, one after the other: 9.5 us of a 57 us launch at config 2.)
+template <int ROWS>
+__device__ __forceinline__ void lse_small_fold(char* smem, const double (&acc)[ROWS], double objl, double* __restrict__ psum_part,
+                                               double* __restrict__ obj_part, long long* st) {
+    constexpr int TILE_BYTES = ROWS * TSS * 8 + TSS * 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* mine = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES + wave * TILE_BYTES);
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) mine[k * 64 + lane] = acc[k];
+    if (obj_part) mine[ROWS * 64 + lane] = objl;
+    __syncthreads();
+    if (st) st[5] = wall_clock64();
+    {
+        const int k = tid >> 4, sg = tid & 15;
+        if (k < ROWS) {  // (ROWS = 16: the upper half of the workgroup idles)
+            const double* src = reinterpret_cast<const double*>(smem + EXP_TABLE_BYTES + (sg >> 1) * TILE_BYTES) + k * 64 + (sg & 1) * 32;
+            double v[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = src[(j + tid) & 31];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; j += 4) {
+                s0 += v[j];
+                s1 += v[j + 1];
+                s2 += v[j + 2];
+                s3 += v[j + 3];
+            }
+            const double tot = row16_sum((s0 + s1) + (s2 + s3));
+            if (sg == 0) psum_part[(int64_t)blockIdx.x * ROWS + k] = tot;
+        }
+    }
+    if (obj_part && tid < 64) {  // the objective terms: 512 values, eight per lane of wave 0
+        double o = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) o += reinterpret_cast<const double*>(smem + EXP_TABLE_BYTES + w * TILE_BYTES)[ROWS * 64 + lane];
+        o = wave_sum(o);
+        if (lane == 0) obj_part[blockIdx.x] = o;
+    }
+    if (st) st[6] = wall_clock64();
+}
 // PRESTAGED: the caller has already requested the wave's first tile (with the same `live_in` mask) before its own prologue.
 template <int NB, bool PRESTAGED = false>
 __device__ __forceinline__ void lse_small_body(char* smem, const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                                                const double* aden, const double* __restrict__ cw, double* __restrict__ logden0,
                                                const double* __restrict__ dn, double* __restrict__ psum_part,
-                                               double* __restrict__ obj_part, uint32_t live_in = 0) {
+                                               double* __restrict__ obj_part, uint32_t live_in = 0, int balanced = 0, int rev = 0, long long* st = nullptr, long long* st_waves = nullptr) {
     constexpr int ROWS = NB * 16;
     constexpr int U_BYTES = ROWS * TSS * 8;
     constexpr int TILE_BYTES = U_BYTES + TSS * 8;  // + the 64 sample weights of the tile
@@ -173,7 +225,10 @@ __device__ __forceinline__ void lse_small_body(char* smem, const double* __restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
     char* buf = smem + EXP_TABLE_BYTES + wave * TILE_BYTES;
-    const int64_t gw = (int64_t)blockIdx.x * nwv + wave;
+    // first tile of the wave's stream (stride W): wave-major, or -- `balanced` -- workgroup-major, which spreads the streams that are
+    // one tile longer evenly over the compute units (config 2: 15 625 tiles over 2048 waves; wave-major gives 161 units 64 tiles
+    // and 95 units 56, workgroup-major 61 or 62 each)
+    const int64_t gw = lse_small_first_tile(balanced, wave, nwv);
     const int64_t W = (int64_t)gridDim.x * nwv;
     const bool has_store = logden0 != nullptr;
 
@@ -192,7 +247,11 @@ __device__ __forceinline__ void lse_small_body(char* smem, const double* __restr
 #pragma unroll
         for (int j = 0; j < ROWS / 2; ++j) live |= (__ballot(a[2 * j] != -INFINITY || a[2 * j + 1] != -INFINITY) ? 1u : 0u) << j;
     }
-    auto stage = [&](int64_t tile) { lse_small_stage<NB>(u, ld, cw, tile, live, buf, lane); };
+    // rev (0 / 1): the stream positions map to the tiles in DESCENDING order -- a loop that sweeps the same matrix again and again
+    // (the self-consistent iteration) alternates the direction, so that a sweep begins with what the previous one left in the
+    // caches (L2, Infinity Cache) instead of evicting it just before it is needed; plain scalar arithmetic, see lse_small_first_tile
+    const int64_t rsgn = 1 - 2 * rev, roff = rev * (ntiles - 1);
+    auto stage = [&](int64_t pos) { lse_small_stage<NB>(u, ld, cw, roff + rsgn * pos, live, buf, lane); };
 
     int64_t t = gw;
     if constexpr (!PRESTAGED) {
@@ -203,6 +262,12 @@ __device__ __forceinline__ void lse_small_body(char* smem, const double* __restr
             wait_vm<1>();  // [this tile][logden store of the previous one]: vmcnt counts stores too
         else
             wait_vm<0>();
+        if (st && t == gw) st[3] = wall_clock64();
+#ifdef MBAR_SMALL_SETPRIO
+        // the two waves of a SIMD take turns at the higher issue priority (otherwise the older one always wins a tie: waves 0-3
+        // of a workgroup ran 16 % ahead of waves 4-7)
+        if (((t - gw) / W) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         double x[ROWS];
         const double w = *reinterpret_cast<const double*>(buf + U_BYTES + lane * 8);
 #pragma unroll
@@ -231,42 +296,39 @@ __device__ __forceinline__ void lse_small_body(char* smem, const double* __restr
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) acc[k] = fma(x[k], r, acc[k]);
         const double ldv = m + log_pos(ssum);
-        const int64_t n = t * TSS + lane;
+        const int64_t n = (roff + rsgn * t) * TSS + lane;
         if (n < N) {
             if (logden0) logden0[n] = ldv;
             objl = fma(w, dn ? (ldv - dn[n]) : ldv, objl);
         }
     }
-    // one partial record per WORKGROUP (the 8 waves are folded through LDS in a fixed order): few enough records for
-    // the SCI update kernel to sum directly, which saves the level-1 reduction launch of the device-resident loop
-    __syncthreads();  // every wave is done with its tile buffer: re-use the LDS behind the tables
-    double* fold = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);
-#pragma unroll
-    for (int k = 0; k < ROWS; ++k) {
-        const double v = wave_sum(acc[k]);
-        if (lane == 0) fold[wave * (ROWS + 1) + k] = v;
-    }
-    const double o = wave_sum(objl);
-    if (lane == 0) fold[wave * (ROWS + 1) + ROWS] = o;
-    __syncthreads();
-    if (threadIdx.x <= ROWS) {
-        double tot = 0.0;
-        for (int w = 0; w < nwv; ++w) tot += fold[w * (ROWS + 1) + threadIdx.x];
-        if (threadIdx.x < ROWS)
-            psum_part[(int64_t)blockIdx.x * ROWS + threadIdx.x] = tot;
-        else if (obj_part)
-            obj_part[blockIdx.x] = tot;
-    }
+    if (st) st[4] = wall_clock64();
+    if (st_waves && lane == 0) st_waves[wave] = wall_clock64();
+    lse_small_fold<ROWS>(smem, acc, objl, psum_part, obj_part, st);
 }
-template <int NB>
+template <int NB, int BAL>
 __global__ void __launch_bounds__(512, 2)
 k_lse_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden0,
             const double* __restrict__ dn, double* __restrict__ psum_part, double* __restrict__ obj_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    exp_table_init(smem);
+    constexpr int ROWS = NB * 16;
+    constexpr int TILE_BYTES = ROWS * TSS * 8 + TSS * 8;
+    // which pairs of rows matter (see lse_small_body), then the wave's first tile is requested before the tables are copied
+    uint32_t live = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS / 2; ++j) live |= ((aden[2 * j] != -INFINITY || aden[2 * j + 1] != -INFINITY) ? 1u : 0u) << j;
+    live = __builtin_amdgcn_readfirstlane(live);
+    {
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int64_t gw = lse_small_first_tile(BAL, wave, blockDim.x >> 6);
+        exp_table_init_dma(smem);  // (ahead of the tile in the memory queue)
+        if (gw < ntiles) lse_small_stage<NB>(u, ld, cw, gw, live, smem + EXP_TABLE_BYTES + wave * TILE_BYTES, lane);
+    }
+    wait_vm<0>();
     __syncthreads();
-    lse_small_body<NB>(smem, u, ld, N, ntiles, aden, cw, logden0, dn, psum_part, obj_part);
+    lse_small_body<NB, true>(smem, u, ld, N, ntiles, aden, cw, logden0, dn, psum_part, obj_part, live, BAL);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,51 +348,83 @@ k_sci_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     constexpr int ROWS = NB * 16;
     constexpr int G = 512 / ROWS;  // groups of threads that share the record sum of one state
     constexpr int TILE_BYTES = ROWS * TSS * 8 + TSS * 8;
-    // the wave's first tile is requested BEFORE anything else: it lands while the tables are copied and the update is computed
-    // (which rows carry samples does not change during a solve: the host passes the mask)
+    // (debug, MBAR_DEBUG_STAMPS: 100 MHz stamps of thread 0 of workgroups 0 and gridDim.x / 2, eight per workgroup)
+    long long* st = (q.stamps && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) ? q.stamps + (blockIdx.x == 0 ? 0 : 8) : nullptr;
+    if (st) st[0] = wall_clock64();
+    // Order of the requests = order of arrival: the previous sweep's records first (a few KB: they gate the update), then the
+    // look-up tables (LDS-DMA), then the wave's first tile -- which lands while the update is computed.  (Until round 5 the tile
+    // went first: the tables queued behind it for 5.7 us, the record loads behind the tables for another 4.)
+    const int tid = threadIdx.x;
+    const int par = q.parity;
+    const double* rprev = q.rec + (int64_t)(par ^ 1) * q.nrec * ROWS;
+    const double* fprev = q.state + (int64_t)(par ^ 1) * ROWS;
+    constexpr int RMAX = 16;
+    const bool direct = q.nrec <= RMAX * G;  // (the usual case: at most 256 records)
+    double rv[RMAX];
+    {
+        const int k = tid % ROWS, g = tid / ROWS;
+#pragma unroll
+        for (int j = 0; j < RMAX; ++j) {
+            const int64_t p = g + (int64_t)j * G;  // (unconditional loads of a clamped index: a predicated load becomes a branch)
+            rv[j] = load_untracked(rprev + (p < q.nrec ? p : q.nrec - 1) * ROWS + k);
+        }
+    }
+    // (everything else the update reads from memory, also ahead of the requests it must not wait for)
+    const int kq = tid < ROWS ? tid : 0;
+    double fo_r = load_untracked(fprev + kq), nk_r = load_untracked(q.Nk + kq), ln_r = load_untracked(q.lnNk + kq);
+    double f1_r = load_untracked(fprev + q.first), nk1_r = load_untracked(q.Nk + q.first);
+    exp_table_init_dma(smem);
     {
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-        if (gw < ntiles) lse_small_stage<NB>(u, ld, cw, gw, q.live, smem + EXP_TABLE_BYTES + wave * TILE_BYTES, lane);
+        const int64_t gw = lse_small_first_tile(q.balanced != 0 ? 1 : 0, wave, blockDim.x >> 6);
+        const int rev = q.pingpong ? (q.parity & 1) : 0;
+        // (the loads above are waited for by hand: not for the table and tile requests issued behind them)
+        if (gw < ntiles) {
+            lse_small_stage<NB>(u, ld, cw, rev * (ntiles - 1) + (1 - 2 * rev) * gw, q.live, smem + EXP_TABLE_BYTES + wave * TILE_BYTES, lane);
+            wait_vm_for<EXP_TABLE_DMA_PER_WAVE + ROWS / 2 + 1>(fo_r, nk_r, ln_r, f1_r, nk1_r, rv);
+        } else {
+            wait_vm_for<EXP_TABLE_DMA_PER_WAVE>(fo_r, nk_r, ln_r, f1_r, nk1_r, rv);
+        }
     }
-    exp_table_init(smem);
+    if (st) st[1] = wall_clock64();
     double* scr = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES + 8 * TILE_BYTES);  // (behind the eight waves' tile buffers)
     double* ps = scr + 512;        // [ROWS] reduced per-state sums
     double* a_s = ps + ROWS;       // [ROWS] a' = f' + ln N (-inf: no samples / padding)
     double* fn_s = a_s + ROWS;     // [ROWS] f'
     double* red = fn_s + ROWS;     // [2]: gauge shift, max relative change
-    const int tid = threadIdx.x;
-    const int par = q.parity;
-    const double* rprev = q.rec + (int64_t)(par ^ 1) * q.nrec * ROWS;
-    const double* fprev = q.state + (int64_t)(par ^ 1) * ROWS;
     {
         const int k = tid % ROWS, g = tid / ROWS;
         double sm = 0.0;
+        if (direct) {
+#pragma unroll
+            for (int j = 0; j < RMAX; ++j) sm += (g + (int64_t)j * G < q.nrec) ? rv[j] : 0.0;  // (the order of the loop below; zeros past the end change nothing)
+        } else {
 #pragma unroll 8  // (same order in every workgroup; eight record loads in flight together)
-        for (int64_t p = g; p < q.nrec; p += G) sm += rprev[p * ROWS + k];
+            for (int64_t p = g; p < q.nrec; p += G) sm += rprev[p * ROWS + k];
+        }
         scr[g * ROWS + k] = sm;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < ROWS) {
         double tot = 0.0;
         for (int g = 0; g < G; ++g) tot += scr[g * ROWS + tid];
         ps[tid] = tot;
     }
-    __syncthreads();
-    if (tid == 0) red[0] = fprev[q.first] - log(ps[q.first] / q.Nk[q.first]);
-    __syncthreads();
+    lds_barrier();
+    if (tid == 0) red[0] = f1_r - log(ps[q.first] / nk1_r);
+    lds_barrier();
     if (tid < 64) {  // one wave: states tid (and tid + 64 would not exist: ROWS <= 32)
         const double small = q.tol < 1e-8 ? q.tol : 1e-8;
         double d = 0.0;
         if (tid < ROWS) {
             const int k = tid;
-            const bool sampled = k < q.K && q.Nk[k] > 0.0;
-            const double fo = fprev[k];
+            const bool sampled = k < q.K && nk_r > 0.0;
+            const double fo = fo_r;
             double fnew = fo, an = -INFINITY;
             if (sampled) {
-                fnew = fo - log(ps[k] / q.Nk[k]) - red[0];
-                an = fnew + q.lnNk[k];
+                fnew = fo - log(ps[k] / nk_r) - red[0];
+                an = fnew + ln_r;
                 if (k != q.first) {
                     const double div = fabs(fnew) < small ? 1.0 : fabs(fnew);
                     d = fabs(fnew - fo) / div;
@@ -347,7 +441,7 @@ k_sci_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         }
         if (tid == 0) red[1] = d;
     }
-    __syncthreads();
+    lds_barrier();
     if (blockIdx.x == 0 && tid < ROWS) {
         q.state[(int64_t)par * ROWS + tid] = fn_s[tid];
         q.f_hist[tid] = tid < q.K ? fn_s[tid] : 0.0;
@@ -358,8 +452,11 @@ k_sci_small(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
     double a_loc[ROWS];
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) a_loc[k] = a_s[k];
-    __syncthreads();
-    lse_small_body<NB, true>(smem, u, ld, N, ntiles, a_loc, cw, nullptr, nullptr, rec, nullptr, q.live);
+    wait_vm<0>();  // this wave's share of the tables (and its first tile) has landed ...
+    __syncthreads();  // ... and so has everybody else's
+    if (st) st[2] = wall_clock64();
+    lse_small_body<NB, true>(smem, u, ld, N, ntiles, a_loc, cw, nullptr, nullptr, rec, nullptr, q.live, q.balanced != 0 ? 1 : 0, q.pingpong ? (q.parity & 1) : 0, st,
+                             (q.stamps && blockIdx.x == 0) ? q.stamps + 16 : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -805,7 +902,7 @@ template <int NB>
 static hipError_t launch_lse_small_t(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                                      const double* aden, const double* cw, double* l0, const double* dn,
                                      double* psum_part, double* obj_part) {
-    auto kern = k_lse_small<NB>;
+    auto kern = g.balanced ? k_lse_small<NB, 1> : k_lse_small<NB, 0>;
     if (g.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);

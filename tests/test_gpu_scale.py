@@ -95,6 +95,16 @@ def test_config2_full_size_matches_the_reference(golden):
         f_sci, r_sci = dm.solve_sci(np.zeros(K), tol=1e-12)
         assert r_sci["success"] and r_sci["iterations"] == int(g["sci_iters"])
         _assert_delta_f(f_sci, g["f_sci"], "pure SCI")
+        # the loop variants: tile streams wave-major / workgroup-major, every sweep ascending / odd iterations descending
+        # (cache re-use between consecutive sweeps): the same sums regrouped (round-off only), the same 92 iterations
+        for balanced, pingpong in ((0, 0), (1, 1), (0, 1)):
+            dm.set_option("small_balanced", balanced)
+            dm.set_option("sci_pingpong", pingpong)
+            fv, rv = dm.solve_sci(np.zeros(K), tol=1e-12)
+            assert rv["success"] and rv["iterations"] == int(g["sci_iters"]), (balanced, pingpong, rv)
+            _assert_delta_f(fv, g["f_sci"], f"pure SCI, balanced={balanced}, pingpong={pingpong}")
+        dm.set_option("small_balanced", 1)
+        dm.set_option("sci_pingpong", 1)
         f, res = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
         _assert_counts(res, g)
         _assert_delta_f(f, g["f_adaptive"], "adaptive")

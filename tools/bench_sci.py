@@ -20,6 +20,12 @@ for K, N in shapes:
         dm.set_Nk(N_k)
         dm.set_option("small_k_kernel", int(os.environ.get("SMALL_K", "1")))  # 0: the 16-lanes-per-sample kernel for K <= 32
         dm.set_option("sci_merged", int(os.environ.get("SCI_MERGED", "1")))  # 0: sweep + separate update kernel per iteration
+        if "SMALL_BALANCED" in os.environ:
+            dm.set_option("small_balanced", int(os.environ["SMALL_BALANCED"]))  # 0: wave-major tile streams
+        if "SCI_PINGPONG" in os.environ:
+            dm.set_option("sci_pingpong", int(os.environ["SCI_PINGPONG"]))  # 1: odd iterations sweep the tiles in descending order
+        if "SCI_BATCH" in os.environ:
+            dm.set_option("sci_batch", int(os.environ["SCI_BATCH"]))
         f0 = np.zeros(K)
         for timing in (1, 0):
             dm.set_option("timing", timing)
