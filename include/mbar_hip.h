@@ -69,14 +69,16 @@ void mbar_ctx_destroy(mbar_ctx* ctx);
 int mbar_ctx_synchronize(mbar_ctx* ctx);
 /* Device and pinned-host blocks freed by contexts are kept for re-use (hipMalloc / hipFree cost more than a sweep at the
  * sizes pymbar is typically run at, and 0.3-0.7 s for the 6-8 GB augmented matrix of an expectation call at K=128, N=4e6);
- * bounded by MBAR_CACHE_MB (environment; default an eighth of the device's memory; 0 = off); an allocation that fails empties
+ * bounded by MBAR_CACHE_MB (environment; default an eighth of the device's memory; 0 = off) WHILE the process has a context,
+ * and cut back to MBAR_CACHE_IDLE_MB (default 1024) when its last context is destroyed; an allocation that fails empties
  * the cache and is tried again.  This returns every parked block to the driver. */
 int mbar_cache_trim(void);
 /* Environment variables read by the library (diagnostics; none changes a result):
- *   MBAR_CACHE_MB        bound of the block cache above
+ *   MBAR_CACHE_MB        bound of the block cache above (MBAR_CACHE_IDLE_MB: what it keeps once no context is left)
  *   MBAR_HOST_THREADS    team size of the host-side K x K factorisation (default: all cores, at most 16)
  *   MBAR_DEBUG_TIMING    per-iteration wall-clock split of the host-driven loops and of the host factorisation on stderr
- *   MBAR_DEBUG_STAMPS    shader-clock stamps of the phases of k_select_newton (selection / set-up / elimination / candidates) on stderr */
+ *   MBAR_DEBUG_STAMPS    in-kernel time stamps on stderr: the phases of k_select_newton (selection / set-up / elimination /
+ *                        candidates, shader clocks) and of k_sci_small (tables, update, first tile, sweep per wave, fold) */
 /* 128-bit content digest of a HOST buffer, computed at memory speed on `threads` host threads (0 = all cores).  The reference's
  * module-level functions are pure functions of the u_kn they are handed (mbar_solvers.py:260-292: every call reads the current
  * array); the Python binding keeps device copies of recently seen host matrices and re-uses one only when the digest of the
@@ -274,14 +276,14 @@ typedef struct mbar_solve_result {
 /* Adaptive NR/SCI on the states with N_k > 0 (others are left untouched).  f_inout[K].
  * history (may be NULL): rows of 4 doubles {choice(0 sci,1 nr), |g_sci|, |g_nr|, max_delta}.
  * check_convergence = 0 runs exactly maxiter iterations (benchmarking).
- * Up to 256 states the whole iteration is device-resident (129 .. 256: blocked Cholesky solve in device memory).
- * Up to 128 states the whole iteration is device-resident (K x K Newton solve in one workgroup, candidate construction,
- * ONE fused sweep for both candidates' gradients and the next Hessian's Gram matrix, choice and convergence test; the host
- * reads a few control words per batch of iterations, replayed from a hipGraph on a single rank, with ONE ncclAllReduce on
- * the stream per iteration across ranks; when the accepted candidate is not the one the sweep speculated on, the loop
- * pauses and the host enqueues that candidate's Gram sweep).  With the
- * host all-reduce transport, above 128 states, or when the device hands a solve back (Newton system not positive
- * definite, candidates > 300 kT apart, non-finite candidate) the same iteration runs host-driven. */
+ * Up to 256 states the whole iteration is device-resident: K x K Newton solve (up to 128 states in one workgroup's
+ * registers, 129 .. 256 by a blocked Cholesky factorisation in device memory), candidate construction, ONE fused sweep for
+ * both candidates' gradients and the next Hessian's Gram matrix, choice and convergence test; the host reads a few control
+ * words per batch of iterations (replayed from a hipGraph on a single rank), with ONE ncclAllReduce on the stream per
+ * iteration across ranks; when the accepted candidate is not the one the sweep speculated on, the loop pauses and the host
+ * enqueues that candidate's Gram sweep.  With the host all-reduce transport, above 256 states, or when the device hands a
+ * solve back (Newton system not positive definite, candidates > 250 kT from the anchor of the sweeps, non-finite candidate)
+ * the same iteration runs host-driven. */
 int mbar_solve_adaptive(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxiter,
                         int64_t min_sc_iter, double gamma, int check_convergence,
                         double* history, int64_t history_rows, mbar_solve_result* result);
@@ -291,7 +293,10 @@ int mbar_solve_adaptive(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxi
  * weights changed since). */
 int mbar_ctx_last_solve_psum(mbar_ctx* ctx, double* psum);
 /* Pure self-consistent iteration, device-resident (f update and convergence measure on the
- * device; the host looks every `check_every` iterations). */
+ * device).  K <= 32 on one rank: ONE launch per iteration (the update rides in the prologue of the sweep); odd iterations
+ * sweep the tiles in descending order ("sci_pingpong": a sweep starts with what the previous one left in the caches).  The
+ * host looks at the relative changes after the first batch ("sci_batch", 16) and then after as many iterations as their
+ * geometric decay predicts are left (at most 256); without the convergence test it does not look until the end. */
 int mbar_solve_sci(mbar_ctx* ctx, double* f_inout, double tol, int64_t maxiter, int check_convergence,
                    mbar_solve_result* result);
 

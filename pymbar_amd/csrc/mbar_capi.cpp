@@ -167,6 +167,26 @@ struct MemCache {
         live.erase(it);
         return d < 0 ? hipHostFree(q) : hipFree(q);
     }
+    // Parked device blocks beyond `keep_bytes` per device go back to the driver, largest first (called when the process's last
+    // context is destroyed: a drop-in that is done with its matrices must not sit on an eighth of a shared GPU)
+    void trim_to(size_t keep_bytes) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& dp : dev) {
+            Pool& p = dp.second;
+            while (p.cached > keep_bytes && !p.free_blocks.empty()) {
+                auto it = std::prev(p.free_blocks.end());
+                live.erase(it->second);
+                (void)hipSetDevice(dp.first);
+                (void)hipFree(it->second);
+                p.cached -= it->first;
+                p.free_blocks.erase(it);
+            }
+        }
+    }
+    size_t idle_limit() {
+        if (const char* e = std::getenv("MBAR_CACHE_IDLE_MB")) return (size_t)std::strtoull(e, nullptr, 10) << 20;
+        return (size_t)1024 << 20;
+    }
     void trim() {
         std::lock_guard<std::mutex> lock(mu);
         for (auto& dp : dev) {
@@ -187,6 +207,7 @@ struct MemCache {
     }
 };
 MemCache g_mem;
+std::atomic<int> g_live_contexts{0};
 struct DevInfo {
     int num_cu = 256;
     std::string arch;
@@ -261,6 +282,7 @@ struct mbar_ctx {
     size_t lognum_part_doubles = 0;
     double* f_hist = nullptr;       // SCI f history [batch][Kp]
     double* vec_tmp = nullptr;      // staging for one N_local-vector (mbar_ctx_row_sub)
+    bool vec_holds_logshift = false;  // vec_tmp holds log(A - shift) of mbar_ctx_vec_logshift (and not some other call's vector)
     // captured SCI batch (launch-bound loop: 3 small kernels per iteration replayed from a hipGraph)
     hipGraphExec_t sci_graph = nullptr;
     int64_t sci_graph_batch = 0, sci_graph_sig = 0;
@@ -288,10 +310,9 @@ struct mbar_ctx {
     bool P_valid = false;
     std::vector<double> P_a0;       // anchor of the resident probability matrix: aden at the build point (Kp entries)
     // options
-    const int64_t opt_staging = 0;  // (tiles are staged by LDS-DMA; the register-staged kernels of rounds 1-3 are gone)
     int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1, opt_direct_results = 1;
-    int64_t opt_small_balanced = 1, opt_newton_mfma = 0, opt_sci_pingpong = 1;
+    int64_t opt_small_balanced = 1, opt_sci_pingpong = 1;
 
     // comm
     ncclComm_t comm = nullptr;
@@ -568,9 +589,9 @@ int lse_variant_for(const mbar_ctx* c) {
     int v = 0;
     // bit 4: the context qualifies for the few-state kernel (one sample per lane, 64-sample tiles); lse_geometry
     // takes it for single-candidate sweeps of up to 32 states
-    if (c->opt_small && c->opt_staging == 0 && c->Kp <= 32 && c->ld % 64 == 0) v |= 0x10;
+    if (c->opt_small && c->Kp <= 32 && c->ld % 64 == 0) v |= 0x10;
     // bit 5: wide panels (129..256 states) may use the single-buffer kernel (four waves per CU instead of two)
-    if (c->opt_wide && c->opt_staging == 0 && c->Kp > 128) v |= 0x20;
+    if (c->opt_wide && c->Kp > 128) v |= 0x20;
     return v;
 }
 bool use_fast(const mbar_ctx* c) { return c->K <= MAX_FAST_K && !c->opt_force_generic; }
@@ -583,7 +604,7 @@ void build_aden(const mbar_ctx* c, const double* f, double* out, int64_t rows) {
 
 // 257 .. 1024 states: the one-read evaluation kernel whose eight waves split the rows of a tile
 bool split_sweep_ok(const mbar_ctx* c, int64_t rows) {
-    return !use_fast(c) && !c->opt_force_generic && c->opt_staging == 0 && !wide_pitch(c) && rows <= 1024 && rows % 64 == 0 && c->opt_wide;
+    return !use_fast(c) && !c->opt_force_generic && !wide_pitch(c) && rows <= 1024 && rows % 64 == 0 && c->opt_wide;
 }
 
 // Evaluation pass for nf vectors whose aden already sits in d_aden (device, row pitch `rows`).
@@ -604,7 +625,7 @@ int run_lse(mbar_ctx* c, int nf, int64_t rows, double* ld0, double* ld1, bool us
         double* obj_part = c->part + (size_t)g.nwaves * rec;
         {
             ScopedTimer t(c, MBAR_TIMER_LSE);
-            HIPCHK(c, launch_lse(c->stream, nb, nf, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), c->cw, ld0,
+            HIPCHK(c, launch_lse(c->stream, nb, nf, g, c->u, c->ld, c->N, d_aden(c), c->cw, ld0,
                                  ld1, dn, psum_part, obj_part));
         }
         {
@@ -721,7 +742,7 @@ GramPlan gram_plan(int64_t Kp, bool quad = false) {
 }
 
 // 129 .. 256 states: the one-read kernel (k_gram_quad) needs LDS-DMA staging
-bool use_quad(const mbar_ctx* c) { return c->opt_quad && c->opt_staging == 0 && use_fast(c) && c->Kp > 128 && c->Kp <= 256; }
+bool use_quad(const mbar_ctx* c) { return c->opt_quad && use_fast(c) && c->Kp > 128 && c->Kp <= 256; }
 GramPlan plan_for(const mbar_ctx* c) { return gram_plan(c->Kp, use_quad(c)); }
 // blocks of 16 states of the 192- / 256-row panel that hold real states: up to 160 / 224 states the one-read kernels leave the
 // last two blocks (padding rows only) out of the staging, the operand step and the matrix instructions
@@ -733,7 +754,6 @@ int quad_live_blocks(const mbar_ctx* c) { return c->opt_quad_trim ? (int)((c->K 
 // reduced Gram matrix (gram_operand_sums below).
 int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan) {
     const int64_t ntiles = (c->N + TS - 1) / TS;
-    const bool dma = c->opt_staging == 0;
     if (c->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent
         HIPCHK(c, launch_shift_logden(c->stream, logden, c->cw, 0.5, c->N, c->lden_eff));
         logden = c->lden_eff;
@@ -769,11 +789,11 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
             {
                 LoopCtl lo;
                 lo.unclamped = c->u_checked && !c->u_posinf;
-                HIPCHK(c, launch_gram_diag(c->stream, it.nbi, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, logden,
+                HIPCHK(c, launch_gram_diag(c->stream, it.nbi, g, c->u, c->ld, c->N, anum_dev + it.ri, logden,
                                            it.ri, gp, nullptr, lo));
             }
             else
-                HIPCHK(c, launch_gram_off(c->stream, it.nbj, dma, g, c->u, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
+                HIPCHK(c, launch_gram_off(c->stream, it.nbj, g, c->u, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
                                           logden, it.ri, it.rj, gp));
         }
         {
@@ -1460,7 +1480,6 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const int m = (int)c->sampled.size();
     const int nb = (int)(Kp / 16);
     const int64_t ntiles = (c->N + TS - 1) / TS;
-    const bool dma = c->opt_staging == 0;
     handed_back = false;
     c->ld0_valid = false;  // (the loop keeps reciprocals / rotating log-denominators in the slot vectors)
     psum.assign(K, 0.0);
@@ -1468,10 +1487,10 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     // a rank that could not get its buffers (or its resident probability matrix) must not wander off into a different
     // sequence of collectives than its peers.
     // P mode: the sweeps run on the resident probability matrix (one more K x N array); if it does not fit ON ANY RANK, or with
-    // register staging, every rank runs the classic sweeps on u.
+    // every rank runs the classic sweeps on u.
     const bool wide = Kp > 128;  // 129 .. 256 states: the one-read kernels whose four waves share a tile stream
     // (129 .. 256 states: P mode exists in its fused form only)
-    bool pmode = c->opt_pmode && dma && !c->P_failed && (!wide || (c->opt_wide_pmode && c->opt_fused));
+    bool pmode = c->opt_pmode && !c->P_failed && (!wide || (c->opt_wide_pmode && c->opt_fused));
     int arc = ensure_ad(c, history ? history_rows : 0);
     if (!arc && wide && !c->chol && cache_malloc((void**)&c->chol, NEWTON_CHOL_WORK * sizeof(double)) != hipSuccess)
         arc = fail(c, MBAR_ERR_HIP, "allocation of the Newton workspace failed");
@@ -1746,10 +1765,9 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     q.cgram = fused ? c->pm_vec + 2 * Kp : nullptr;
     q.light_ok = light ? 1 : 0;
     q.stamps = nullptr;
-    q.newton_mfma = c->opt_newton_mfma ? 1 : 0;
     if (std::getenv("MBAR_DEBUG_STAMPS")) {
-        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 64 * 8 * sizeof(long long)));
-        HIPCHK(c, hipMemsetAsync(c->stamps, 0, 64 * 8 * sizeof(long long), c->stream));
+        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 65 * 8 * sizeof(long long)));
+        HIPCHK(c, hipMemsetAsync(c->stamps, 0, 65 * 8 * sizeof(long long), c->stream));
         q.stamps = c->stamps;
     }
 
@@ -1779,7 +1797,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
             if (wide)
                 HIPCHK(c, launch_gram_quad(c->stream, nb, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, gram_part, lca));
             else
-                HIPCHK(c, launch_gram_diag(c->stream, nb, dma, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, gram_part,
+                HIPCHK(c, launch_gram_diag(c->stream, nb, gg, pmode ? c->P : c->u, c->ld, c->N, d_anum(c), lden, 0, gram_part,
                                            nullptr, lca));
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
             if (tp.a && tp.b) c->pending.push_back(tp);
@@ -1853,7 +1871,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
                 HIPCHK(c, launch_psweep(c->stream, nb, 2, gl, c->P, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr, psum_part,
                                         lcb));
             else
-                HIPCHK(c, launch_lse(c->stream, nb, 2, dma, gl, c->u, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr,
+                HIPCHK(c, launch_lse(c->stream, nb, 2, gl, c->u, c->ld, c->N, d_aden(c), c->cw, c->logden[0], nullptr,
                                      nullptr, psum_part, obj_part, lcb));
             if (tp.a && tp.b && !ext) (void)hipEventRecord(tp.b, c->stream);
             if (tp.a && tp.b) c->pending.push_back(tp);
@@ -1896,7 +1914,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     const bool use_graph = c->opt_graph && !stream_transport(c);
     auto prepare_graph = [&]() -> int {
         const int64_t sig = ((int64_t)gg.blocks << 40) ^ ((int64_t)gl.blocks << 20) ^ ((int64_t)m << 12) ^ (pmode ? 128 : 0) ^ (fused ? 256 : 0) ^
-                            (c->weighted ? 64 : 0) ^ (c->opt_staging ? 32 : 0) ^ (lc_slot.unclamped ? 512 : 0) ^ (merged ? 1024 : 0) ^ (light ? 2048 : 0) ^ (int64_t)nb;
+                            (c->weighted ? 64 : 0) ^ (lc_slot.unclamped ? 512 : 0) ^ (merged ? 1024 : 0) ^ (light ? 2048 : 0) ^ (int64_t)nb;
         if (!c->ad_graph || c->ad_graph_batch != batch || c->ad_graph_sig != sig) {
             // (the captured iterations are the steady-state ones: no Newton solve of their own when it rides with the selection)
             const bool need_saved = need_newton;
@@ -1996,7 +2014,7 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         if (it > res.iterations) max_delta = h[ad_off_state(c)];
     }
     if (q.stamps) {
-        std::vector<long long> st(64 * 8);
+        std::vector<long long> st(65 * 8);
         HIPCHK(c, hipMemcpy(st.data(), c->stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) {
             const long long* p = st.data() + 8 * i;
@@ -2066,6 +2084,7 @@ int mbar_ctx_create(mbar_ctx** out, int device, int64_t K, int64_t N_local) {
         return fail(nullptr, MBAR_ERR_NODEVICE, "no HIP device visible (libmbar_hip needs an MI355X / gfx950 GPU)");
     if (device < 0 || device >= n) return fail(nullptr, MBAR_ERR_ARG, "device index out of range");
     mbar_ctx* c = new mbar_ctx();
+    g_live_contexts.fetch_add(1);
     c->device = device;
     c->K = K;
     c->Kp = padded_K(K);
@@ -2174,6 +2193,7 @@ void mbar_ctx_destroy(mbar_ctx* c) {
             (void)hipStreamDestroy(c->stream);
     }
     delete c;
+    if (g_live_contexts.fetch_sub(1) == 1) g_mem.trim_to(g_mem.idle_limit());
 }
 
 int mbar_ctx_synchronize(mbar_ctx* c) {
@@ -2308,10 +2328,6 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
         c->opt_sci_pingpong = value;
         (void)drop_graphs(c);
     }
-    else if (k == "newton_mfma") {
-        c->opt_newton_mfma = value;
-        (void)drop_graphs(c);
-    }
     else if (k == "small_balanced") {
         c->opt_small_balanced = value;
         (void)drop_graphs(c);
@@ -2384,6 +2400,7 @@ int mbar_ctx_row_sub(mbar_ctx* c, int64_t row, const double* v_host) {
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->vec_tmp) HIPCHK(c, cache_malloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
     double* tmp = c->vec_tmp;
+    if (v_host) c->vec_holds_logshift = false;
     if (v_host)  // NULL: subtract the vector of the previous call again (one observable at many states)
         HIPCHK(c, hipMemcpyAsync(tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_row_sub(c->stream, c->u + row * c->ld, tmp, c->N));
@@ -2403,6 +2420,7 @@ int mbar_ctx_rows_sub(mbar_ctx* c, int64_t dst_row0, int64_t src_row0, int64_t n
     if (nrows == 0) return MBAR_OK;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->vec_tmp) HIPCHK(c, cache_malloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
+    if (v_host) c->vec_holds_logshift = false;
     if (v_host)  // NULL: the vector of the previous call again (one observable at many states)
         HIPCHK(c, hipMemcpyAsync(c->vec_tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_rows_sub(c->stream, c->u + dst_row0 * c->ld, c->u + src_row0 * c->ld, c->ld, nrows, c->vec_tmp, c->N));
@@ -2454,7 +2472,10 @@ int mbar_ctx_vec_logshift(mbar_ctx* c, const double* A_host, double* shift_out) 
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->vec_tmp) HIPCHK(c, cache_malloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
     HIPCHK(c, hipMemcpyAsync(c->vec_tmp, A_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    return logshift_rows(c, c->vec_tmp, 1, shift_out);
+    c->vec_holds_logshift = false;
+    const int lrc = logshift_rows(c, c->vec_tmp, 1, shift_out);
+    c->vec_holds_logshift = lrc == MBAR_OK;
+    return lrc;
 }
 
 int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const double* v_host, const int32_t* label_host) {
@@ -2465,6 +2486,7 @@ int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const do
     if (!c->vec_tmp) HIPCHK(c, cache_malloc((void**)&c->vec_tmp, (size_t)c->ld * sizeof(double)));
     int* dlabel = nullptr;
     HIPCHK(c, cache_malloc((void**)&dlabel, (size_t)c->N * sizeof(int)));
+    c->vec_holds_logshift = false;
     hipError_t e = hipMemcpyAsync(c->vec_tmp, v_host, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dlabel, label_host, (size_t)c->N * sizeof(int), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = launch_fill_masked_rows(c->stream, c->u + row0 * c->ld, c->ld, c->N, nrows, c->vec_tmp, dlabel);
@@ -2573,7 +2595,9 @@ int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
 
 int mbar_ctx_weights_from_vec(mbar_ctx* c, double power) {
     if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
-    if (!c->vec_tmp) return fail(c, MBAR_ERR_STATE, "mbar_ctx_weights_from_vec: no observable in the staging vector (mbar_ctx_vec_logshift first)");
+    if (!c->vec_tmp || !c->vec_holds_logshift)
+        return fail(c, MBAR_ERR_STATE, "mbar_ctx_weights_from_vec: no observable in the staging vector (mbar_ctx_vec_logshift first; "
+                                       "mbar_ctx_row_sub / rows_sub / fill_masked_rows re-use that vector)");
     if (!(std::fabs(power) <= 8.0)) return fail(c, MBAR_ERR_ARG, "mbar_ctx_weights_from_vec: |power| must be <= 8");
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->lden_eff) {
@@ -2584,10 +2608,16 @@ int mbar_ctx_weights_from_vec(mbar_ctx* c, double power) {
         HIPCHK(c, cache_malloc((void**)&c->cwsq, (size_t)c->ld * sizeof(double)));
         HIPCHK(c, hipMemsetAsync(c->cwsq, 0, (size_t)c->ld * sizeof(double), c->stream));
     }
-    HIPCHK(c, launch_weights_from_log(c->stream, c->vec_tmp, power, c->N, c->cw, c->cwsq));
+    int* flag = reinterpret_cast<int*>(d_misc(c));
+    int overflow = 0;
+    HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    HIPCHK(c, launch_weights_from_log(c->stream, c->vec_tmp, power, c->N, c->cw, c->cwsq, flag));
+    HIPCHK(c, hipMemcpyAsync(&overflow, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->weighted = true;
     c->last_psum.clear();
+    if (overflow)  // (the weights are formed in LINEAR space here: an observable spanning more than ~1e154 overflows its square)
+        return fail(c, MBAR_ERR_NUMERIC, "mbar_ctx_weights_from_vec: (A - shift)^power is not finite for some sample; use the log-space path");
     return MBAR_OK;
 }
 
@@ -3008,7 +3038,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     auto prime_merged = [&]() -> int {
         HIPCHK(c, hipMemcpyAsync(c->scratch, hf.data(), rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
         ScopedTimer t(c, MBAR_TIMER_LSE);
-        HIPCHK(c, launch_lse(c->stream, nbk, 1, true, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr, nullptr, nullptr, c->part,
+        HIPCHK(c, launch_lse(c->stream, nbk, 1, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr, nullptr, nullptr, c->part,
                              c->part + (size_t)2 * g.blocks * rows));
         return MBAR_OK;
     };
@@ -3019,7 +3049,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     int64_t it = 0;  // iterations accepted so far
     long long* sci_stamps = nullptr;
     if (merged && std::getenv("MBAR_DEBUG_STAMPS")) {
-        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 64 * 8 * sizeof(long long)));
+        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 65 * 8 * sizeof(long long)));
         HIPCHK(c, hipMemsetAsync(c->stamps, 0, 64 * 8 * sizeof(long long), c->stream));
         sci_stamps = c->stamps;
     }
@@ -3063,10 +3093,10 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
             double* obj_part = c->part + (size_t)g.nwaves * rows;
             if (timed) {
                 ScopedTimer t(c, MBAR_TIMER_LSE);
-                HIPCHK(c, launch_lse(c->stream, nbk, 1, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr,
+                HIPCHK(c, launch_lse(c->stream, nbk, 1, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr,
                                      nullptr, nullptr, psum_part, obj_part));
             } else {
-                HIPCHK(c, launch_lse(c->stream, nbk, 1, c->opt_staging == 0, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr,
+                HIPCHK(c, launch_lse(c->stream, nbk, 1, g, c->u, c->ld, c->N, d_aden(c), c->cw, nullptr,
                                      nullptr, nullptr, psum_part, obj_part));
             }
             const double* upd_src = psum_part;

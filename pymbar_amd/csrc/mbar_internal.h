@@ -85,7 +85,7 @@ struct LaunchGeom {
 // one candidate; 0x20: single-buffer kernel for 129..256 states); the geometry records its choice in LaunchGeom::variant
 // (1 = k_lse, one tile stream per wave; 4 = k_lse_small; 5 = k_lse_wide)
 LaunchGeom lse_geometry(int nb, int nf, int num_cu, int64_t ntiles, int64_t grid_override, int variant);
-hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g,
+hipError_t launch_lse(hipStream_t s, int nb, int nf, const LaunchGeom& g,
                       const double* u, int64_t ld, int64_t N, const double* aden /*[nf][16nb]*/,
                       const double* cw, double* logden0, double* logden1, const double* dn,
                       double* psum_part, double* obj_part, const LoopCtl& lc = LoopCtl());
@@ -104,11 +104,11 @@ hipError_t launch_rows_logshift(hipStream_t s, double* base, int64_t ld, int64_t
 // rows[i][k] = label[k] == i ? v[k] : +inf,  i < nrows (row pitch ld)
 hipError_t launch_fill_masked_rows(hipStream_t s, double* rows, int64_t ld, int64_t n, int64_t nrows, const double* v,
                                    const int* label);
-hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u,
+hipError_t launch_gram_diag(hipStream_t s, int nb, const LaunchGeom& g, const double* u,
                             int64_t ld, int64_t N, const double* anum /*indexed from row0*/,
                             const double* logden, int64_t row0, double* gram_part, double* psum_part,
                             const LoopCtl& lc = LoopCtl());
-hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
+hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, const LaunchGeom& g, const double* u, int64_t ld,
                            int64_t N, const double* anum_i, const double* anum_j, const double* logden,
                            int64_t row_i0, int64_t row_j0, double* gram_part);
 
@@ -183,7 +183,8 @@ struct SciLoopArgs {
 };
 hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* cw,
                             const SciLoopArgs& q);
-hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int64_t n, double* cw, double* cwsq);
+// (*overflow, zeroed by the caller, is set when a weight is not finite)
+hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int64_t n, double* cw, double* cwsq, int* overflow);
 hipError_t launch_reduce_level1(hipStream_t s, const double* part, int64_t nparts, int64_t count, double* out,
                                 int64_t* nchunks);
 hipError_t launch_mfma_peak(hipStream_t s, int blocks, int iters, double* sink);
@@ -231,8 +232,6 @@ struct AdaptArgs {
     // fused loop: the last iteration may run without its Gram matrix (CTL_LIGHT); 0 = never (small problems: an idle launch
     // per iteration would cost more than the one lighter sweep saves)
     int light_ok;
-    // 64 .. 127 unknowns: the Gauss-Jordan eliminations on the fp64 matrix cores, four pivots per step (newton_body_mfma)
-    int newton_mfma;
     // MBAR_DEBUG_STAMPS=1: shader-clock stamps of the phases of k_select_newton (thread 0; [8] per launch slot, 64 slots)
     long long* stamps;
 };

@@ -889,11 +889,11 @@ static hipError_t launch_lse_t(hipStream_t s, const LaunchGeom& g, const double*
 }
 
 template <int NB>
-static hipError_t launch_lse_nb(hipStream_t s, int nf, bool dma, const LaunchGeom& g, const double* u,
+static hipError_t launch_lse_nb(hipStream_t s, int nf, const LaunchGeom& g, const double* u,
                                 int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
                                 const double* dn, double* pp, double* op, const LoopCtl& lc) {
     // (LDS-DMA staging only: the register-staged instantiations of rounds 1-3 were a tuning knob, never the faster path)
-    if (g.variant != 1 || !dma) return hipErrorInvalidValue;
+    if (g.variant != 1) return hipErrorInvalidValue;
     if (nf == 1) return launch_lse_t<NB, 1, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
     return launch_lse_t<NB, 2, true>(s, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
 }
@@ -932,12 +932,11 @@ hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const do
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom& g, const double* u,
+hipError_t launch_lse(hipStream_t s, int nb, int nf, const LaunchGeom& g, const double* u,
                       int64_t ld, int64_t N, const double* aden, const double* cw, double* l0, double* l1,
                       const double* dn, double* pp, double* op, const LoopCtl& lc) {
     if (lc.ctl && g.variant == 4) return hipErrorInvalidValue;
     if (g.variant == 5) {  // (geometry chose the single-buffer wide-panel kernel: nb = 12 or 16, LDS-DMA staging)
-        if (!dma) return hipErrorInvalidValue;
         auto go = [&](auto kern) -> hipError_t {
             if (g.lds_bytes > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -958,7 +957,7 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
         return hipErrorInvalidValue;
     }
     if (g.variant == 4) {  // (geometry chose the few-state kernel: nf == 1, nb <= 3, LDS-DMA staging, pitch % 64 == 0)
-        if (nf != 1 || !dma || (ld % TSS) != 0) return hipErrorInvalidValue;
+        if (nf != 1 || (ld % TSS) != 0) return hipErrorInvalidValue;
         switch (nb) {
             case 1: return launch_lse_small_t<1>(s, g, u, ld, N, aden, cw, l0, dn, pp, op);
             case 2: return launch_lse_small_t<2>(s, g, u, ld, N, aden, cw, l0, dn, pp, op);
@@ -967,7 +966,7 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, bool dma, const LaunchGeom&
     }
     switch (nb) {
 #define MBAR_CASE(NB_) \
-    case NB_: return launch_lse_nb<NB_>(s, nf, dma, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
+    case NB_: return launch_lse_nb<NB_>(s, nf, g, u, ld, N, aden, cw, l0, l1, dn, pp, op, lc);
         MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7)
         MBAR_CASE(8) MBAR_CASE(12) MBAR_CASE(16)
 #undef MBAR_CASE

@@ -244,10 +244,9 @@ static hipError_t launch_gram_t(hipStream_t s, const LaunchGeom& g, const double
                                   : launch(k_gram<NBI, NBJ, DIAG, DMA, false, CLAMP, PMODE>);
 }
 
-hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g, const double* u, int64_t ld,
+hipError_t launch_gram_diag(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld,
                             int64_t N, const double* anum, const double* logden, int64_t row0, double* gp,
                             double* pp, const LoopCtl& lc) {
-    if (!dma) return hipErrorInvalidValue;  // (LDS-DMA staging only)
     if (lc.pmode) {  // resident probability matrix: `u` = P, `logden` = the reciprocals 1 / s_n
         switch (nb) {
 #define MBAR_CASE(NB_) \
@@ -271,10 +270,9 @@ hipError_t launch_gram_diag(hipStream_t s, int nb, bool dma, const LaunchGeom& g
     }
 }
 
-hipError_t launch_gram_off(hipStream_t s, int nbj, bool dma, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
+hipError_t launch_gram_off(hipStream_t s, int nbj, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                            const double* ai, const double* aj, const double* logden, int64_t ri, int64_t rj,
                            double* gp) {
-    if (!dma) return hipErrorInvalidValue;
     if (nbj == 8)  // 64 x 128 rectangle: 32 blocks, pinned accumulator classes, one 192-row tile buffer per wave
         return launch_gram_t<4, 8, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
     return launch_gram_t<4, 4, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);

@@ -678,221 +678,6 @@ __device__ __forceinline__ void newton_body(const AdaptArgs& q, long long* st = 
 
     newton_tail<NT>(q, xs, bad, s_f, s_ps, s_nk, s_ln, s_a0, smp, pos, tid);
 }
-// ---------------------------------------------------------------------------------------------
-// The same gauge-fixed Gauss-Jordan solve for 64 .. 127 unknowns with the eliminations on the fp64 MATRIX cores: FOUR pivots per
-// barrier, the rank-4 update of every live 16 x 16 block one v_mfma_f64_16x16x4 (the two-pivot register version above spends
-// ~870 clocks per step on ~180 vector FMAs per thread and ~900 on its latency chain, 64 steps; here a step is one chain and at
-// most sixteen matrix instructions per wave, 32 steps).
-//   Layout: the augmented matrix [A | b] (128 x 128, b in column 127, row 127 padding) lives in the ACCUMULATOR layout of the
-//   matrix instruction -- block (I, J), lane l, register r <-> row 16 I + 4 r + (l >> 4), column 16 J + (l & 15); wave w owns block
-//   rows 2 w and 2 w + 1 (sixteen blocks, 128 registers).
-//   Step (pivots j0 .. j0 + 3, all inside block column J0 = j0 / 16): the four pivot columns are published through LDS (their
-//   owners are the lanes with (l & 15) in [j0 % 16, + 4) of block column J0; b_j travels in slot 127 as in the register version);
-//   one barrier; every lane factors the 4 x 4 pivot block P = L D L^T for itself (d_k are exactly the pivots of the sequential
-//   elimination: recorded, and compared with the threshold) and solves P x = e_k for ITS operand column k = l >> 4; the
-//   A operand is -M with M = C P^-1 (rows of the pivot block: I - D P^-1, which leaves them as d_q (P^-1 R)_q, diagonal in the
-//   pivot columns); the B operand is the pivot rows R = C^T (symmetry of the live block; columns left of the pivots take
-//   garbage and are never read again); acc(I, J) += (-M_I) R_J for J >= J0.  x_i = b_i / d_i at the end: no triangular solves.
-//   A last group with fewer than four pivots (M not a multiple of 4, or index 127) masks the pivot block to the identity there.
-// ---------------------------------------------------------------------------------------------
-typedef double v4d_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double gram_elem_lds(const double* g, int nb, int ki, int kj) {
-    if (ki > kj) {
-        const int t = ki;
-        ki = kj;
-        kj = t;
-    }
-    const int I = ki >> 4, J = kj >> 4;
-    const int b = I * nb - (I * (I - 1)) / 2 + (J - I);
-    return g[b * (16 * 17) + (ki & 15) * 17 + (kj & 15)];  // (SELECT_GRAM_PITCH = 17, defined with the selection below)
-}
-__device__ __forceinline__ void newton_body_mfma(const AdaptArgs& q, const double* gram_lds, long long* st = nullptr) {  // 256 threads
-    constexpr int NC = 128;
-    __shared__ double colbuf[2][4][NC];  // [parity of the step][pivot column k][row]; [k][127] = b_{j0 + k}
-    __shared__ double pv[NC], rh[NC], xs[NC + 1];
-    __shared__ double s_f[128], s_ps[128], s_nk[128], s_ln[128];
-    __shared__ double s_cc[128], s_a0[128];
-    __shared__ int smp[NC + 1], pos[128];
-    if (q.ctl[CTL_DONE] != 0) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lc = lane & 15, lr = lane >> 4;
-    const int M = q.m - 1, nb = q.Kp / 16;
-    for (int k = tid; k < q.Kp; k += 256) {
-        s_f[k] = k < q.K ? q.f[k] : 0.0;
-        s_ps[k] = q.psum[k];
-        s_nk[k] = q.Nk[k];
-        s_ln[k] = q.lnNk[k];
-        s_cc[k] = q.pmode ? (q.fused ? q.cgram[k] : q.ccur[k]) : 1.0;
-        s_a0[k] = q.pmode ? q.a0[k] : 0.0;
-        pos[k] = 0;
-    }
-    for (int i = tid; i < q.m; i += 256) smp[i] = q.sampled[i];
-    __syncthreads();
-    for (int i = tid; i < q.m; i += 256) pos[smp[i]] = i;
-
-    // ---- tile set-up in the accumulator layout
-    v4d_t acc[2][8];
-    {
-        int kj[8];
-        double cj[8];
-#pragma unroll
-        for (int J = 0; J < 8; ++J) {
-            const int k = 16 * J + lc;
-            kj[J] = k < M ? smp[k + 1] : 0;
-            cj[J] = s_cc[kj[J]];
-        }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * (2 * w + ii) + 4 * r + lr;
-                const int ki = i < M ? smp[i + 1] : 0;
-                const double ci = s_cc[ki], psi = s_ps[ki], gi = psi - s_nk[ki];
-#pragma unroll
-                for (int J = 0; J < 8; ++J) {
-                    const int k = 16 * J + lc;
-                    double v = -(gram_lds ? gram_elem_lds(gram_lds, nb, ki, kj[J]) : gram_elem(q.gram_red, nb, ki, kj[J]));
-                    if (q.pmode) v *= ci * cj[J];
-                    if (i < M) {
-                        if (k < M) {
-                            if (i == k) v += psi;
-                        } else {
-                            v = (k == NC - 1) ? gi : 0.0;
-                        }
-                    } else {
-                        v = (i == k && k != NC - 1) ? 1.0 : 0.0;
-                    }
-                    acc[ii][J][r] = v;
-                }
-            }
-        }
-    }
-    double pmax = 0.0;
-    {
-        __shared__ double s_pmax[4];
-        double v = 0.0;
-        for (int i = tid; i < q.m; i += 256) v = fmax(v, s_ps[smp[i]]);
-        v = wave_max(v);
-        if (lane == 0) s_pmax[w] = v;
-        __syncthreads();
-#pragma unroll
-        for (int x = 0; x < 4; ++x) pmax = fmax(pmax, s_pmax[x]);
-    }
-    const double piv_thr = pmax * 2.220446049250313e-16 * (double)(M > 0 ? M : 1);
-    if (st && tid == 0) st[2] = clock64();
-
-    // ---- elimination
-    bool bad = false;
-    int par = 0;
-    const double e0 = lr == 0 ? 1.0 : 0.0, e1 = lr == 1 ? 1.0 : 0.0, e2 = lr == 2 ? 1.0 : 0.0, e3 = lr == 3 ? 1.0 : 0.0;
-#pragma unroll
-    for (int J0 = 0; J0 < 8; ++J0) {
-        if (16 * J0 < M) {
-            for (int jl = 0; jl < 16; jl += 4) {
-                const int j0 = 16 * J0 + jl;
-                if (j0 >= M) break;
-                const int npiv = M - j0 < 4 ? M - j0 : 4;
-                double(*cb)[NC] = colbuf[par];
-                par ^= 1;
-                // 1. the pivot columns as they stand (slot 127 belongs to b)
-                const int cl = lc - jl;
-                if (cl >= 0 && cl < 4) {
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = 16 * (2 * w + ii) + 4 * r + lr;
-                            if (i != NC - 1) cb[cl][i] = acc[ii][J0][r];
-                        }
-                }
-                if (w == (J0 >> 1) && lc == 15) {  // b_{j0 + k}: block (J0, 7), register jl / 4, lanes 15 + 16 k
-                    const v4d_t t = acc[J0 & 1][7];
-                    cb[lr][NC - 1] = jl == 0 ? t[0] : (jl == 4 ? t[1] : (jl == 8 ? t[2] : t[3]));
-                }
-                __syncthreads();
-                // 2. P = L D L^T of the 4 x 4 pivot block (identity where the group has no pivot)
-                double p00 = cb[0][j0], p10 = cb[0][j0 + 1], p20 = cb[0][j0 + 2], p30 = cb[0][j0 + 3];
-                double p11 = cb[1][j0 + 1], p21 = cb[1][j0 + 2], p31 = cb[1][j0 + 3];
-                double p22 = cb[2][j0 + 2], p32 = cb[2][j0 + 3], p33 = cb[3][j0 + 3];
-                if (npiv < 4) {
-                    p30 = p31 = p32 = 0.0;
-                    p33 = 1.0;
-                    if (npiv < 3) {
-                        p20 = p21 = 0.0;
-                        p22 = 1.0;
-                    }
-                    if (npiv < 2) {
-                        p10 = 0.0;
-                        p11 = 1.0;
-                    }
-                }
-                const double d0 = p00, rd0 = recip_fast(d0);
-                const double l10 = p10 * rd0, l20 = p20 * rd0, l30 = p30 * rd0;
-                const double d1 = fma(-l10, p10, p11), rd1 = recip_fast(d1);
-                const double t21 = fma(-l20, p10, p21), t31 = fma(-l30, p10, p31);
-                const double l21 = t21 * rd1, l31 = t31 * rd1;
-                const double d2 = fma(-l21, t21, fma(-l20, p20, p22)), rd2 = recip_fast(d2);
-                const double t32 = fma(-l31, t21, fma(-l30, p20, p32));
-                const double l32 = t32 * rd2;
-                const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, p30, p33))), rd3 = recip_fast(d3);
-                if (tid == 0) {
-                    pv[j0] = d0;
-                    if (npiv > 1) pv[j0 + 1] = d1;
-                    if (npiv > 2) pv[j0 + 2] = d2;
-                    if (npiv > 3) pv[j0 + 3] = d3;
-                }
-                // (padding pivots are exactly 1: the test passes for them)
-                if (!(d0 > piv_thr) || !isfinite(d0) || !(d1 > piv_thr || npiv < 2) || !isfinite(d1) || !(d2 > piv_thr || npiv < 3) ||
-                    !isfinite(d2) || !(d3 > piv_thr || npiv < 4) || !isfinite(d3))
-                    bad = true;  // the same in every thread
-                // column lr of P^-1: forward with e_lr, scale, back
-                const double y0 = e0, y1 = fma(-l10, y0, e1), y2 = fma(-l21, y1, fma(-l20, y0, e2));
-                const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, e3)));
-                const double x3 = y3 * rd3;
-                const double x2 = fma(-l32, x3, y2 * rd2);
-                const double x1 = fma(-l31, x3, fma(-l21, x2, y1 * rd1));
-                const double x0 = fma(-l30, x3, fma(-l20, x2, fma(-l10, x1, y0 * rd0)));
-                // 3. A operand: -M, lane (row lc of the block, pivot lr)
-                double am[2];
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii) {
-                    const int row = 16 * (2 * w + ii) + lc;
-                    double m = fma(cb[3][row], x3, fma(cb[2][row], x2, fma(cb[1][row], x1, cb[0][row] * x0)));
-                    const int qd = row - j0;  // pivot row q of this group?
-                    if (qd >= 0 && qd < npiv) {
-                        const double dq = qd == 0 ? d0 : (qd == 1 ? d1 : (qd == 2 ? d2 : d3));
-                        const double xq = qd == 0 ? x0 : (qd == 1 ? x1 : (qd == 2 ? x2 : x3));
-                        m = fma(-dq, xq, qd == lr ? 1.0 : 0.0);
-                    }
-                    if (lr >= npiv) m = 0.0;
-                    am[ii] = -m;
-                }
-                // 4. B operand (pivot rows by symmetry; column 127 = b) and the rank-4 updates
-#pragma unroll
-                for (int J = J0; J < 8; ++J) {
-                    const double rb = cb[lr][16 * J + lc];
-                    acc[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[0], rb, acc[0][J], 0, 0, 0);
-                    acc[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[1], rb, acc[1][J], 0, 0, 0);
-                }
-            }
-        }
-    }
-    if (st && tid == 0) st[3] = clock64();
-    if (lc == 15) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rh[16 * (2 * w + ii) + 4 * r + lr] = acc[ii][7][r];
-    }
-    __syncthreads();
-    if (tid == 0) xs[0] = 0.0;
-    if (tid < M) xs[tid + 1] = rh[tid] / pv[tid];
-    __syncthreads();
-    if (st && tid == 0) st[4] = clock64();
-    newton_tail<256>(q, xs, bad, s_f, s_ps, s_nk, s_ln, s_a0, smp, pos, tid);
-}
-
 template <int T, int R>
 __global__ void __launch_bounds__(T * T)
 k_newton(AdaptArgs q) {
@@ -1142,12 +927,10 @@ k_chol_finish(AdaptArgs q, const double* __restrict__ Aw) {
 // loads -- all 36 in flight -- before the matrix-vector product below reads them.
 constexpr int SELECT_GRAM_PITCH = 17;  // a 16 x 16 block's rows are stored 17 doubles apart: the column walk of a row is conflict-free
 constexpr int SELECT_GRAM_LDS_DOUBLES = 36 * 16 * SELECT_GRAM_PITCH;
-// Returns true when the reduced Gram blocks were staged in gram_lds (the Newton solve that rides behind reads them from there).
-__device__ __forceinline__ bool select_body(const AdaptArgs& q, double* gram_lds = nullptr) {  // (256 threads; the pointers of q may be LDS or global)
+__device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds = nullptr) {  // (256 threads; the pointers of q may be LDS or global)
     __shared__ double red[4];
     int* ctl = q.ctl;
-    if (ctl[CTL_DONE] != 0) return false;
-    bool staged = false;
+    if (ctl[CTL_DONE] != 0) return;
     const int tid = threadIdx.x, Kp = q.Kp;
     const double tol = q.prm[1];
     const int min_sc = (int)q.prm[2];
@@ -1183,7 +966,6 @@ __device__ __forceinline__ bool select_body(const AdaptArgs& q, double* gram_lds
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) gram_lds[b * (16 * SELECT_GRAM_PITCH) + (tid >> 4) * SELECT_GRAM_PITCH + (tid & 15)] = v[b];
             __syncthreads();
-            staged = true;
             for (int j = h * 64; j < h * 64 + 64; ++j) {
                 int ki = k, kj = j;
                 if (ki > kj) {
@@ -1262,7 +1044,6 @@ __device__ __forceinline__ bool select_body(const AdaptArgs& q, double* gram_lds
         else if (q.fused && !reuse)
             ctl[CTL_DONE] = 3;  // pause: the host enqueues the Gram sweep of the accepted candidate (same flags on every rank)
     }
-    return staged;
 }
 __global__ void __launch_bounds__(256)
 k_select(AdaptArgs q, int gram_in_lds) {
@@ -1272,25 +1053,17 @@ k_select(AdaptArgs q, int gram_in_lds) {
 // Fused loop: the selection of iteration i and the Newton solve of iteration i + 1 in ONE launch (a kernel boundary costs ~5 us;
 // at the sizes pymbar is mostly used at that is a tenth of an iteration).  A stop or pause flag raised by the selection makes the
 // solve return at once.
-// MFMA: the eliminations of the solve on the matrix cores (newton_body_mfma; R = 8 only: 64 .. 127 unknowns).
-template <int R, bool MFMA>
+template <int R>
 __global__ void __launch_bounds__(256)
 k_select_newton(AdaptArgs q, int gram_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
     long long* st = q.stamps ? q.stamps + 8 * (q.ctl[CTL_ITER] & 63) : nullptr;  // (debug: one slot per iteration)
     if (st && threadIdx.x == 0) st[0] = clock64();
-    const bool staged = select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
+    select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
     __syncthreads();
     if (st && threadIdx.x == 0) st[1] = clock64();
-    if constexpr (MFMA)
-        newton_body_mfma(q, staged ? select_dyn_lds : nullptr, st);
-    else
-        newton_body<16, R>(q, st);
+    newton_body<16, R>(q, st);
     if (st && threadIdx.x == 0) st[5] = clock64();
-}
-__global__ void __launch_bounds__(256)
-k_newton_mfma(AdaptArgs q) {
-    newton_body_mfma(q, nullptr);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1543,8 +1316,6 @@ hipError_t launch_newton(hipStream_t s, const AdaptArgs& a) {
         hipLaunchKernelGGL((k_newton<8, 4>), dim3(1), dim3(64), 0, s, a);
     else if (M <= 63)
         hipLaunchKernelGGL((k_newton<16, 4>), dim3(1), dim3(256), 0, s, a);
-    else if (a.newton_mfma)
-        hipLaunchKernelGGL(k_newton_mfma, dim3(1), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((k_newton<16, 8>), dim3(1), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -1593,9 +1364,8 @@ hipError_t launch_select_newton(hipStream_t s, const AdaptArgs& a) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, s, a, stage);
         return hipGetLastError();
     };
-    if (M <= 63) return go(k_select_newton<4, false>);
-    if (a.newton_mfma) return go(k_select_newton<8, true>);
-    return go(k_select_newton<8, false>);
+    if (M <= 63) return go(k_select_newton<4>);
+    return go(k_select_newton<8>);
 }
 
 hipError_t launch_select(hipStream_t s, const AdaptArgs& a) {
@@ -1617,17 +1387,22 @@ hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld,
 // cw[n] = exp(p v[n]), cwsq[n] = exp(p v[n] / 2) for n < N: per-sample weights A'^p from the staging vector log A' of an observable
 // (mbar_ctx_weights_from_vec; the padding behind N keeps its zeros)
 __global__ void __launch_bounds__(256)
-k_weights_from_log(const double* __restrict__ v, double p, int64_t n, double* __restrict__ cw, double* __restrict__ cwsq) {
+k_weights_from_log(const double* __restrict__ v, double p, int64_t n, double* __restrict__ cw, double* __restrict__ cwsq,
+                   int* __restrict__ overflow) {
+    bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double x = p * v[i];
-        cw[i] = exp(x);
+        const double e = exp(x);
+        cw[i] = e;
         cwsq[i] = exp(0.5 * x);
+        bad |= !(e <= 1.79e308);  // inf (the observable spans more than 1e308^(1/p)) or NaN
     }
+    if (bad) atomicOr(overflow, 1);
 }
-hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int64_t n, double* cw, double* cwsq) {
+hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int64_t n, double* cw, double* cwsq, int* overflow) {
     int64_t bx = (n + 255) / 256;
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(k_weights_from_log, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, v, p, n, cw, cwsq);
+    hipLaunchKernelGGL(k_weights_from_log, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, v, p, n, cw, cwsq, overflow);
     return hipGetLastError();
 }
 hipError_t launch_zero(hipStream_t s, void* p, size_t bytes) {

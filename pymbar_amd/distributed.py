@@ -14,6 +14,7 @@ the host through the :class:`HostGroup` (``"host"``); callers that must not fall
 returned kind.
 """
 import hashlib
+import hmac
 import logging
 import os
 import socket
@@ -95,8 +96,10 @@ class HostGroup:
     spawner does with a random value) tells this group's hub from anything else listening there.  Rank 0 binds the interface
     of ``MASTER_ADDR`` (loopback for a single node; the wildcard address only when that name is not a usable local interface --
     see ``_bind_candidates`` -- or ``MBAR_RDZV_BIND`` says so).  ``timeout`` bounds the rendezvous; once the group stands, a
-    collective may wait ``data_timeout`` for a slow peer (default ``MBAR_RDZV_DATA_TIMEOUT`` or 600 s: ranks skew by minutes
-    when one of them uploads tens of GB first, but a dead peer must not hang a job for an hour).  Messages above 64 MB travel
+    collective may wait ``data_timeout`` for a slow peer (default ``MBAR_RDZV_DATA_TIMEOUT`` or 3600 s: ranks skew by minutes
+    when one of them uploads tens of GB, runs a BAR initialisation or a CPU baseline first).  The wildcard address is a
+    fallback for ONE situation -- the resolved address is not an interface of this host (``EADDRNOTAVAIL``) -- and is logged
+    as a warning when no ``MBAR_RDZV_SECRET`` strengthens the handshake token.  Messages above 64 MB travel
     in pieces (a K x K all-reduce on the host transport is 8 K^2 bytes)."""
 
     def __init__(self, rank, world, addr="127.0.0.1", base_port=29501, token="", timeout=120.0, data_timeout=None):
@@ -107,12 +110,16 @@ class HostGroup:
         if self.world <= 1:
             return
         if data_timeout is None:
-            data_timeout = float(os.environ.get("MBAR_RDZV_DATA_TIMEOUT", "600"))
+            data_timeout = float(os.environ.get("MBAR_RDZV_DATA_TIMEOUT", "3600"))
         tok = hashlib.sha256(f"{token}|{self.world}".encode()).digest()[:16]
         deadline = time.time() + timeout
         if self.rank == 0:
+            import errno
+
             last = None
-            for bind_addr in _bind_candidates(addr):
+            candidates = _bind_candidates(addr)
+            for i, bind_addr in enumerate(candidates):
+                not_local = False
                 for port in range(base_port, base_port + _PORT_SPAN):
                     try:
                         ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -124,7 +131,20 @@ class HostGroup:
                     except OSError as exc:
                         last = exc
                         ls.close()
+                        if exc.errno == errno.EADDRNOTAVAIL:  # not an interface of this host: no port will do
+                            not_local = True
+                            break
                 if self._listener is not None:
+                    if bind_addr == "0.0.0.0" and not os.environ.get("MBAR_RDZV_SECRET") and not os.environ.get("MBAR_RDZV_BIND"):
+                        import logging
+
+                        logging.getLogger(__name__).warning(
+                            "rendezvous hub listens on the wildcard address (MASTER_ADDR=%s is not a local interface) and no "
+                            "MBAR_RDZV_SECRET is set: the handshake token derives from launch parameters only", addr)
+                    break
+                # the next candidate is the wildcard address: only because this one is not a local interface -- never because its
+                # ports happen to be taken (EADDRINUSE on all of them is an error, not a reason to listen everywhere)
+                if i + 1 < len(candidates) and not not_local:
                     break
             if self._listener is None:
                 raise RuntimeError(f"rendezvous: no free port in [{base_port}, {base_port + _PORT_SPAN}): {last}")
@@ -140,8 +160,8 @@ class HostGroup:
                     conn.settimeout(5.0)
                     hello = _recv_exact(conn, len(_MAGIC) + 16 + 4)
                     peer = struct.unpack("<i", hello[-4:])[0]
-                    if hello[: len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):-4] != tok or not (0 < peer < self.world) \
-                            or peer in self._socks:
+                    if hello[: len(_MAGIC)] != _MAGIC or not hmac.compare_digest(hello[len(_MAGIC):-4], tok) \
+                            or not (0 < peer < self.world) or peer in self._socks:
                         conn.close()
                         continue
                     conn.sendall(b"OK")
@@ -262,10 +282,13 @@ def attach_allreduce(dm, group, prefer="rccl"):
     """Give ``dm`` its cross-rank reduction over the ranks of ``group``.  Returns "none", "rccl" or "host".
 
     ``group`` is a :class:`HostGroup` (or any object with ``rank``, ``world``, ``broadcast_bytes`` and
-    ``allreduce(array, op)``).  Collective: every rank of the group must call it."""
+    ``allreduce(array, op)``).  Collective: every rank of the group must call it.  When RCCL was preferred and "host" comes
+    back, ``dm.rccl_error`` holds, on EVERY rank, the message of the lowest rank that failed (a launcher can print it)."""
     if group is None or group.world <= 1:
         return "none"
+    dm.rccl_error = None
     rank, nranks = group.rank, group.world
+    my_error = None
     if prefer == "rccl":
         if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
             # single-node rendezvous: RCCL's bootstrap sockets may use the loopback interface (it is skipped by
@@ -283,6 +306,7 @@ def attach_allreduce(dm, group, prefer="rccl"):
                 payload = bytes(buf.raw)
             except Exception as exc:  # pragma: no cover - needs RCCL
                 logger.warning("RCCL unique id could not be created (%s); using the host all-reduce", exc)
+                my_error = f"rank 0: ncclGetUniqueId: {exc}"
         payload = group.broadcast_bytes(payload, src=0)
         ok = payload is not None
         if ok:
@@ -290,11 +314,20 @@ def attach_allreduce(dm, group, prefer="rccl"):
                 dm.comm_init_rccl(payload, rank, nranks)
             except Exception as exc:  # pragma: no cover - needs several GPUs
                 logger.warning("RCCL initialisation failed on rank %d (%s); using the host all-reduce", rank, exc)
+                my_error = f"rank {rank}: ncclCommInitRank: {exc}"
                 ok = False
+        elif my_error is None:
+            my_error = f"rank {rank}: no unique id arrived from rank 0"
         flag = np.array([1.0 if ok else 0.0])
         group.allreduce(flag, "min")
         if flag[0] == 1.0:
             return "rccl"
+        # the message of the lowest failing rank, on every rank
+        who = np.array([float(rank) if not ok else float(nranks)])
+        group.allreduce(who, "min")
+        src = int(who[0]) if who[0] < nranks else 0
+        msg = group.broadcast_bytes((my_error or "unknown").encode() if rank == src else None, src=src)
+        dm.rccl_error = msg.decode(errors="replace") if msg else "unknown"
         # not every rank has a communicator: NOBODY may keep one (a rank that still issued ncclAllReduce while the
         # others reduce on the host would deadlock every later sweep)
         dm.comm_destroy()

@@ -151,8 +151,11 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
     if (dedup and not bootstrap and S > 0 and np.all(obs_list == obs_list[0]) and len(state_list) == S
             and len(np.unique(state_list)) == S and getattr(mbar, "_dm", None) is not None
             and hasattr(mbar._dm, "weights_from_vec") and getattr(mbar._dm, "nranks", 1) == 1):
-        return _single_observable_moments(mbar, A_n[int(obs_list[0])], state_list, int(obs_list[0]), len(A_n), col_of_state,
-                                          L_list, uncertainty_method, return_theta)
+        try:
+            return _single_observable_moments(mbar, A_n[int(obs_list[0])], state_list, int(obs_list[0]), len(A_n), col_of_state,
+                                              L_list, uncertainty_method, return_theta)
+        except _LinearWeightsOverflow:
+            pass  # an observable spanning more than ~1e154: its square has no linear-space weights; the log-space path below has no such limit
     # The augmented matrix goes to the device once.  A bootstrap replicate (mbar.py:905-912 gathers
     # u_kn[:, bootstrap_rints[n]]) is the same matrix with per-sample multiplicities = draw counts.
     # (observables are made strictly positive so that they can live in log space, mbar.py:858-867: shift[i] is the reference's
@@ -210,6 +213,21 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
     return result_vals
 
 
+class _LinearWeightsOverflow(Exception):
+    """``(A - shift)**p`` overflowed on the device (mbar_ctx_weights_from_vec, MBAR_ERR_NUMERIC)."""
+
+
+def _weights_from_vec(dm, power):
+    from ._lib import MbarHipError
+
+    try:
+        dm.weights_from_vec(power)
+    except MbarHipError as exc:
+        if exc.code == -6:  # MBAR_ERR_NUMERIC
+            raise _LinearWeightsOverflow() from exc
+        raise
+
+
 def _single_observable_moments(mbar, A_row, state_list, obs_index, n_obs, col_of_state, L_list, uncertainty_method, return_theta):
     """``compute_expectations_inner`` for ONE observable evaluated at S distinct RESIDENT states (``compute_expectations(A_n)``,
     mbar.py:1039-1312, the common call) WITHOUT an augmented matrix.  The weight column of "A at state l" is
@@ -236,7 +254,7 @@ def _single_observable_moments(mbar, A_row, state_list, obs_index, n_obs, col_of
         dm.set_sample_weights(None)
         lognum0 = dm.lognum(f_k)                       # resident rows as states: -f_l
         shift[obs_index] = dm.vec_logshift(A_row)       # log(A - shift) stays on the device
-        dm.weights_from_vec(1.0)
+        _weights_from_vec(dm, 1.0)
         lognum1 = dm.lognum(f_k)                       # log sum_n A'_n exp(-u_ln - logden_n)
         f_states = -lognum0[states]
         A_i = np.exp(lognum1[states] - lognum0[states])
@@ -244,7 +262,7 @@ def _single_observable_moments(mbar, A_row, state_list, obs_index, n_obs, col_of
         result_vals["f"] = f_states
         if return_theta:
             G1, ws1 = dm.gram_w(f_k)
-            dm.weights_from_vec(2.0)
+            _weights_from_vec(dm, 2.0)
             G2, _ = dm.gram_w(f_k)
             dm.set_sample_weights(None)
             G0, ws0 = dm.gram_w(f_k)

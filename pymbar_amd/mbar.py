@@ -140,7 +140,14 @@ class MBAR:
 
                 early_upload["thread"] = threading.Thread(target=_upload, daemon=True)
                 early_upload["thread"].start()
-            self.u_kn = _private_copy(src)
+            try:
+                self.u_kn = _private_copy(src)
+            except BaseException:  # (a MemoryError on a matrix of many GB: the upload beside it must not leave its device copy behind)
+                if early_upload is not None:
+                    early_upload["thread"].join()
+                    if early_upload["dm"] is not None:
+                        early_upload["dm"].close()
+                raise
         elif shared:
             self.u_kn = src.view()
             self.u_kn.setflags(write=False)

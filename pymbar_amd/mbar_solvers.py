@@ -85,8 +85,9 @@ class _ResidentCache:
     of any kind therefore costs a fresh upload, never a stale answer.
     An entry in use is never closed: handles are reference-counted (an evicted entry is closed by its last user), every cache
     operation runs under a lock, and a handle -- a context is not thread-safe -- is used by one thread at a time.
-    Bounded: ``PYMBAR_AMD_RESIDENT_CACHE`` entries (default 2; 0 switches the cache off) and
-    ``PYMBAR_AMD_RESIDENT_CACHE_GB`` (default 32) of device memory; least recently used first out;
+    Bounded: ``PYMBAR_AMD_RESIDENT_CACHE`` entries (default 2: the unchanged class alternates between ``self.u_kn`` and one
+    bootstrap replicate's matrix; 0 switches the cache off) and ``PYMBAR_AMD_RESIDENT_CACHE_GB`` (default 12: one matrix of
+    config 3's size, no more -- a drop-in must not sit on a large part of a shared GPU) of device memory; least recently used first out;
     :func:`drop_resident_cache` releases everything."""
 
     class Entry:
@@ -110,7 +111,7 @@ class _ResidentCache:
     @staticmethod
     def limits():
         return (int(os.environ.get("PYMBAR_AMD_RESIDENT_CACHE", "2")),
-                float(os.environ.get("PYMBAR_AMD_RESIDENT_CACHE_GB", "32")) * 1e9)
+                float(os.environ.get("PYMBAR_AMD_RESIDENT_CACHE_GB", "12")) * 1e9)
 
     @staticmethod
     def digest(a):

@@ -33,17 +33,11 @@ done
 timeout 600 python -W ignore $REPO/tests/refshim/boundary_check.py > $REPO/$OUT/boundary.json 2> $REPO/$OUT/boundary.err
 echo "boundary rc=$?"; tail -c 600 $REPO/$OUT/boundary.json
 
-# test_fes.py's kernel-density cases and the example's kde section need scikit-learn, which the GPU box's python3.10 lacks;
-# the conda python3.9 of the same image has it (and numexpr): the drop-in is ctypes + numpy only and runs under it unchanged
-PY39=/opt/conda/bin/python3.9
-if [ -x $PY39 ]; then
-  PYTHONPATH=$REPO/tests/refshim:$REF:$REPO timeout 900 $PY39 -m pytest $REF/pymbar/tests/test_fes.py -p refshim_plugin -p no:cacheprovider -q \
-      --rootdir=/tmp -c /dev/null -W ignore > $REPO/$OUT/suite_test_fes.py_python39.txt 2>&1
-  echo "rc=$?" >> $REPO/$OUT/suite_test_fes.py_python39.txt; tail -4 $REPO/$OUT/suite_test_fes.py_python39.txt
-fi
-EXPY=python; [ -x $PY39 ] && EXPY=$PY39
+# (test_fes.py's kernel-density cases and the example's kde section need scikit-learn; some boxes of the pool have it under
+# python3.10, some do not -- there the kde cases are skipped and the example stops at its kde section.  The image's conda
+# python3.9 has scikit-learn but cannot load libmbar_hip.so: its libstdc++ lacks GLIBCXX_3.4.29.)
 mkdir -p /tmp/exrun && cd /tmp/exrun
-TMPDIR=/tmp/exrun timeout 600 $EXPY $REPO/tests/refshim/run_example.py $REF/examples/harmonic-oscillators/harmonic-oscillators.py \
+TMPDIR=/tmp/exrun timeout 600 python $REPO/tests/refshim/run_example.py $REF/examples/harmonic-oscillators/harmonic-oscillators.py \
     > $REPO/$OUT/example.txt 2> $REPO/$OUT/example.err
 echo "example rc=$?" | tee -a $REPO/$OUT/example.txt; tail -2 $REPO/$OUT/example.err
 
