@@ -200,6 +200,19 @@ int mbar_ctx_set_Nk(mbar_ctx* ctx, const double* N_k);
  * state) is the vector of draw counts, so replicates re-use the resident matrix instead of a gathered copy. */
 int mbar_ctx_set_sample_weights(mbar_ctx* ctx, const double* c_n);
 
+/* A bootstrap replicate DRAWN ON THE DEVICE (extension: the reference draws with numpy's generator on the host, one pass over
+ * N integers + a bincount per replicate -- 33 ms of host work at N = 4e6 where the replicate's solve takes 5): the multiplicities
+ * c_n of mbar_ctx_set_sample_weights become the draw counts of replicate `replicate` of the counter-based stream `seed` -- slot j
+ * (position j in state order, 0 <= j < cumN[K_states]) of the state that owns positions cumN[k] .. cumN[k+1]-1 draws one of
+ * those positions, a pure function of (seed, replicate, j); order[p] (or NULL: p itself) is the sample at position p, for
+ * x_kindices other than the default; n_global0 = first global sample of this rank's shard.  mbar_bootstrap_draws returns the
+ * SAME draws on the host as the reference's bootstrap_rints row (mbar.py:433: rints[sample of slot j] = sample drawn): host only,
+ * no context.  Same-seed determinism (tests/test_mbar.py:533-545 of the reference) holds by construction. */
+int mbar_ctx_draw_bootstrap_weights(mbar_ctx* ctx, uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states,
+                                    const int64_t* order, int64_t n_global0);
+int mbar_bootstrap_draws(uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states, const int64_t* order,
+                         int64_t* rints_out);
+
 /* Per-sample weights c_n = (A_n - shift)^power from the observable mbar_ctx_vec_logshift left in the staging vector (as
  * log(A_n - shift)), formed on the device: no upload, no host pass over N doubles.  What it is for: ONE observable evaluated at
  * the resident states (compute_expectations(A_n), mbar.py:1039-1312) needs no augmented matrix at all -- the weight column of

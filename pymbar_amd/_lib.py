@@ -80,6 +80,8 @@ SIGNATURES = {
     "mbar_ctx_set_Nk": (C.c_int, [_ctx, _dp]),
     "mbar_ctx_set_sample_weights": (C.c_int, [_ctx, _dp]),
     "mbar_ctx_weights_from_vec": (C.c_int, [_ctx, C.c_double]),
+    "mbar_ctx_draw_bootstrap_weights": (C.c_int, [_ctx, C.c_uint64, C.c_int64, _ip, C.c_int64, _ip, C.c_int64]),
+    "mbar_bootstrap_draws": (C.c_int, [C.c_uint64, C.c_int64, _ip, C.c_int64, _ip, _ip]),
     "mbar_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mbar_ctx_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "mbar_ctx_set_host_allreduce": (C.c_int, [_ctx, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]),
@@ -142,6 +144,24 @@ def host_digest(a, threads=0):
     out = (C.c_uint64 * 2)()
     check(load_library().mbar_host_digest(C.c_void_p(a.ctypes.data), a.nbytes, int(threads), out))
     return bytes(out)
+
+
+def bootstrap_draws(seed, replicate, cumN, order=None):
+    """The draws of replicate ``replicate`` of the counter-based bootstrap stream ``seed`` as the reference's ``bootstrap_rints`` row
+    (``mbar_bootstrap_draws``; host only, no GPU needed): ``rints[sample of slot j] = sample drawn``, state by state."""
+    import numpy as np
+
+    cumN = np.ascontiguousarray(cumN, dtype=np.int64)
+    total = int(cumN[-1])
+    out = np.zeros(total, dtype=np.int64)
+    ip = C.POINTER(C.c_int64)
+    optr = None
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        optr = order.ctypes.data_as(ip)
+    check(load_library().mbar_bootstrap_draws(C.c_uint64(int(seed)), int(replicate), cumN.ctypes.data_as(ip), len(cumN) - 1, optr,
+                                              out.ctypes.data_as(ip)))
+    return out
 
 
 def host_newton_direction(H, g, threads=0):

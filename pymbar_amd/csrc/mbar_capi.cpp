@@ -282,6 +282,9 @@ struct mbar_ctx {
     size_t lognum_part_doubles = 0;
     double* f_hist = nullptr;       // SCI f history [batch][Kp]
     double* vec_tmp = nullptr;      // staging for one N_local-vector (mbar_ctx_row_sub)
+    int64_t* boot_idx = nullptr;    // bootstrap draws: cum[K + 1] | order[total] (mbar_ctx_draw_bootstrap_weights keeps the last layout)
+    size_t boot_idx_words = 0;
+    uint64_t boot_layout_digest[2] = {0, 0};
     bool vec_holds_logshift = false;  // vec_tmp holds log(A - shift) of mbar_ctx_vec_logshift (and not some other call's vector)
     // captured SCI batch (launch-bound loop: 3 small kernels per iteration replayed from a hipGraph)
     hipGraphExec_t sci_graph = nullptr;
@@ -2182,6 +2185,7 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->f_hist) (void)cache_free(c->f_hist);
     if (c->hstage) (void)cache_host_free(c->hstage);
     if (c->vec_tmp) (void)cache_free(c->vec_tmp);
+    if (c->boot_idx) (void)cache_free(c->boot_idx);
     if (c->stamps) (void)hipFree(c->stamps);
     if (c->sci_graph) (void)hipGraphExecDestroy(c->sci_graph);
     if (c->stream) {  // (idle: synchronised above) kept for the next context on this device
@@ -2590,6 +2594,71 @@ int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->weighted = weighted;
     c->last_psum.clear();
+    return MBAR_OK;
+}
+
+int mbar_ctx_draw_bootstrap_weights(mbar_ctx* c, uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states,
+                                    const int64_t* order, int64_t n_global0) {
+    if (!c || !cumN) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (K_states < 1 || replicate < 0 || n_global0 < 0) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: bad argument");
+    const int64_t total = cumN[K_states];
+    if (cumN[0] != 0 || total < n_global0 + c->N) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: the runs do not cover this shard");
+    for (int64_t k = 0; k < K_states; ++k)
+        if (cumN[k + 1] < cumN[k]) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: cumN must not decrease");
+    HIPCHK(c, hipSetDevice(c->device));
+    // the layout (runs + order) goes to the device once per layout, not once per replicate
+    const size_t words = (size_t)(K_states + 1) + (order ? (size_t)total : 0);
+    uint64_t dg[2] = {0, 0};
+    {
+        uint64_t a[2], b[2] = {0, 0};
+        (void)mbar_host_digest(cumN, (int64_t)((K_states + 1) * sizeof(int64_t)), 1, a);
+        if (order) (void)mbar_host_digest(order, (int64_t)((size_t)total * sizeof(int64_t)), 0, b);
+        dg[0] = a[0] ^ (b[0] * 0x9E3779B97F4A7C15ull) ^ (uint64_t)words;
+        dg[1] = a[1] ^ (b[1] * 0xC2B2AE3D27D4EB4Full) ^ (order ? 1u : 0u);
+    }
+    if (!c->boot_idx || c->boot_idx_words != words || c->boot_layout_digest[0] != dg[0] || c->boot_layout_digest[1] != dg[1]) {
+        if (c->boot_idx && c->boot_idx_words < words) {
+            (void)cache_free(c->boot_idx);
+            c->boot_idx = nullptr;
+        }
+        if (!c->boot_idx) HIPCHK(c, cache_malloc((void**)&c->boot_idx, words * sizeof(int64_t)));
+        HIPCHK(c, hipMemcpyAsync(c->boot_idx, cumN, (size_t)(K_states + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        if (order)
+            HIPCHK(c, hipMemcpyAsync(c->boot_idx + K_states + 1, order, (size_t)total * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (the host arrays may go away)
+        c->boot_idx_words = words;
+        c->boot_layout_digest[0] = dg[0];
+        c->boot_layout_digest[1] = dg[1];
+    }
+    if (!c->lden_eff) {
+        HIPCHK(c, cache_malloc((void**)&c->lden_eff, (size_t)c->ld * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->lden_eff, 0, (size_t)c->ld * sizeof(double), c->stream));
+    }
+    if (!c->cwsq) {
+        HIPCHK(c, cache_malloc((void**)&c->cwsq, (size_t)c->ld * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->cwsq, 0, (size_t)c->ld * sizeof(double), c->stream));
+    }
+    HIPCHK(c, launch_fill(c->stream, c->cw, 0.0, c->N));
+    HIPCHK(c, launch_bootstrap_counts(c->stream, seed, replicate, c->boot_idx, K_states, total, order ? c->boot_idx + K_states + 1 : nullptr,
+                                      n_global0, c->N, c->cw));
+    HIPCHK(c, launch_sqrt_vec(c->stream, c->cwsq, c->cw, c->N));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->weighted = true;
+    c->last_psum.clear();
+    return MBAR_OK;
+}
+
+int mbar_bootstrap_draws(uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states, const int64_t* order, int64_t* rints_out) {
+    if (!cumN || !rints_out || K_states < 1 || replicate < 0 || cumN[0] != 0) return fail(nullptr, MBAR_ERR_ARG, "mbar_bootstrap_draws: bad argument");
+    for (int64_t k = 0; k < K_states; ++k) {
+        const int64_t start = cumN[k], nk = cumN[k + 1] - start;
+        if (nk < 0) return fail(nullptr, MBAR_ERR_ARG, "mbar_bootstrap_draws: cumN must not decrease");
+        for (int64_t i = 0; i < nk; ++i) {
+            const int64_t pos = start + bootstrap_draw(seed, (uint64_t)replicate, (uint64_t)(start + i), (uint64_t)nk);
+            const int64_t slot_sample = order ? order[start + i] : start + i;
+            rints_out[slot_sample] = order ? order[pos] : pos;
+        }
+    }
     return MBAR_OK;
 }
 

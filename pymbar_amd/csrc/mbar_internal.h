@@ -24,6 +24,25 @@ inline int lse_nb_for(int64_t Kp) {
     return 0;
 }
 
+// Bootstrap draws as a counter-based stream (mbar_ctx_draw_bootstrap_weights on the device, mbar_bootstrap_draws on the host: the
+// same function of (seed, replicate, slot)): slot j of a state with n samples draws position bootstrap_draw(...) in [0, n).
+// Two rounds of the splitmix64 finaliser over key and counter; the range reduction is a 64 x 64 -> high-64 multiply (bias <= n / 2^64).
+#if defined(__HIPCC__)
+#define MBAR_HD __host__ __device__
+#else
+#define MBAR_HD
+#endif
+MBAR_HD inline uint64_t bootstrap_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+MBAR_HD inline int64_t bootstrap_draw(uint64_t seed, uint64_t replicate, uint64_t slot, uint64_t n) {
+    const uint64_t key = bootstrap_mix64(seed + 0x9E3779B97F4A7C15ull * (replicate + 1));
+    const uint64_t z = bootstrap_mix64(bootstrap_mix64(key ^ (slot * 0xD1342543DE82EF95ull)) + slot);
+    return (int64_t)(((unsigned __int128)z * (unsigned __int128)n) >> 64);
+}
+
 // Control words of the device-resident solver loop (ints in device memory).  Kernels that are handed a pointer to them
 // exit at once when CTL_DONE is set (iterations enqueued past convergence are no-ops) and pick the logden vector of the
 // current f from three rotating slots (base + slot * slot_stride), so that a whole iteration can be enqueued -- or
@@ -184,6 +203,10 @@ struct SciLoopArgs {
 hipError_t launch_sci_small(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* cw,
                             const SciLoopArgs& q);
 // (*overflow, zeroed by the caller, is set when a weight is not finite)
+// cw[sample] += 1 for every draw of the replicate whose sample lies in this shard [n0, n0 + N) (cw zeroed by the caller; the adds are
+// of exact small integers: order-independent).  cum: [K + 1] positions of the states' runs; order: sample index of a position, or NULL
+hipError_t launch_bootstrap_counts(hipStream_t s, uint64_t seed, int64_t replicate, const int64_t* cum, int64_t K, int64_t total,
+                                   const int64_t* order, int64_t n0, int64_t N, double* cw);
 hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int64_t n, double* cw, double* cwsq, int* overflow);
 hipError_t launch_reduce_level1(hipStream_t s, const double* part, int64_t nparts, int64_t count, double* out,
                                 int64_t* nchunks);

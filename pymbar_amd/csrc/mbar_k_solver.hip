@@ -1405,6 +1405,30 @@ hipError_t launch_weights_from_log(hipStream_t s, const double* v, double p, int
     hipLaunchKernelGGL(k_weights_from_log, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, v, p, n, cw, cwsq, overflow);
     return hipGetLastError();
 }
+// One bootstrap replicate as draw counts (mbar.py:417-449: every state redraws its N_k samples from its own samples): slot j of the
+// state whose run of positions contains j draws one of that run's positions; the sample there gets one more count.
+__global__ void __launch_bounds__(256)
+k_bootstrap_counts(uint64_t seed, int64_t replicate, const int64_t* __restrict__ cum, int64_t K, int64_t total,
+                   const int64_t* __restrict__ order, int64_t n0, int64_t N, double* __restrict__ cw) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = K;  // the state k with cum[k] <= j < cum[k + 1] (empty states have empty runs)
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cum[mid] <= j) lo = mid; else hi = mid;
+        }
+        const int64_t start = cum[lo], nk = cum[lo + 1] - start;
+        const int64_t pos = start + bootstrap_draw(seed, (uint64_t)replicate, (uint64_t)j, (uint64_t)nk);
+        const int64_t sample = (order ? order[pos] : pos) - n0;
+        if (sample >= 0 && sample < N) atomicAdd(cw + sample, 1.0);
+    }
+}
+hipError_t launch_bootstrap_counts(hipStream_t s, uint64_t seed, int64_t replicate, const int64_t* cum, int64_t K, int64_t total,
+                                   const int64_t* order, int64_t n0, int64_t N, double* cw) {
+    int64_t bx = (total + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(k_bootstrap_counts, dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, s, seed, replicate, cum, K, total, order, n0, N, cw);
+    return hipGetLastError();
+}
 hipError_t launch_zero(hipStream_t s, void* p, size_t bytes) {
     if (bytes == 0) return hipSuccess;
     if ((bytes & 15) != 0 || ((uintptr_t)p & 15) != 0 || bytes < (size_t)1 << 16) return hipMemsetAsync(p, 0, bytes, s);

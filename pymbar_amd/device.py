@@ -201,6 +201,19 @@ class DeviceMatrix:
             raise ValueError(f"sample weights must have shape ({self.N_local},)")
         self._check(self._lib.mbar_ctx_set_sample_weights(self._ctx, _dptr(c_n)))
 
+    def draw_bootstrap_weights(self, seed, replicate, cumN, order=None, n_global0=0):
+        """Per-sample multiplicities = draw counts of bootstrap replicate ``replicate`` of the counter-based stream ``seed``, drawn
+        ON THE DEVICE (``mbar_ctx_draw_bootstrap_weights``; :func:`pymbar_amd._lib.bootstrap_draws` gives the same draws on the
+        host).  ``cumN`` (K + 1): positions of the states' runs; ``order``: sample index of a position (``None``: the default layout)."""
+        cumN = np.ascontiguousarray(cumN, dtype=np.int64)
+        ip = C.POINTER(C.c_int64)
+        optr = None
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.int64)
+            optr = order.ctypes.data_as(ip)
+        self._check(self._lib.mbar_ctx_draw_bootstrap_weights(self._ctx, C.c_uint64(int(seed)), int(replicate), cumN.ctypes.data_as(ip),
+                                                              len(cumN) - 1, optr, int(n_global0)))
+
     def weights_from_vec(self, power):
         """Per-sample weights ``(A_n - shift)**power`` from the observable ``vec_logshift`` left on the device (no upload, no host
         pass): the weighted sums of a single observable at the resident states.  ``set_sample_weights(None)`` restores 1."""

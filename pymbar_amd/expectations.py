@@ -170,7 +170,10 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
                 f_k = mbar.f_k
             else:
                 f_k = mbar.f_k_boots[n - 1, :]
-                dm.set_sample_weights(np.bincount(mbar.bootstrap_rints[n - 1], minlength=N))
+                if hasattr(mbar, "_set_bootstrap_weights"):  # (this repository's class: drawn on the device when its stream lives there)
+                    mbar._set_bootstrap_weights(dm, n - 1)
+                else:
+                    dm.set_sample_weights(np.bincount(mbar.bootstrap_rints[n - 1], minlength=N))
             f_full, lognum = _augmented_solve(dm, K, R_dm, f_k)
             f_states = np.array([-lognum[row_of_state[int(l)]] for l in state_list])
             A_i = np.array([np.exp(lognum[obs_row0 + s] - lognum[row_of_state[int(state_list[s])]]) for s in range(S)])

@@ -100,11 +100,16 @@ class MBAR:
 
     Parameters follow pymbar/mbar.py:85-99.  ``u_kn`` is (K, N) [or (K, L, N_max) ``u_kln``];
     ``N_k`` (K,) may contain zeros.  Extra keywords: ``device`` selects the GPU; ``copy=False`` keeps a read-only reference to a
-    float64 C-contiguous ``u_kn`` instead of the reference's host copy (the caller must then leave the array alone)."""
+    float64 C-contiguous ``u_kn`` instead of the reference's host copy (the caller must then leave the array alone);
+    ``bootstrap_rng``: ``"reference"`` (default) draws the bootstrap replicates with ``numpy.random.default_rng(rseed)`` exactly as
+    the reference does (mbar.py:417-449: the same ``bootstrap_rints`` and ``f_k_boots`` for the same ``rseed``), ``"device"`` draws
+    them on the GPU from a counter-based stream keyed by ``rseed`` (the same statistics, deterministic under ``rseed``, not numpy's
+    numbers; a replicate then costs its solve -- no pass over N integers on the host -- and ``bootstrap_rints`` is materialised on
+    first access)."""
 
     def __init__(self, u_kn, N_k, maximum_iterations=10000, relative_tolerance=1.0e-7, verbose=False,
                  initial_f_k=None, solver_protocol=None, initialize="zeros", x_kindices=None, n_bootstraps=0,
-                 bootstrap_solver_protocol=None, rseed=None, device=None, copy=True):
+                 bootstrap_solver_protocol=None, rseed=None, device=None, copy=True, bootstrap_rng="reference"):
         from .device import DeviceMatrix
 
         self.N_k = np.array(N_k, dtype=np.int64)
@@ -233,7 +238,32 @@ class MBAR:
         self.f_k = mbar_solvers.solve_mbar_for_all_states(self._dm, self.N_k, self.f_k, self.states_with_samples,
                                                           solver_protocol)
 
+        if bootstrap_rng not in ("reference", "device"):
+            raise ParameterError("bootstrap_rng must be 'reference' or 'device'")
         self.n_bootstraps = 0
+        self._bootstrap_stream = None   # (seed, cumN, order) of the device stream, or None: numpy's, rows stored
+        self._bootstrap_rints = None
+        if n_bootstraps > 0 and bootstrap_rng == "device" and hasattr(self._dm, "draw_bootstrap_weights"):
+            groups = _sample_groups(self.x_kindices, K)
+            if all(len(groups[k]) == int(self.N_k[k]) for k in range(K)):
+                self.n_bootstraps = n_bootstraps
+                self.f_k_boots = np.zeros([n_bootstraps, K])
+                cumN = np.concatenate(([0], np.cumsum(self.N_k))).astype(np.int64)
+                default_layout = all(isinstance(g, range) for g in groups)
+                order = None if default_layout else np.concatenate([np.asarray(g, dtype=np.int64) for g in groups])
+                seed = int(self.rng.integers(np.iinfo(np.int64).max))   # (deterministic under rseed)
+                self._bootstrap_stream = (seed, cumN, order)
+                for b in range(n_bootstraps):
+                    self._set_bootstrap_weights(self._dm, b)
+                    f_k_init = self.f_k.copy()
+                    if initialize == "BAR":
+                        f_k_init = self._initialize_with_bar(self.u_kn[:, self._bootstrap_row(b)], f_k_init=self.f_k.copy())
+                    try:
+                        self.f_k_boots[b, :] = mbar_solvers.solve_mbar_for_all_states(
+                            self._dm, self.N_k, f_k_init, self.states_with_samples, bootstrap_solver_protocol)
+                    finally:
+                        self._dm.set_sample_weights(None)
+                n_bootstraps = 0  # (done)
         if n_bootstraps > 0:
             self.n_bootstraps = n_bootstraps
             self.f_k_boots = np.zeros([n_bootstraps, K])
@@ -243,13 +273,12 @@ class MBAR:
             # rng.integers(N_k, size=N_k) per state and replicate, in state order -- is the reference's
             groups = _sample_groups(self.x_kindices, K)
             for b in range(n_bootstraps):
-                rints = np.zeros(self.N, int)
+                rints = self._bootstrap_rints[b]  # (the row is filled in place: every pass over N integers counts at N = 4e6)
                 for k in range(K):
                     k_indices = groups[k]
                     draw = self.rng.integers(int(self.N_k[k]), size=int(self.N_k[k]))
                     if isinstance(k_indices, range):  # default layout: the samples of state k are one contiguous run
-                        rints[k_indices.start:k_indices.stop] = draw
-                        rints[k_indices.start:k_indices.stop] += k_indices.start
+                        np.add(draw, k_indices.start, out=rints[k_indices.start:k_indices.stop])
                     else:
                         rints[k_indices] = k_indices[draw]
                 # a replicate is the vector of draw counts: the resident matrix is re-used, nothing is gathered
@@ -263,7 +292,6 @@ class MBAR:
                         self._dm, self.N_k, f_k_init, self.states_with_samples, bootstrap_solver_protocol)
                 finally:
                     self._dm.set_sample_weights(None)
-                self.bootstrap_rints[b, :] = rints
         elif n_bootstraps < 0:
             logger.warning("n_bootstraps must be an integer >= 0")
 
@@ -273,6 +301,37 @@ class MBAR:
             logger.info("f_k = ")
             logger.info(self.f_k)
             logger.info("MBAR initialization complete.")
+
+    # ---- bootstrap replicates -----------------------------------------------------------------------
+    @property
+    def bootstrap_rints(self):
+        """(n_bootstraps, N) resampled sample indices (mbar.py:420): stored rows with the reference's generator; with
+        ``bootstrap_rng="device"`` regenerated from the counter-based stream on first access (n_bootstraps x N integers)."""
+        if self._bootstrap_rints is None and self._bootstrap_stream is not None:
+            self._bootstrap_rints = np.stack([self._bootstrap_row(b) for b in range(self.n_bootstraps)])
+        return self._bootstrap_rints
+
+    @bootstrap_rints.setter
+    def bootstrap_rints(self, value):
+        self._bootstrap_rints = value
+
+    def _bootstrap_row(self, b):
+        """The resampled indices of replicate ``b`` (one row of ``bootstrap_rints``)."""
+        if self._bootstrap_stream is None or self._bootstrap_rints is not None:
+            return self._bootstrap_rints[b]
+        from . import _lib
+
+        seed, cumN, order = self._bootstrap_stream
+        return _lib.bootstrap_draws(seed, b, cumN, order)
+
+    def _set_bootstrap_weights(self, dm, b):
+        """Make replicate ``b`` the sample multiplicities of ``dm`` (this object's matrix, or an augmented one over the same
+        samples): drawn on the device from the counter-based stream, or the draw counts of the stored row."""
+        if self._bootstrap_stream is not None and self._bootstrap_rints is None and hasattr(dm, "draw_bootstrap_weights"):
+            seed, cumN, order = self._bootstrap_stream
+            dm.draw_bootstrap_weights(seed, b, cumN, order)
+        else:
+            dm.set_sample_weights(np.bincount(self._bootstrap_row(b), minlength=self.N))
 
     # ---- weights ----------------------------------------------------------------------------------
     @property

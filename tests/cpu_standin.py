@@ -103,6 +103,14 @@ class OracleMatrix:
             assert np.all(c == np.round(c)) and c.shape == (self.u_full.shape[1],)
             self.u = np.repeat(self.u_full, c.astype(int), axis=1)
 
+    def draw_bootstrap_weights(self, seed, replicate, cumN, order=None, n_global0=0):
+        """Model of mbar_ctx_draw_bootstrap_weights: the draw counts of the counter-based stream (the host function of the C
+        library yields the draws; it needs no GPU)."""
+        from pymbar_amd import _lib
+
+        rints = _lib.bootstrap_draws(seed, replicate, cumN, order)
+        self.set_sample_weights(np.bincount(rints, minlength=self.u_full.shape[1] if hasattr(self, "u_full") else self.u.shape[1]))
+
     def weights_from_vec(self, power):
         """Real-valued per-sample weights (A - shift)**power from the observable vec_logshift left behind (model of
         mbar_ctx_weights_from_vec): they enter the log-space numerators and the W^T W sums."""

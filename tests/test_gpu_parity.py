@@ -217,6 +217,56 @@ def test_mbar_bootstrap_on_gpu():
     b.close()
 
 
+def test_bootstrap_replicates_drawn_on_the_device(DM):
+    """mbar_ctx_draw_bootstrap_weights: the multiplicities the device draws are the draw counts of mbar_bootstrap_draws (the
+    host face of the same counter-based stream) -- for the default layout, for an order vector, on a shard (n_global0) -- and the
+    class with bootstrap_rng="device" solves those replicates (oracle on the gathered matrix), deterministic under rseed, also
+    through the bootstrap branch of the expectations."""
+    import pymbar_amd
+    from pymbar_amd import _lib
+
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn([0.0, 1.0, 2.0, 3.0], [1.0, 2.0, 3.0, 4.0], [3000, 0, 2500, 2001], seed=4)
+    N, K = u_kn.shape[1], len(N_k)
+    cum = np.concatenate(([0], np.cumsum(N_k))).astype(np.int64)
+    f = np.array([0.0, 0.3, 0.5, 0.9])
+    perm = np.random.default_rng(1).permutation(N)
+    with DM.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        for order in (None, perm):
+            for rep in (0, 1, 7):
+                dm.draw_bootstrap_weights(12345, rep, cum, order)
+                rints = _lib.bootstrap_draws(12345, rep, cum, order)
+                ps, _, _ = dm.eval(f)
+                dm.set_sample_weights(np.bincount(rints, minlength=N))
+                ps_ref, _, _ = dm.eval(f)
+                assert np.array_equal(ps[0], ps_ref[0]), (rep, order is None)   # the same integer multiplicities: the same bits
+        dm.set_sample_weights(None)
+    n0, n1 = 2048, 6016   # a shard of the same replicate
+    with DM.from_host(u_kn, columns=(n0, n1)) as sh:
+        sh.set_Nk(N_k)
+        sh.draw_bootstrap_weights(12345, 3, cum, None, n_global0=n0)
+        ps, _, _ = sh.eval(f)
+        sh.set_sample_weights(np.bincount(_lib.bootstrap_draws(12345, 3, cum), minlength=N)[n0:n1])
+        ps_ref, _, _ = sh.eval(f)
+        assert np.array_equal(ps[0], ps_ref[0])
+    a = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=4, rseed=11, bootstrap_rng="device")
+    b = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=4, rseed=11, bootstrap_rng="device")
+    assert a._bootstrap_stream is not None and a._bootstrap_rints is None
+    assert np.array_equal(a.f_k_boots, b.f_k_boots)
+    A = np.cos(x_n) + 2.0
+    ea = a.compute_expectations(A, uncertainty_method="bootstrap")     # (replicates drawn on the augmented matrix's context)
+    eb = b.compute_expectations(A, uncertainty_method="bootstrap")
+    assert np.array_equal(ea["sigma"], eb["sigma"]) and np.all(np.isfinite(ea["sigma"])) and np.all(ea["sigma"] > 0)
+    assert a._bootstrap_rints is None
+    sws = np.where(N_k > 0)[0]
+    rints = a.bootstrap_rints
+    for i in range(4):
+        fr, _ = oracle.solve_mbar_for_all_states(u_kn[:, rints[i]], N_k, a.f_k.copy(), sws, tol=1e-12, min_sc_iter=0)
+        np.testing.assert_allclose(a.f_k_boots[i], fr, rtol=1e-8, atol=1e-9)
+    a.close()
+    b.close()
+
+
 def test_two_candidates_far_apart(DM):
     """The fused two-candidate sweep derives the second candidate from the first one's exponentials through
     exp(a'_k - a_k); candidates hundreds of kT apart take the two-sweep fallback.  Both must match the oracle."""

@@ -128,6 +128,54 @@ def test_bootstrap_draws_are_the_references(golden):
     assert np.array_equal(_private_copy(big), big) and _private_copy(big) is not big
 
 
+def test_bootstrap_replicates_from_the_counter_based_stream():
+    """bootstrap_rng="device": the replicates come from the library's counter-based stream instead of numpy's generator --
+    deterministic under rseed (reference tests/test_mbar.py:533-545), every state redraws ITS OWN samples (mbar.py:425-431), the
+    lazily materialised bootstrap_rints are the draws the solves saw (oracle on the gathered matrix), for the default layout and
+    for samples interleaved through x_kindices; other seeds give other draws; the uncertainties agree with the reference stream's
+    statistically."""
+    from oracle import mbar_oracle as oracle
+    from pymbar_amd import _lib
+
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn([0.0, 1.0, 2.0, 3.0], [1.0, 2.0, 4.0, 3.0], [300, 0, 250, 200], seed=4)
+    N, K = int(np.sum(N_k)), len(N_k)
+    default = np.repeat(np.arange(K), N_k)
+    a = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=6, rseed=123, bootstrap_rng="device")
+    b = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=6, rseed=123, bootstrap_rng="device")
+    c = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=6, rseed=124, bootstrap_rng="device")
+    assert a._bootstrap_stream is not None and a._bootstrap_rints is None   # nothing of size N was kept
+    assert np.array_equal(a.f_k_boots, b.f_k_boots) and not np.array_equal(a.f_k_boots, c.f_k_boots)
+    rints = a.bootstrap_rints
+    assert rints.shape == (6, N) and np.array_equal(rints, b.bootstrap_rints) and not np.array_equal(rints, c.bootstrap_rints)
+    assert np.array_equal(default[rints], np.tile(default, (6, 1)))         # a state draws from its own samples
+    assert len({tuple(r) for r in rints}) == 6                              # replicates differ
+    sws = np.where(N_k > 0)[0]
+    for i in range(6):
+        fr, _ = oracle.solve_mbar_for_all_states(u_kn[:, rints[i]], N_k, a.f_k.copy(), sws, tol=1e-12, min_sc_iter=0)
+        np.testing.assert_allclose(a.f_k_boots[i], fr, rtol=1e-8, atol=1e-9)
+    # interleaved samples: the draws follow x_kindices
+    perm = np.random.default_rng(0).permutation(N)
+    m2 = pymbar_amd.MBAR(u_kn[:, perm], N_k, n_bootstraps=3, rseed=123, x_kindices=default[perm], bootstrap_rng="device")
+    r2 = m2.bootstrap_rints
+    assert np.array_equal(default[perm][r2], np.tile(default[perm], (3, 1)))
+    fr, _ = oracle.solve_mbar_for_all_states(u_kn[:, perm][:, r2[1]], N_k, m2.f_k.copy(), sws, tol=1e-12, min_sc_iter=0)
+    np.testing.assert_allclose(m2.f_k_boots[1], fr, rtol=1e-8, atol=1e-9)
+    # the host function: uniform within a state (chi-square of 200 000 draws over 50 positions), counts sum to N
+    cum = np.array([0, 50], dtype=np.int64)
+    draws = np.concatenate([_lib.bootstrap_draws(99, rep, cum) for rep in range(4000)])
+    counts = np.bincount(draws, minlength=50)
+    chi2 = float(np.sum((counts - counts.mean()) ** 2 / counts.mean()))
+    assert counts.sum() == 200_000 and chi2 < 100.0, chi2                   # (49 degrees of freedom: 100 is p ~ 2e-5)
+    # statistically the same uncertainties as with the reference's generator
+    ref = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=200, rseed=5)
+    dev = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=200, rseed=5, bootstrap_rng="device")
+    s_ref = ref.compute_free_energy_differences(uncertainty_method="bootstrap")["dDelta_f"][0, 3]
+    s_dev = dev.compute_free_energy_differences(uncertainty_method="bootstrap")["dDelta_f"][0, 3]
+    assert abs(s_dev - s_ref) < 0.25 * s_ref, (s_dev, s_ref)
+    with pytest.raises(ParameterError):
+        pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=2, bootstrap_rng="numpy")
+
+
 def test_initialize_bar_and_unnormalized_log_weights(golden):
     """initialize="BAR" feeds the solver the chained pairwise guess (tests/golden/bar_init.npz holds the reference's
     values); _computeUnnormalizedLogWeights is the reference's one-line logsumexp (mbar.py:1919-1934)."""

@@ -38,6 +38,7 @@ def ctor():
         x_n, u_kn, N_k = problem(K, N)
         out = []
         for label, kw in (("MBAR(u_kn, N_k)", {}), ("copy=False", dict(copy=False)), ("n_bootstraps=10", dict(n_bootstraps=10)),
+                          ("n_bootstraps=10, bootstrap_rng='device'", dict(n_bootstraps=10, bootstrap_rng="device")),
                           ('initialize="BAR"', dict(initialize="BAR"))):
             m = pymbar_amd.MBAR(u_kn, N_k, **kw)
             m.close()
