@@ -14,10 +14,12 @@ LIB = os.path.join(CSRC, "libmbar_hip.so")
 # Kernel families in separate translation units (compiled in parallel: ~40 s on 8 cores instead of 2.5 min for the one file of
 # rounds 1-3; an edit to one family recompiles that family): shared device helpers in mbar_device.h.
 KERNEL_SOURCES = ["mbar_k_eval.hip", "mbar_k_gram.hip", "mbar_k_quad.hip", "mbar_k_pmode.hip", "mbar_k_fused.hip", "mbar_k_solver.hip"]
-SOURCES = KERNEL_SOURCES + ["mbar_capi.cpp"]
+HOST_SOURCES = ["mbar_capi.cpp", "mbar_loops.cpp", "mbar_comm.cpp", "mbar_host.cpp"]  # (shared internal header: mbar_ctx.h)
+SOURCES = KERNEL_SOURCES + HOST_SOURCES
 COMMON_DEPS = ["mbar_internal.h", os.path.join("..", "..", "include", "mbar_hip.h")]
+HOST_DEPS = ["mbar_ctx.h"]
 KERNEL_DEPS = ["mbar_device.h", "exp2_table.inc", "log_table.inc"]
-DEPS = SOURCES + COMMON_DEPS + KERNEL_DEPS
+DEPS = SOURCES + COMMON_DEPS + KERNEL_DEPS + HOST_DEPS
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -31,7 +33,7 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-    deps = [src] + COMMON_DEPS + (KERNEL_DEPS if src in KERNEL_SOURCES else [])
+    deps = [src] + COMMON_DEPS + (KERNEL_DEPS if src in KERNEL_SOURCES else HOST_DEPS)
     if _stale(obj, deps):
         cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         subprocess.run(cmd, check=True, cwd=CSRC)

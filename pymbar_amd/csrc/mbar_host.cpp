@@ -1,0 +1,427 @@
+// Host-only parts of libmbar_hip.so: the state of the caching allocator, the K x K linear algebra of the host-driven loop (Cholesky
+// factorisation of the gauge-fixed Hessian -- blocked and threaded from 320 / 448 unknowns -- with a Jacobi pseudo-inverse
+// fallback: the minimum-norm semantics of numpy.linalg.lstsq, mbar_solvers.py:582-583), the content digest behind the resident
+// cache of host matrices, and the host face of the bootstrap stream.  Nothing here touches a kernel.
+#include "mbar_ctx.h"
+
+using namespace mbar;
+using namespace mbar::host;
+
+namespace mbar {
+namespace host {
+
+thread_local std::string g_last_error;
+MemCache g_mem;
+std::atomic<int> g_live_contexts{0};
+std::mutex g_dev_mu;
+std::map<int, DevInfo> g_dev_info;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- dense K x K helpers (host) ---------------------------------------------------------------
+// Cholesky solve of A x = b (A m x m SPD, row-major, destroyed).  Returns false on breakdown.
+bool chol_solve(std::vector<double>& A, std::vector<double>& b, int m) {
+    // pivots below eps * m * (largest diagonal entry) count as zero, like the singular values numpy.linalg.lstsq drops
+    // (mbar_solvers.py:582, rcond = machine precision): a state whose weights underflow leaves a row of H at ~1e-300, and
+    // dividing by it would throw the Newton candidate to +-inf where lstsq returns a zero component
+    double dmax = 0.0;
+    for (int j = 0; j < m; ++j) dmax = std::max(dmax, A[(size_t)j * m + j]);
+    const double thr = dmax * std::numeric_limits<double>::epsilon() * m;
+    // Right-looking, panels of 4 columns: the trailing update is a rank-4 update whose inner loops run along rows without a
+    // reduction, so the compiler vectorises them as they stand (255 unknowns: 0.57 ms against 1.38 ms for the dot-product form
+    // -- at 129..256 states, where the loop is host-driven, this solve was most of the time between two sweeps).
+    constexpr int P = 4;
+    std::vector<double> col((size_t)P * m);
+    for (int j0 = 0; j0 < m; j0 += P) {
+        const int j1 = std::min(j0 + P, m);
+        for (int c = j0; c < j1; ++c) {
+            double d = A[(size_t)c * m + c];
+            if (!(d > thr) || !std::isfinite(d)) return false;
+            d = std::sqrt(d);
+            A[(size_t)c * m + c] = d;
+            const double inv = 1.0 / d;
+            double* cc = col.data() + (size_t)(c - j0) * m;
+            for (int i = c + 1; i < m; ++i) cc[i] = (A[(size_t)i * m + c] *= inv);
+            for (int i = c + 1; i < m; ++i) {  // the rest of the panel's columns
+                const double li = cc[i];
+                double* row = A.data() + (size_t)i * m;
+                const int kend = std::min(i, j1 - 1);
+                for (int k = c + 1; k <= kend; ++k) row[k] -= li * cc[k];
+            }
+        }
+        if (j1 - j0 == P) {  // (a short last panel has no trailing block)
+            const double *c0 = col.data(), *c1 = c0 + m, *c2 = c1 + m, *c3 = c2 + m;
+            for (int i = j1; i < m; ++i) {
+                const double l0 = c0[i], l1 = c1[i], l2 = c2[i], l3 = c3[i];
+                double* row = A.data() + (size_t)i * m;
+                for (int k = j1; k <= i; ++k) row[k] -= l0 * c0[k] + l1 * c1[k] + l2 * c2[k] + l3 * c3[k];
+            }
+        }
+    }
+    for (int i = 0; i < m; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= A[(size_t)i * m + k] * b[k];
+        b[i] = s / A[(size_t)i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < m; ++k) s -= A[(size_t)k * m + i] * b[k];
+        b[i] = s / A[(size_t)i * m + i];
+    }
+    for (int i = 0; i < m; ++i)
+        if (!std::isfinite(b[i])) return false;
+    return true;
+}
+
+// The same factorisation for the state counts whose K x K solve stays on the host (more than 256 states): blocks of CHOL_BLOCK
+// columns, the rows below the diagonal block shared out over a team of host threads in chunks of eight (one cache line of a block
+// column).  A row below the block depends on the block's own factor only (phase 1: its entries in the block's columns -- a
+// triangular solve against the diagonal block) and then on the finished block columns of the rows above it (phase 2: the
+// rank-CHOL_BLOCK update of its trailing entries).  Phase 2 of one block and phase 1 of the next touch the same rows, so a thread
+// runs them back to back and a block costs ONE barrier; the caller's thread updates and factors the next diagonal block first and
+// publishes it while the others are still in phase 2.  Every entry receives the same operations in the same order whatever the
+// number of threads: results do not depend on it.  (The rank-8 row update is where the flops are: compiled a second and third time
+// for AVX2 + FMA and AVX-512 and chosen at run time -- the library itself is built for baseline x86-64.)
+#define MBAR_ROW_UPDATE8_BODY                                                                                                  \
+    const double *c0 = cb, *c1 = cb + ms, *c2 = cb + 2 * ms, *c3 = cb + 3 * ms, *c4 = cb + 4 * ms, *c5 = cb + 5 * ms,         \
+                 *c6 = cb + 6 * ms, *c7 = cb + 7 * ms;                                                                         \
+    const double l0 = c0[i], l1 = c1[i], l2 = c2[i], l3 = c3[i], l4 = c4[i], l5 = c5[i], l6 = c6[i], l7 = c7[i];               \
+    for (int k = k0; k <= k1; ++k)                                                                                             \
+        row[k] -= ((l0 * c0[k] + l1 * c1[k]) + (l2 * c2[k] + l3 * c3[k])) + ((l4 * c4[k] + l5 * c5[k]) + (l6 * c6[k] + l7 * c7[k]));
+void row_update8_base(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
+    MBAR_ROW_UPDATE8_BODY
+}
+__attribute__((target("avx2,fma")))
+void row_update8_avx2(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
+    MBAR_ROW_UPDATE8_BODY
+}
+__attribute__((target("avx512f")))
+void row_update8_avx512(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
+    MBAR_ROW_UPDATE8_BODY
+}
+#undef MBAR_ROW_UPDATE8_BODY
+constexpr int CHOL_BLOCK = 32;
+constexpr int CHOL_BLOCKED_MIN = 320;   // unknowns from which the blocked form is used ...
+constexpr int CHOL_THREADED_MIN = 448;  // ... and from which it is worth a team (below: one thread, same code)
+int host_team_size(int m) {
+    if (m < CHOL_THREADED_MIN) return 1;
+    int t = (int)std::thread::hardware_concurrency();
+    {   // (the cores this process may actually run on: a container or taskset may leave it fewer than the machine has, and a
+        // spinning team larger than that only takes turns)
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) t = std::min(t > 0 ? t : 1 << 20, (int)CPU_COUNT(&set));
+    }
+    if (const char* e = std::getenv("MBAR_HOST_THREADS")) t = std::atoi(e);
+    t = std::max(1, std::min(t, 16));
+    return std::min(t, std::max(1, m / 96));
+}
+bool chol_solve_blocked(std::vector<double>& A, std::vector<double>& b, int m, int threads) {
+    double dmax = 0.0;
+    for (int j = 0; j < m; ++j) dmax = std::max(dmax, A[(size_t)j * m + j]);
+    const double thr = dmax * std::numeric_limits<double>::epsilon() * m;
+    constexpr int B = CHOL_BLOCK;
+    const size_t ms = ((size_t)m + 7) & ~(size_t)7;  // padded length of a block column: chunks of 8 rows = whole cache lines
+    struct Free { void operator()(void* q) const { std::free(q); } };
+    std::unique_ptr<double, Free> colmem((double*)std::aligned_alloc(64, 2 * (size_t)B * ms * sizeof(double)));
+    if (!colmem) return false;
+    double* const colbuf[2] = {colmem.get(), colmem.get() + (size_t)B * ms};  // colbuf[block & 1][c * ms + i] = L[i][j0 + c]
+    double Lt[B * B];  // the current diagonal block's factor, transposed: Lt[c * B + k] = L[j0 + k][j0 + c]
+    const auto update8 = __builtin_cpu_supports("avx512f") ? row_update8_avx512
+                         : (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? row_update8_avx2 : row_update8_base;
+    const int T = std::max(1, threads);
+    const int nblk = (m + B - 1) / B;
+    std::atomic<int> diag_ready{-1}, arrived{0}, failed{0};
+    auto spin_until = [&](auto&& cond) {
+        int spins = 0;
+        while (!cond())
+            if (++spins > 8192) std::this_thread::yield();
+    };
+    // rows [i_lo, i_hi) owned by thread t: chunks of eight by absolute row index, dealt round-robin
+    auto for_my_rows = [&](int t, int i_lo, auto&& fn) {
+        for (int q = i_lo / 8; q * 8 < m; ++q) {
+            if (q % T != t) continue;
+            for (int i = std::max(q * 8, i_lo); i < std::min(q * 8 + 8, m); ++i) fn(i);
+        }
+    };
+    auto phase2_row = [&](int i, int bi_prev) {  // trailing entries of row i: columns j1(prev) .. i
+        const int k0 = (bi_prev + 1) * B;
+        double* row = A.data() + (size_t)i * m;
+        const double* cb = colbuf[bi_prev & 1];
+        for (int c = 0; c < B; c += 8) update8(row, cb + (size_t)c * ms, ms, i, k0, i);
+    };
+    auto phase1_row = [&](int i, int bi) {  // row i of the triangular solve x L_block^T = A[i, block], column by column
+        const int j0 = bi * B, jb = std::min(B, m - j0);
+        double* rb = A.data() + (size_t)i * m + j0;
+        double* cb = colbuf[bi & 1];
+        for (int c = 0; c < jb; ++c) {
+            const double v = rb[c] / Lt[c * B + c];
+            rb[c] = v;
+            cb[(size_t)c * ms + i] = v;
+            const double* lt = Lt + c * B;  // lt[k] = L[j0 + k][j0 + c]
+            for (int k = c + 1; k < jb; ++k) rb[k] -= v * lt[k];
+        }
+    };
+    auto factor_diag = [&](int bi) -> bool {  // plain column Cholesky of the B x B block, then its transpose for phase 1
+        const int j0 = bi * B, j1 = std::min(j0 + B, m);
+        for (int c = j0; c < j1; ++c) {
+            double* rc_ = A.data() + (size_t)c * m;
+            double d = rc_[c];
+            for (int k = j0; k < c; ++k) d -= rc_[k] * rc_[k];
+            if (!(d > thr) || !std::isfinite(d)) return false;
+            d = std::sqrt(d);
+            rc_[c] = d;
+            for (int i = c + 1; i < j1; ++i) {
+                double* ri = A.data() + (size_t)i * m;
+                double v = ri[c];
+                for (int k = j0; k < c; ++k) v -= ri[k] * rc_[k];
+                ri[c] = v / d;
+            }
+        }
+        for (int c = 0; c < j1 - j0; ++c)
+            for (int k = c; k < j1 - j0; ++k) Lt[c * B + k] = A[(size_t)(j0 + k) * m + j0 + c];
+        return true;
+    };
+    auto run = [&](int t) {
+        for (int bi = 0; bi < nblk; ++bi) {
+            const int j1 = std::min((bi + 1) * B, m);
+            if (t == 0) {
+                if (bi > 0)
+                    for (int i = bi * B; i < j1; ++i) phase2_row(i, bi - 1);  // the next diagonal block's rows first
+                if (!factor_diag(bi)) {
+                    failed.store(1, std::memory_order_release);
+                    return;
+                }
+                diag_ready.store(bi, std::memory_order_release);
+            }
+            if (j1 >= m) return;  // (the last block has no rows below it)
+            if (bi > 0) for_my_rows(t, j1, [&](int i) { phase2_row(i, bi - 1); });
+            if (t != 0) {
+                spin_until([&]() { return diag_ready.load(std::memory_order_acquire) >= bi || failed.load(std::memory_order_acquire); });
+                if (failed.load(std::memory_order_acquire)) return;
+            }
+            for_my_rows(t, j1, [&](int i) { phase1_row(i, bi); });
+            arrived.fetch_add(1, std::memory_order_acq_rel);
+            spin_until([&]() { return arrived.load(std::memory_order_acquire) >= T * (bi + 1) || failed.load(std::memory_order_acquire); });
+            if (failed.load(std::memory_order_acquire)) return;
+        }
+    };
+    const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
+    const double t_begin = dbg ? now_ms() : 0.0;
+    {
+        std::vector<std::thread> team;
+        for (int t = 1; t < T; ++t) team.emplace_back(run, t);
+        run(0);
+        for (auto& th : team) th.join();
+    }
+    if (dbg) std::fprintf(stderr, "[mbar] blocked Cholesky m=%d, %d threads: factorisation %.3f ms\n", m, T, now_ms() - t_begin);
+    if (failed.load()) return false;
+    for (int i = 0; i < m; ++i) {  // L y = b
+        double s = b[i];
+        const double* row = A.data() + (size_t)i * m;
+        for (int k = 0; k < i; ++k) s -= row[k] * b[k];
+        b[i] = s / row[i];
+    }
+    for (int i = m - 1; i >= 0; --i) {  // L^T x = y, along the rows of L
+        const double* row = A.data() + (size_t)i * m;
+        const double xi = b[i] / row[i];
+        b[i] = xi;
+        for (int k = 0; k < i; ++k) b[k] -= row[k] * xi;
+    }
+    for (int i = 0; i < m; ++i)
+        if (!std::isfinite(b[i])) return false;
+    return true;
+}
+
+// Cyclic Jacobi eigendecomposition of a symmetric matrix: A = V diag(w) V^T.
+void jacobi_eigh(std::vector<double> A, int m, std::vector<double>& w, std::vector<double>& V) {
+    V.assign((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i) V[(size_t)i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < m; ++i) {
+            diag += A[(size_t)i * m + i] * A[(size_t)i * m + i];
+            for (int j = i + 1; j < m; ++j) off += A[(size_t)i * m + j] * A[(size_t)i * m + j];
+        }
+        if (off <= 1e-30 * (diag + 1e-300)) break;
+        for (int p = 0; p < m - 1; ++p)
+            for (int q = p + 1; q < m; ++q) {
+                const double apq = A[(size_t)p * m + q];
+                if (apq == 0.0) continue;
+                const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < m; ++k) {
+                    const double akp = A[(size_t)k * m + p], akq = A[(size_t)k * m + q];
+                    A[(size_t)k * m + p] = cs * akp - sn * akq;
+                    A[(size_t)k * m + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < m; ++k) {
+                    const double apk = A[(size_t)p * m + k], aqk = A[(size_t)q * m + k];
+                    A[(size_t)p * m + k] = cs * apk - sn * aqk;
+                    A[(size_t)q * m + k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < m; ++k) {
+                    const double vkp = V[(size_t)k * m + p], vkq = V[(size_t)k * m + q];
+                    V[(size_t)k * m + p] = cs * vkp - sn * vkq;
+                    V[(size_t)k * m + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    w.resize(m);
+    for (int i = 0; i < m; ++i) w[i] = A[(size_t)i * m + i];
+}
+
+// Newton direction: x = H^+ g - (H^+ g)[0]  (mbar_solvers.py:582-583).  H is PSD with null vector 1;
+// fixing x[0] = 0 and solving the (m-1) x (m-1) SPD system gives the same vector.  If that system is
+// not positive definite (disconnected states), fall back to the minimum-norm pseudo-inverse solution.
+void newton_direction(const std::vector<double>& H, const std::vector<double>& g, int m, std::vector<double>& x) {
+    x.assign(m, 0.0);
+    if (m <= 1) return;
+    const int r = m - 1;
+    std::vector<double> A((size_t)r * r), b(r);
+    for (int i = 0; i < r; ++i) {
+        b[i] = g[i + 1];
+        for (int j = 0; j < r; ++j) A[(size_t)i * r + j] = H[(size_t)(i + 1) * m + (j + 1)];
+    }
+    if (r >= CHOL_BLOCKED_MIN ? chol_solve_blocked(A, b, r, host_team_size(r)) : chol_solve(A, b, r)) {
+        for (int i = 0; i < r; ++i) x[i + 1] = b[i];
+        return;
+    }
+    std::vector<double> w, V;
+    jacobi_eigh(H, m, w, V);
+    double wmax = 0.0;
+    for (double v : w) wmax = std::max(wmax, std::fabs(v));
+    const double cut = wmax * std::numeric_limits<double>::epsilon() * m;
+    std::vector<double> y(m, 0.0);
+    for (int e = 0; e < m; ++e) {
+        if (std::fabs(w[e]) <= cut) continue;
+        double proj = 0.0;
+        for (int k = 0; k < m; ++k) proj += V[(size_t)k * m + e] * g[k];
+        proj /= w[e];
+        for (int k = 0; k < m; ++k) y[k] += V[(size_t)k * m + e] * proj;
+    }
+    for (int k = 0; k < m; ++k) x[k] = y[k] - y[0];
+}
+
+
+
+}  // namespace host
+}  // namespace mbar
+
+extern "C" {
+
+int mbar_cache_trim(void) {
+    g_mem.trim();
+    return MBAR_OK;
+}
+
+// ---- content digest of a host buffer ------------------------------------------------------------------------------------
+// The module-level functions of the reference are pure functions of their arguments (mbar_solvers.py:260-292): a caller may edit
+// u_kn in place between two calls.  The Python side keeps device copies of recently seen host matrices and has to know whether
+// the bytes behind an address are still the bytes it uploaded; this is that test, at memory speed on all host cores.
+// 128 bits: every 1 MiB chunk runs four independent 64-bit lanes acc <- rotl(acc ^ w, 29) * ODD over its 8-byte words (a
+// bijection of acc for a fixed word and injective in the word for a fixed acc, so a change of ONE word always changes its
+// lane), the lanes fold into two words by maps that are injective in each lane, and the chunk digests are chained in chunk
+// order by the same step with two different multipliers.  A single changed element is therefore ALWAYS detected; an arbitrary
+// multi-element change escapes with probability ~2^-128.  Not cryptographic (nobody is forging matrices).
+namespace {
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+constexpr uint64_t DG_M0 = 0x9E3779B97F4A7C15ull, DG_M1 = 0xC2B2AE3D27D4EB4Full, DG_M2 = 0x165667B19E3779F9ull,
+                   DG_M3 = 0xD6E8FEB86659FD93ull;
+constexpr int64_t DG_CHUNK = 1 << 20;
+
+void digest_chunk(const unsigned char* p, int64_t n, uint64_t out[2]) {
+    uint64_t a0 = DG_M0 ^ (uint64_t)n, a1 = DG_M1, a2 = DG_M2, a3 = DG_M3;
+    int64_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        a0 = rotl64(a0 ^ w[0], 29) * DG_M1;
+        a1 = rotl64(a1 ^ w[1], 29) * DG_M2;
+        a2 = rotl64(a2 ^ w[2], 29) * DG_M3;
+        a3 = rotl64(a3 ^ w[3], 29) * DG_M0;
+    }
+    if (i < n) {  // tail: zero-padded (the length is part of the seed)
+        uint64_t w[4] = {0, 0, 0, 0};
+        std::memcpy(w, p + i, (size_t)(n - i));
+        a0 = rotl64(a0 ^ w[0], 29) * DG_M1;
+        a1 = rotl64(a1 ^ w[1], 29) * DG_M2;
+        a2 = rotl64(a2 ^ w[2], 29) * DG_M3;
+        a3 = rotl64(a3 ^ w[3], 29) * DG_M0;
+    }
+    out[0] = a0 ^ rotl64(a1, 13) ^ rotl64(a2, 29) ^ rotl64(a3, 47);
+    out[1] = a0 * DG_M2 + a1 * DG_M3 + a2 * DG_M0 + a3 * DG_M1;
+}
+}  // namespace
+
+int mbar_host_digest(const void* data, int64_t nbytes, int threads, uint64_t* out2) {
+    if ((!data && nbytes > 0) || nbytes < 0 || !out2) return fail(nullptr, MBAR_ERR_ARG, "mbar_host_digest: bad argument");
+    const unsigned char* p = (const unsigned char*)data;
+    const int64_t nchunks = (nbytes + DG_CHUNK - 1) / DG_CHUNK;
+    std::vector<uint64_t> part((size_t)nchunks * 2);
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)nt, (int64_t)64, nchunks / 8}));  // (>= 8 MiB per thread)
+    auto work = [&](int t) {
+        for (int64_t c = t; c < nchunks; c += nt)
+            digest_chunk(p + c * DG_CHUNK, std::min<int64_t>(DG_CHUNK, nbytes - c * DG_CHUNK), &part[(size_t)c * 2]);
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    uint64_t h0 = DG_M3 ^ (uint64_t)nbytes, h1 = DG_M2 + (uint64_t)nbytes;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        h0 = rotl64(h0 ^ part[(size_t)c * 2], 31) * DG_M0;
+        h1 = rotl64(h1 ^ part[(size_t)c * 2 + 1], 27) * DG_M1;
+    }
+    out2[0] = h0 ^ (h0 >> 32);
+    out2[1] = h1 ^ (h1 >> 29);
+    return MBAR_OK;
+}
+
+int mbar_host_newton_direction(const double* H, const double* g, int m, int threads, double* x) {
+    if (!H || !g || !x || m < 1) return fail(nullptr, MBAR_ERR_ARG, "mbar_host_newton_direction: bad argument");
+    std::vector<double> Hv(H, H + (size_t)m * m), gv(g, g + m), xv;
+    if (threads != 0) {  // (test hook: the blocked factorisation with a given team size, whatever m; < 0: the panels-of-4 form)
+        const int r = m - 1;
+        std::vector<double> A((size_t)r * r), b(r);
+        for (int i = 0; i < r; ++i) {
+            b[i] = gv[i + 1];
+            for (int j = 0; j < r; ++j) A[(size_t)i * r + j] = Hv[(size_t)(i + 1) * m + (j + 1)];
+        }
+        if (r > 0 && (threads > 0 ? chol_solve_blocked(A, b, r, threads) : chol_solve(A, b, r))) {
+            x[0] = 0.0;
+            for (int i = 0; i < r; ++i) x[i + 1] = b[i];
+            return MBAR_OK;
+        }
+    }
+    newton_direction(Hv, gv, m, xv);
+    std::copy(xv.begin(), xv.end(), x);
+    return MBAR_OK;
+}
+
+int mbar_bootstrap_draws(uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states, const int64_t* order, int64_t* rints_out) {
+    if (!cumN || !rints_out || K_states < 1 || replicate < 0 || cumN[0] != 0) return fail(nullptr, MBAR_ERR_ARG, "mbar_bootstrap_draws: bad argument");
+    for (int64_t k = 0; k < K_states; ++k) {
+        const int64_t start = cumN[k], nk = cumN[k + 1] - start;
+        if (nk < 0) return fail(nullptr, MBAR_ERR_ARG, "mbar_bootstrap_draws: cumN must not decrease");
+        for (int64_t i = 0; i < nk; ++i) {
+            const int64_t pos = start + bootstrap_draw(seed, (uint64_t)replicate, (uint64_t)(start + i), (uint64_t)nk);
+            const int64_t slot_sample = order ? order[start + i] : start + i;
+            rints_out[slot_sample] = order ? order[pos] : pos;
+        }
+    }
+    return MBAR_OK;
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
-// Internal interface between the host C-ABI (mbar_capi.cpp) and the gfx950 kernels
-// (mbar_kernels.hip).  Not part of the public ABI.
+// Internal interface between the host side (mbar_capi.cpp, mbar_loops.cpp, mbar_comm.cpp, mbar_host.cpp; their shared header is
+// mbar_ctx.h) and the gfx950 kernels (mbar_k_*.hip).  Not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
