@@ -278,6 +278,26 @@ class HostGroup:
         self.close()
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on the process's STDOUT when its first communicator is initialised; a launcher that parses
+    rank 0's standard output (bench.py prints ONE JSON line there) must not find it: file descriptor 1 points at stderr meanwhile."""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def attach_allreduce(dm, group, prefer="rccl"):
     """Give ``dm`` its cross-rank reduction over the ranks of ``group``.  Returns "none", "rccl" or "host".
 
@@ -302,7 +322,8 @@ def attach_allreduce(dm, group, prefer="rccl"):
                 from . import _lib
 
                 buf = C.create_string_buffer(128)
-                _lib.check(_lib.load_library().mbar_comm_unique_id(buf))
+                with _StdoutToStderr():
+                    _lib.check(_lib.load_library().mbar_comm_unique_id(buf))
                 payload = bytes(buf.raw)
             except Exception as exc:  # pragma: no cover - needs RCCL
                 logger.warning("RCCL unique id could not be created (%s); using the host all-reduce", exc)
@@ -311,7 +332,8 @@ def attach_allreduce(dm, group, prefer="rccl"):
         ok = payload is not None
         if ok:
             try:
-                dm.comm_init_rccl(payload, rank, nranks)
+                with _StdoutToStderr():
+                    dm.comm_init_rccl(payload, rank, nranks)
             except Exception as exc:  # pragma: no cover - needs several GPUs
                 logger.warning("RCCL initialisation failed on rank %d (%s); using the host all-reduce", rank, exc)
                 my_error = f"rank {rank}: ncclCommInitRank: {exc}"

@@ -28,7 +28,14 @@ def main():
             its.append(cur)
             cur = []
     seqs = collections.Counter(tuple(n for n, _, _ in it) for it in its)
-    seq, cnt = seqs.most_common(1)[0]
+    # (a bench run holds several loops -- config 3's, config 5's, ...: one block of tables per launch sequence, the most frequent four)
+    for seq, cnt in seqs.most_common(4):
+        if cnt < 3:
+            continue
+        report(its, seq)
+
+
+def report(its, seq):
     # (iterations past convergence are no-ops of a few microseconds: keep those whose longest kernel is a real sweep)
     sel = [it for it in its if tuple(n for n, _, _ in it) == seq and max(d for _, d, _ in it) > 100.0]
     if not sel:
