@@ -982,6 +982,9 @@ int mbar_ctx_draw_bootstrap_weights(mbar_ctx* c, uint64_t seed, int64_t replicat
         dg[1] = a[1] ^ (b[1] * 0xC2B2AE3D27D4EB4Full) ^ (order ? 1u : 0u);
     }
     if (!c->boot_idx || c->boot_idx_words != words || c->boot_layout_digest[0] != dg[0] || c->boot_layout_digest[1] != dg[1]) {
+        if (order)
+            for (int64_t p = 0; p < total; ++p)
+                if (order[p] < 0 || order[p] >= total) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: order entry out of range");
         if (c->boot_idx && c->boot_idx_words < words) {
             (void)cache_free(c->boot_idx);
             c->boot_idx = nullptr;

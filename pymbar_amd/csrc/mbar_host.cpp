@@ -412,9 +412,13 @@ int mbar_host_newton_direction(const double* H, const double* g, int m, int thre
 
 int mbar_bootstrap_draws(uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states, const int64_t* order, int64_t* rints_out) {
     if (!cumN || !rints_out || K_states < 1 || replicate < 0 || cumN[0] != 0) return fail(nullptr, MBAR_ERR_ARG, "mbar_bootstrap_draws: bad argument");
+    for (int64_t k = 0; k < K_states; ++k)
+        if (cumN[k + 1] < cumN[k]) return fail(nullptr, MBAR_ERR_ARG, "mbar_bootstrap_draws: cumN must not decrease");
+    if (order)  // (the positions index the output: a stray entry would write outside it)
+        for (int64_t p = 0; p < cumN[K_states]; ++p)
+            if (order[p] < 0 || order[p] >= cumN[K_states]) return fail(nullptr, MBAR_ERR_ARG, "mbar_bootstrap_draws: order entry out of range");
     for (int64_t k = 0; k < K_states; ++k) {
         const int64_t start = cumN[k], nk = cumN[k + 1] - start;
-        if (nk < 0) return fail(nullptr, MBAR_ERR_ARG, "mbar_bootstrap_draws: cumN must not decrease");
         for (int64_t i = 0; i < nk; ++i) {
             const int64_t pos = start + bootstrap_draw(seed, (uint64_t)replicate, (uint64_t)(start + i), (uint64_t)nk);
             const int64_t slot_sample = order ? order[start + i] : start + i;
