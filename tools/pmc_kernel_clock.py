@@ -2,7 +2,10 @@
 contains the given substring, mean duration and mean counters over its full launches (no-op launches of the device-resident
 loop, a few microseconds each, are dropped), and the effective shader clock GRBM_GUI_ACTIVE / 8 XCDs / duration.
 
-    python tools/pmc_kernel_clock.py counter_collection.csv kernel_trace.csv k_fused [min_us]
+    python tools/pmc_kernel_clock.py counter_collection.csv kernel_trace.csv k_fused [min_us] [--json out.json]
+
+With --json the clock (and the matrix-pipe share, when SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE are there) is
+also written as a small record: bench.py quotes the latest profiles/r*_pmc_fused_clock.json as `roofline.frac_at_measured_clock`.
 """
 import collections
 import csv
@@ -10,8 +13,14 @@ import sys
 
 
 def main():
-    ctr_csv, trace_csv, needle = sys.argv[1:4]
-    min_us = float(sys.argv[4]) if len(sys.argv) > 4 else 100.0
+    argv = list(sys.argv)
+    json_out = None
+    if "--json" in argv:
+        i = argv.index("--json")
+        json_out = argv[i + 1]
+        del argv[i:i + 2]
+    ctr_csv, trace_csv, needle = argv[1:4]
+    min_us = float(argv[4]) if len(argv) > 4 else 100.0
     dur = {}
     for r in csv.DictReader(open(trace_csv)):
         if needle in r["Kernel_Name"]:
@@ -32,7 +41,15 @@ def main():
     for c in names:
         print(f"   {c:28s} {means[c]:.5g}")
     if "GRBM_GUI_ACTIVE" in means:
-        print(f"   effective clock = GRBM_GUI_ACTIVE / 8 / duration = {means['GRBM_GUI_ACTIVE'] / 8 / mean_us / 1e3:.3f} GHz")
+        ghz = means["GRBM_GUI_ACTIVE"] / 8 / mean_us / 1e3
+        print(f"   effective clock = GRBM_GUI_ACTIVE / 8 / duration = {ghz:.3f} GHz")
+        if json_out:
+            import json
+
+            rec = {"kernel": needle, "full_launches": len(full), "mean_us": mean_us, "effective_clock_GHz": ghz,
+                   "how": "rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE ...: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration (tools/pmc_kernel_clock.py)",
+                   "counters_mean_per_launch": means}
+            json.dump(rec, open(json_out, "w"), indent=1)
 
 
 if __name__ == "__main__":
