@@ -268,14 +268,18 @@ int quad_live_blocks(const mbar_ctx* c) { return c->opt_quad_trim ? (int)((c->K 
 // Results: gram blocks at red + red_off (plan order).  The per-state operand sums are not accumulated on the
 // device: rows of p sum to one (sum_k p_nk = 1, resp. sum_k N_k W_nk = 1), so they are column sums of the
 // reduced Gram matrix (gram_operand_sums below).
-int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan) {
+// pmat (or nullptr: the reduced potentials) = a resident probability matrix, `logden` then the reciprocals 1 / s_n with the
+// multiplicities' roots already folded in (P mode of the host-driven loop above 256 states: panels and rectangles only)
+int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan, const double* pmat) {
     const int64_t ntiles = (c->N + TS - 1) / TS;
-    if (c->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent
+    const double* mat = pmat ? pmat : c->u;
+    if (c->weighted && !pmat) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent
         HIPCHK(c, launch_shift_logden(c->stream, logden, c->cw, 0.5, c->N, c->lden_eff));
         logden = c->lden_eff;
     }
     for (const auto& it : plan.items) {
         if (it.diag && it.nbi > 8) {  // one read of the matrix: the four waves of a workgroup split the panel's blocks
+            if (pmat) return fail(c, MBAR_ERR_STATE, "run_gram: no P-mode form of the one-read panel outside the device-resident loop");
             LaunchGeom g = gram_quad_geometry(it.nbi, c->num_cu, ntiles, c->opt_grid);
             g.live_blocks = quad_live_blocks(c);
             const size_t rec = (size_t)it.nblk * 256;
@@ -305,12 +309,13 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
             {
                 LoopCtl lo;
                 lo.unclamped = c->u_checked && !c->u_posinf;
-                HIPCHK(c, launch_gram_diag(c->stream, it.nbi, g, c->u, c->ld, c->N, anum_dev + it.ri, logden,
+                lo.pmode = pmat != nullptr;
+                HIPCHK(c, launch_gram_diag(c->stream, it.nbi, g, mat, c->ld, c->N, anum_dev + it.ri, logden,
                                            it.ri, gp, nullptr, lo));
             }
             else
-                HIPCHK(c, launch_gram_off(c->stream, it.nbj, g, c->u, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
-                                          logden, it.ri, it.rj, gp));
+                HIPCHK(c, launch_gram_off(c->stream, it.nbj, g, mat, c->ld, c->N, anum_dev + it.ri, anum_dev + it.rj,
+                                          logden, it.ri, it.rj, gp, pmat != nullptr));
         }
         {
             ScopedTimer t(c, MBAR_TIMER_REDUCE);
@@ -626,6 +631,7 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     if (c->ad) (void)cache_free(c->ad);
     if (c->P) (void)cache_free(c->P);
     if (c->pm_vec) (void)cache_free(c->pm_vec);
+    if (c->pm_ld0) (void)cache_free(c->pm_ld0);
     if (c->part_g) (void)cache_free(c->part_g);
     if (c->cwsq) (void)cache_free(c->cwsq);
     if (c->chol) (void)cache_free(c->chol);
@@ -693,6 +699,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "light_last") c->opt_light_last = value;
     else if (k == "direct_results") c->opt_direct_results = value;
     else if (k == "sci_merged") c->opt_sci_merged = value;
+    else if (k == "host_pmode") c->opt_host_pmode = value;
     else if (k == "sci_pingpong") {
         c->opt_sci_pingpong = value;
         (void)drop_graphs(c);

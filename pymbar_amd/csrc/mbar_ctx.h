@@ -303,6 +303,7 @@ struct mbar_ctx {
     double* P = nullptr;
     bool P_failed = false;          // the allocation did not fit: stay in the classic mode for the life of the context
     double* pm_vec = nullptr;       // a0[Kp] | ccur[Kp] | cgram[Kp]
+    double* pm_ld0 = nullptr;       // host-driven loop on P (257 .. 1024 states): log-denominators at the anchor, ld doubles
     double* part_g = nullptr;       // Gram partial records of the fused-sweep loop (the psum records use `part`)
     size_t part_g_doubles = 0;
     double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
@@ -316,7 +317,7 @@ struct mbar_ctx {
     // options
     int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1, opt_direct_results = 1;
-    int64_t opt_small_balanced = 1, opt_sci_pingpong = 1;
+    int64_t opt_small_balanced = 1, opt_sci_pingpong = 1, opt_host_pmode = 1;
 
     // comm
     ncclComm_t comm = nullptr;
@@ -411,7 +412,7 @@ GramPlan gram_plan(int64_t Kp, bool quad = false);
 bool use_quad(const mbar_ctx* c);
 GramPlan plan_for(const mbar_ctx* c);
 int quad_live_blocks(const mbar_ctx* c);
-int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan);
+int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan, const double* pmat = nullptr);
 void gram_operand_sums(const double* G, int64_t K, const double* w, double* out);
 void unpack_gram(const GramPlan& plan, const double* blocks, int64_t K, double* G);
 int ensure_red(mbar_ctx* c, size_t want);

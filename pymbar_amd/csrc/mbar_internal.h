@@ -127,9 +127,10 @@ hipError_t launch_gram_diag(hipStream_t s, int nb, const LaunchGeom& g, const do
                             int64_t ld, int64_t N, const double* anum /*indexed from row0*/,
                             const double* logden, int64_t row0, double* gram_part, double* psum_part,
                             const LoopCtl& lc = LoopCtl());
+// (pmode: `u` is the resident probability matrix, `logden` the reciprocals 1 / s_n, the anum vectors are not read)
 hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, const LaunchGeom& g, const double* u, int64_t ld,
                            int64_t N, const double* anum_i, const double* anum_j, const double* logden,
-                           int64_t row_i0, int64_t row_j0, double* gram_part);
+                           int64_t row_i0, int64_t row_j0, double* gram_part, bool pmode = false);
 
 // 129 .. 256 states (nbt = 12 or 16 blocks of 16) in ONE read: the four waves of a workgroup share a tile stream and split
 // the nbt (nbt + 1) / 2 upper-triangular blocks; gram_part: [blocks][nblk][256], block b = (I, J), I <= J, row-major.
@@ -286,6 +287,8 @@ hipError_t launch_fill(hipStream_t s, double* v, double value, int64_t n);
 // zero fill at HBM write speed (hipMemsetAsync below 64 KB or for unaligned ranges)
 hipError_t launch_zero(hipStream_t s, void* p, size_t bytes);
 hipError_t launch_sqrt_vec(hipStream_t s, double* dst, const double* src, int64_t n);  // dst[i] = sqrt(src[i])
+hipError_t launch_rinv_from_logden(hipStream_t s, const double* ld0, const double* ldv, const double* cw, bool weighted, int64_t N,
+                                   double* out);
 hipError_t launch_rinv_weighted(hipStream_t s, const double* rinv, const double* cw, int64_t N, double* out,
                                 const LoopCtl& lc = LoopCtl());
 // K x K Newton system (gauge-fixed, Gauss-Jordan in registers, one workgroup) + both candidates + sweep inputs

@@ -272,7 +272,11 @@ hipError_t launch_gram_diag(hipStream_t s, int nb, const LaunchGeom& g, const do
 
 hipError_t launch_gram_off(hipStream_t s, int nbj, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                            const double* ai, const double* aj, const double* logden, int64_t ri, int64_t rj,
-                           double* gp) {
+                           double* gp, bool pmode) {
+    if (pmode) {  // resident probability matrix: one multiplication per operand element instead of an exponential
+        if (nbj == 8) return launch_gram_t<4, 8, false, true, true, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
+        return launch_gram_t<4, 4, false, true, true, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
+    }
     if (nbj == 8)  // 64 x 128 rectangle: 32 blocks, pinned accumulator classes, one 192-row tile buffer per wave
         return launch_gram_t<4, 8, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
     return launch_gram_t<4, 4, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);

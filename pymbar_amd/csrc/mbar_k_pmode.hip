@@ -31,6 +31,26 @@ k_rinv_weighted(const double* __restrict__ rinv, const double* __restrict__ cw, 
         out[n] = rinv[n] * sqrt(cw[n]);
 }
 
+// out[n] = exp(ld0[n] - ld[n]) (* sqrt(cw[n]) when weighted): the reciprocal 1 / s_n of the P-mode Gram sweep for a point f whose
+// log-denominators came from a sweep on u (the host-driven loop above 256 states): s_n = sum_k P_kn exp(a_k - a0_k) = exp(ld - ld0)
+__global__ void __launch_bounds__(256)
+k_rinv_from_logden(const double* __restrict__ ld0, const double* __restrict__ ldv, const double* __restrict__ cw, int weighted,
+                   int64_t N, double* __restrict__ out) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        double r = exp(ld0[n] - ldv[n]);
+        if (weighted) r *= sqrt(cw[n]);
+        out[n] = r;
+    }
+}
+hipError_t launch_rinv_from_logden(hipStream_t s, const double* ld0, const double* ldv, const double* cw, bool weighted, int64_t N,
+                                   double* out) {
+    int64_t bx = (N + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_rinv_from_logden, dim3((unsigned)bx), dim3(256), 0, s, ld0, ldv, cw, weighted ? 1 : 0, N, out);
+    return hipGetLastError();
+}
+
 // Build sweep of P mode: the single-candidate evaluation sweep at the anchor point a0 (log-sum-exp over states, per-state
 // sums: the solver's initial gradient) that ALSO writes the normalised probabilities P_kn = e_kn / s_n.  They go back into
 // the LDS tile in place of the energies they came from and leave with coalesced 16-byte stores that mirror the DMA

@@ -29,6 +29,43 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
     bool done = false;
     const GramPlan plan = plan_for(c);
     const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
+    // P mode of the host-driven loop (257 .. 1024 states, where this loop is the only one): the paneled Gram sweep on u spends 12
+    // row-blocks of exponentials per 32 matrix instructions (0.51-0.55 of the matrix peak).  With a resident probability matrix
+    // P = exp(a0 - u - logden(a0)) built once at the start point its operands are P_kn / s_n -- ONE multiplication -- with
+    // s_n = sum_k P_kn exp(a_k - a0_k) = exp(logden_n(f) - logden_n(a0)) from the log-denominators the evaluation sweep on u leaves
+    // anyway; the per-state factors exp(a_k - a0_k) are applied to the K x K result on the host.  One more K x N array; if it does
+    // not fit, or a state moves more than 250 kT from the anchor (then: a new anchor), the classic sweep runs.
+    const int64_t Kp = c->Kp;
+    bool hp = c->opt_pmode && c->opt_host_pmode && Kp > 256 && !c->P_failed;
+    for (const auto& item : plan.items) hp = hp && !(item.diag && item.nbi > 8);
+    std::vector<double> a0, an_host((size_t)Kp), cm((size_t)Kp, 1.0);
+    auto anchor_here = [&]() -> int {  // P at the current f (whose log-denominators are in slot `cur`)
+        if (!c->P && cache_malloc((void**)&c->P, (size_t)Kp * c->ld * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->P = nullptr;
+            c->P_failed = true;
+            hp = false;
+            return MBAR_OK;
+        }
+        if (!c->pm_ld0) HIPCHK(c, cache_malloc((void**)&c->pm_ld0, (size_t)c->ld * sizeof(double)));
+        if (!c->lden_eff) {
+            HIPCHK(c, cache_malloc((void**)&c->lden_eff, (size_t)c->ld * sizeof(double)));
+            HIPCHK(c, hipMemsetAsync(c->lden_eff, 0, (size_t)c->ld * sizeof(double), c->stream));
+        }
+        a0.assign((size_t)Kp, 0.0);
+        build_aden(c, f.data(), a0.data(), Kp);
+        std::copy(a0.begin(), a0.end(), c->hstage);
+        HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, (size_t)Kp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_make_p(c->stream, c->num_cu, c->u, c->ld, c->N, Kp, d_aden(c), c->logden[cur], c->P));
+        HIPCHK(c, hipMemcpyAsync(c->pm_ld0, c->logden[cur], (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (hstage is re-used below)
+        c->P_valid = false;  // (not the device-resident loop's warm-start matrix)
+        return MBAR_OK;
+    };
+    if (hp) {
+        rc = anchor_here();
+        if (rc) return rc;
+    }
     double tA = 0, tH = 0, tB = 0;
     const int64_t it0 = res.iterations;
     const double t0 = now_ms();
@@ -41,9 +78,28 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
             if (rc) return rc;
             std::vector<double> an((size_t)c->Kp);
             build_aden(c, f.data(), an.data(), c->Kp);
-            std::copy(an.begin(), an.end(), c->hstage + 2 * c->Kp);
-            HIPCHK(c, hipMemcpyAsync(d_anum(c), c->hstage + 2 * c->Kp, an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            rc = run_gram(c, d_anum(c), c->logden[cur], 0, plan);
+            if (hp) {  // multipliers relative to the anchor; a state that has moved too far re-anchors P at the current f
+                bool far = false;
+                for (int64_t k = 0; k < Kp; ++k) {
+                    const bool live = !std::isinf(an[k]) && !std::isinf(a0[k]);
+                    const double d = live ? an[k] - a0[k] : 0.0;
+                    if (!(std::fabs(d) < 250.0) || std::isinf(an[k]) != std::isinf(a0[k])) far = true;
+                    cm[k] = live ? std::exp(d) : 0.0;
+                }
+                if (far) {
+                    rc = anchor_here();
+                    if (rc) return rc;
+                    for (int64_t k = 0; k < Kp; ++k) cm[k] = std::isinf(a0[k]) ? 0.0 : 1.0;
+                }
+            }
+            if (hp) {
+                HIPCHK(c, launch_rinv_from_logden(c->stream, c->pm_ld0, c->logden[cur], c->cw, c->weighted, c->N, c->lden_eff));
+                rc = run_gram(c, d_anum(c), c->lden_eff, 0, plan, c->P);
+            } else {
+                std::copy(an.begin(), an.end(), c->hstage + 2 * c->Kp);
+                HIPCHK(c, hipMemcpyAsync(d_anum(c), c->hstage + 2 * c->Kp, an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                rc = run_gram(c, d_anum(c), c->logden[cur], 0, plan);
+            }
             if (rc) return rc;
             rc = allreduce_dev(c, c->red, (int64_t)total, 0);
             if (rc) return rc;
@@ -51,6 +107,9 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
             rc = sync_stream(c);
             if (rc) return rc;
             unpack_gram(plan, c->hred, K, gram.data());
+            if (hp)  // the per-state factors the P-mode sweep leaves out
+                for (int64_t i = 0; i < K; ++i)
+                    for (int64_t j = 0; j < K; ++j) gram[(size_t)i * K + j] *= cm[i] * cm[j];
         }
         const double t_a1 = now_ms();
         for (int i = 0; i < m; ++i) {

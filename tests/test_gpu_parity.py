@@ -445,7 +445,11 @@ def test_adaptive_solves_above_128_states_match_the_oracle(DM, K, N):
         start += n_k
     with DM.from_host(u_kn) as dm:
         dm.set_Nk(N_k)
-        for case in (dict(min_sc_iter=0), dict(min_sc_iter=2), dict(min_sc_iter=0, boot=True)):
+        cases = [dict(min_sc_iter=0), dict(min_sc_iter=2), dict(min_sc_iter=0, boot=True)]
+        if K > 256:  # the host-driven loop's Gram sweep on a resident probability matrix (default) and on u
+            cases += [dict(min_sc_iter=0, host_pmode=0), dict(min_sc_iter=0, boot=True, host_pmode=0)]
+        for case in cases:
+            dm.set_option("host_pmode", case.get("host_pmode", 1))
             u_or = u_kn[:, rints] if case.get("boot") else u_kn
             hist = []
             r_or = oracle.adaptive(np.ascontiguousarray(u_or[sws]), Nf, np.zeros(len(sws)), tol=tol, min_sc_iter=case["min_sc_iter"],
