@@ -121,9 +121,10 @@ int mbar_device_synchronize(int device);
  *                    (k_fused_quad; default); 0 = two sweeps on u there (what runs when P does not fit)
  *   "quad_trim"      1 = 129 .. 160 and 193 .. 224 states: the one-read Gram / fused sweeps skip the two padding blocks of the
  *                    192- / 256-row panel (default); 0 = the whole panel
- *   "host_pmode"     1 = above 256 states the host-driven loop also builds a resident probability matrix once per solve and runs its
- *                    paneled Gram sweeps on it (one multiplication per operand instead of an exponential; default); 0 = on u
- *                    (what runs when P does not fit)
+ *   "host_pmode"     above 256 states the host-driven loop also builds a resident probability matrix once per solve and runs
+ *                    BOTH of its sweeps on it (one multiplication per element instead of an exponential): 2 = Gram sweep in
+ *                    256-state panels, one read each, + 128 x 256 rectangles (default); 1 = in the 128-state panels and 64 x 128
+ *                    rectangles of the sweep on u; 0 = both sweeps on u (what runs when P does not fit)
  *   "pcache"         1 = the resident probability matrix outlives the solve that built it: a later adaptive solve on the same
  *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
  *                    one fused sweep instead of the build sweep (default); 0 = every solve builds (cold-solve timings)

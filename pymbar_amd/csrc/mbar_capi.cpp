@@ -257,6 +257,40 @@ GramPlan gram_plan(int64_t Kp, bool quad) {
     return p;
 }
 
+// The plan of the host-driven loop's P mode (more than 256 states): 256-state panels, each ONE read of its rows (k_gram_quad on
+// the probability matrix), the remainder (64 / 128 / 192 states) as one more diagonal panel, and between the panels the
+// rectangles of k_gram_rect: 128 x 256 (64 x 256 for the short remainder), four waves on one shared tile stream.  At 1024 states
+// 4 + 12 launches that read 5632 rows of the matrix (gram_plan above: 64 launches, 11776 rows).
+GramPlan gram_plan_pmode(int64_t Kp) {
+    GramPlan p;
+    struct Panel { int64_t r0; int nb; };
+    std::vector<Panel> panels;
+    for (int64_t r = 0; r < Kp;) {
+        const int nb = Kp - r >= 256 ? 16 : (int)((Kp - r) / 16);  // Kp is a multiple of 64 here
+        panels.push_back({r, nb});
+        r += 16 * nb;
+    }
+    size_t off = 0;
+    for (const auto& a : panels) {
+        const int nblk = a.nb * (a.nb + 1) / 2;
+        p.items.push_back({true, a.r0, a.r0, a.nb, a.nb, nblk, off});
+        off += nblk;
+    }
+    for (size_t ia = 0; ia < panels.size(); ++ia)
+        for (size_t ib = ia + 1; ib < panels.size(); ++ib) {
+            const Panel &a = panels[ia], &b = panels[ib];  // a is a 256-state panel; b one too, or the remainder
+            const Panel &rows = b.nb == 16 ? a : b, &cols = b.nb == 16 ? b : a;
+            for (int done = 0; done < rows.nb;) {
+                const int nbi = rows.nb - done >= 8 ? 8 : 4;
+                p.items.push_back({false, rows.r0 + 16 * done, cols.r0, nbi, 16, nbi * 16, off});
+                off += (size_t)nbi * 16;
+                done += nbi;
+            }
+        }
+    p.total_blocks = off;
+    return p;
+}
+
 // 129 .. 256 states: the one-read kernel (k_gram_quad) needs LDS-DMA staging
 bool use_quad(const mbar_ctx* c) { return c->opt_quad && use_fast(c) && c->Kp > 128 && c->Kp <= 256; }
 GramPlan plan_for(const mbar_ctx* c) { return gram_plan(c->Kp, use_quad(c)); }
@@ -278,10 +312,9 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
         logden = c->lden_eff;
     }
     for (const auto& it : plan.items) {
-        if (it.diag && it.nbi > 8) {  // one read of the matrix: the four waves of a workgroup split the panel's blocks
-            if (pmat) return fail(c, MBAR_ERR_STATE, "run_gram: no P-mode form of the one-read panel outside the device-resident loop");
-            LaunchGeom g = gram_quad_geometry(it.nbi, c->num_cu, ntiles, c->opt_grid);
-            g.live_blocks = quad_live_blocks(c);
+        if (!it.diag && it.nbj == 16) {  // P mode: rectangle against a 256-state panel, four waves on one shared tile stream
+            if (!pmat) return fail(c, MBAR_ERR_STATE, "run_gram: the 256-column rectangles exist on the probability matrix only");
+            const LaunchGeom g = gram_quad_geometry(it.nbi + 16, c->num_cu, ntiles, c->opt_grid);
             const size_t rec = (size_t)it.nblk * 256;
             int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
             if (rc) return rc;
@@ -289,7 +322,25 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
             if (rc) return rc;
             {
                 ScopedTimer t(c, MBAR_TIMER_GRAM);
-                HIPCHK(c, launch_gram_quad(c->stream, it.nbi, g, c->u, c->ld, c->N, anum_dev + it.ri, logden, c->part));
+                HIPCHK(c, launch_gram_rect(c->stream, it.nbi, g, pmat, c->ld, c->N, it.ri, it.rj, logden, c->part));
+            }
+            ScopedTimer t(c, MBAR_TIMER_REDUCE);
+            HIPCHK(c, launch_reduce(c->stream, c->part, g.nwaves, (int64_t)rec, c->scratch, c->red + red_off + it.off * 256));
+            continue;
+        }
+        if (it.diag && it.nbi > 8) {  // one read of the matrix: the four waves of a workgroup split the panel's blocks
+            LaunchGeom g = gram_quad_geometry(it.nbi, c->num_cu, ntiles, c->opt_grid);
+            g.live_blocks = pmat ? 0 : quad_live_blocks(c);
+            const size_t rec = (size_t)it.nblk * 256;
+            int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
+            if (rc) return rc;
+            rc = ensure(c, &c->scratch, &c->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * rec);
+            if (rc) return rc;
+            {
+                ScopedTimer t(c, MBAR_TIMER_GRAM);
+                LoopCtl lo;
+                lo.pmode = pmat != nullptr;  // (then: the panel's rows of the probability matrix, `logden` = reciprocals)
+                HIPCHK(c, launch_gram_quad(c->stream, it.nbi, g, mat + it.ri * c->ld, c->ld, c->N, anum_dev + it.ri, logden, c->part, lo));
             }
             ScopedTimer t(c, MBAR_TIMER_REDUCE);
             HIPCHK(c, launch_reduce(c->stream, c->part, g.nwaves, (int64_t)rec, c->scratch, c->red + red_off + it.off * 256));

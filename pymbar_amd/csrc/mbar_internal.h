@@ -137,6 +137,9 @@ hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, const LaunchGeom& 
 // LDS-DMA staging only.  lc.pmode: `u` is the resident probability matrix, `logden` the reciprocals 1 / s_n.
 LaunchGeom gram_quad_geometry(int nbt, int num_cu, int64_t ntiles, int64_t grid_override);
 // Pout (classic operands only): the operand tiles exp(anum - u - logden) are also written out there (the probability matrix)
+// P mode only: nbi (4 / 8) x 16 blocks between the panels at rows ri and rj of the resident probability matrix, see k_gram_rect
+hipError_t launch_gram_rect(hipStream_t s, int nbi, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, int64_t ri, int64_t rj,
+                            const double* rinv, double* gram_part);
 hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                             const double* anum, const double* logden, double* gram_part, const LoopCtl& lc = LoopCtl(),
                             double* Pout = nullptr);
@@ -146,7 +149,7 @@ hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const d
 // (per-state sums without that factor); psum_part [blocks][nf][rows], obj_part [blocks][nf]
 hipError_t launch_lse_split(hipStream_t s, int num_cu, int nf, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
                             const double* cw, double* logden, double* logden1, const double* dn, double* psum_part, double* obj_part,
-                            int* blocks_out);
+                            int* blocks_out, const double* ld_anchor = nullptr /* P mode: u = P, aden = multipliers, see k_lse_split */);
 hipError_t launch_lse_generic(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t K,
                               const double* aden, const double* cw, double* logden, const double* dn,
                               double* obj_part /*[blocks]*/, int* blocks_out);

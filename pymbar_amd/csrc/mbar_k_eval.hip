@@ -590,26 +590,32 @@ k_lse_wide(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // operands are in registers right after the loop top, and the buffer is refilled there (the exponentials of the tile hide the
 // request) -- instead of the layout-agnostic kernels' two reads of the matrix per candidate.
 // ---------------------------------------------------------------------------------------------
-template <int NBW, int NF>
+// PMODE (round 5, the host-driven loop above 256 states): `u` is the resident probability matrix P = exp(a0 - u - logden(a0)),
+// aden[k] the first candidate's MULTIPLIER exp(a_k - a0_k) (0: state without samples / padding), ld_anchor = logden(a0): an
+// element is P_kn * multiplier -- no exponential, no shift, the first meeting of the waves is skipped -- and
+// logden_n = ld_anchor_n + log(sum).
+template <int NBW, int NF, bool PMODE>
 __global__ void __launch_bounds__(512, 1)
 k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, int64_t rows,
             const double* __restrict__ aden, const double* __restrict__ cw, double* __restrict__ logden,
             double* __restrict__ logden1, const double* __restrict__ dn, double* __restrict__ psum_part,
-            double* __restrict__ obj_part) {
+            double* __restrict__ obj_part, const double* __restrict__ ld_anchor) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RW = NBW * 16;                  // rows per wave
     constexpr int NP = RW / 8;                    // LDS-DMA pieces per wave and tile
     constexpr int U_BYTES = RW * TS * 8;
-    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the tile's 16 sample weights
+    constexpr int TILE_BYTES = U_BYTES + (PMODE ? 2 : 1) * TS * 8;  // + the tile's 16 sample weights (P mode: + its 16 anchor log-denominators)
     constexpr int NW = 8;
     constexpr int NBUF = NBW <= 4 ? 2 : 1;        // tile buffers per wave
+    constexpr int NREQ = NP + (PMODE ? 2 : 1);    // LDS-DMA requests of a wave that has all of its rows, per tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ks = lane & 15, ns = lane >> 4;
     exp_table_init(smem);
     double* xmax = reinterpret_cast<double*>(smem + EXP_TABLE_BYTES);  // [NW][TS]
-    double* xsum = xmax + NW * TS;                                     // [NF][NW][TS]
-    char* buf = smem + EXP_TABLE_BYTES + (1 + NF) * NW * TS * 8 + wave * (NBUF * TILE_BYTES);
+    double* xsum = PMODE ? xmax : xmax + NW * TS;                      // [NF][NW][TS]  (P mode: two of them, by tile parity, no maxima)
+    constexpr int MEET_VECS = PMODE ? 2 * NF : 1 + NF;
+    char* buf = smem + EXP_TABLE_BYTES + MEET_VECS * NW * TS * 8 + wave * (NBUF * TILE_BYTES);
     const int64_t r0 = (int64_t)wave * RW;
     const StageOffsets so = make_stage_offsets(ld, lane);
     // rows this wave never requests: zero once, in both buffers
@@ -626,7 +632,7 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 #pragma unroll
     for (int I = 0; I < NBW; ++I) {
         const int64_t r = r0 + 16 * I + ks;
-        a[I] = r < rows ? aden[r] : -INFINITY;
+        a[I] = r < rows ? aden[r] : (PMODE ? 0.0 : -INFINITY);
         c[I] = (NF == 2 && r < rows) ? aden[rows + r] : 0.0;
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[f][I] = 0.0;
@@ -646,66 +652,86 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         for (int j = 0; j < NP; ++j)
             if (r0 + 8 * j < rows) stage_piece<true>(u + (r0 + 8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
         stage_vec16<true>(cw, tile * TS, dst + U_BYTES, lane);
+        if constexpr (PMODE) stage_vec16<true>(ld_anchor, tile * TS, dst + U_BYTES + TS * 8, lane);
     };
     const int64_t G = gridDim.x;
     int64_t t = blockIdx.x;
-    int cur = 0;
+    int cur = 0, cur2 = 0;
+    // A wave keeps NBUF tiles in flight: all of a tile's operands are in registers right after the loop top, and its buffer is
+    // refilled THERE with the tile NBUF periods ahead (round 5; before, the two-buffer form requested tile i + 1 only once tile i
+    // had landed -- one 64 KB tile per CU in flight, 3.4 TB/s at 512 states).  Waves whose rows are all real count their requests
+    // (the queue retires in order: at most one tile's NREQ requests may still be out when this tile is read); the others --
+    // fewer or no requests -- wait for everything.
+    const bool counted = NBUF == 2 && r0 + RW <= rows;
     if (t < ntiles) stage(t, buf);
+    if (NBUF == 2 && t + G < ntiles) stage(t + G, buf + TILE_BYTES);
     for (; t < ntiles; t += G) {
         char* cbuf = buf + cur * TILE_BYTES;
-        wait_vm<0>();  // this tile (requested a tile period ago) and the previous tile's logden stores
-        if (NBUF == 2 && t + G < ntiles) stage(t + G, buf + (cur ^ 1) * TILE_BYTES);
-        double x[GROUPS][NBW], w[GROUPS], mloc[GROUPS];
+        if (counted && t + G < ntiles) wait_vm<NREQ>(); else wait_vm<0>();  // this tile has landed
+        double x[GROUPS][NBW], w[GROUPS], mloc[GROUPS], lda[GROUPS];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             w[g] = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+            lda[g] = PMODE ? *reinterpret_cast<const double*>(cbuf + U_BYTES + TS * 8 + (4 * g + ns) * 8) : 0.0;
 #pragma unroll
             for (int I = 0; I < NBW; ++I) x[g][I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g]);
         }
-        if constexpr (NBUF == 1) {  // the wave's slice is in registers: its one buffer takes the next tile now
+        {  // the wave's slice is in registers: its buffer takes the tile NBUF periods ahead now
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (t + G < ntiles) stage(t + G, buf);
+            if (t + NBUF * G < ntiles) stage(t + NBUF * G, cbuf);
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int g = 0; g < GROUPS; ++g) {
-#pragma unroll
-            for (int I = 0; I < NBW; ++I) x[g][I] = a[I] - x[g][I];
-            mloc[g] = row16_max(tree_max<NBW>(x[g]));
-            if (ks == 0) xmax[wave * TS + 4 * g + ns] = mloc[g];
-        }
-        __syncthreads();
         double m2[GROUPS];
+        if constexpr (!PMODE) {
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+                for (int I = 0; I < NBW; ++I) x[g][I] = a[I] - x[g][I];
+                mloc[g] = row16_max(tree_max<NBW>(x[g]));
+                if (ks == 0) xmax[wave * TS + 4 * g + ns] = mloc[g];
+            }
+            lds_barrier();  // (LDS traffic only: __syncthreads() would also wait for the tiles in flight)
+        }
+        // (P mode meets ONCE per tile: the sums alternate between two vectors, so a fast wave writing tile i+1's sums cannot
+        // touch what a slow wave still reads of tile i, and tile i+2's writers are past tile i+1's barrier)
+        double* xs = PMODE ? xsum + (cur2 ? NF * NW * TS : 0) : xsum;
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            double m = xmax[4 * g + ns];
+            if constexpr (PMODE) {
+                m2[g] = 0.0;
 #pragma unroll
-            for (int wv = 1; wv < NW; ++wv) m = fmax(m, xmax[wv * TS + 4 * g + ns]);
-            m2[g] = m * LOG2E_S;
+                for (int I = 0; I < NBW; ++I) x[g][I] *= a[I];
+            } else {
+                double m = xmax[4 * g + ns];
 #pragma unroll
-            for (int I = 0; I < NBW; ++I) x[g][I] = fma(x[g][I], LOG2E_S, -m2[g]);
-            exp2s_batch<NBW>(x[g]);
+                for (int wv = 1; wv < NW; ++wv) m = fmax(m, xmax[wv * TS + 4 * g + ns]);
+                m2[g] = m * LOG2E_S;
+#pragma unroll
+                for (int I = 0; I < NBW; ++I) x[g][I] = fma(x[g][I], LOG2E_S, -m2[g]);
+                exp2s_batch<NBW>(x[g]);
+            }
             double s0 = tree_sum<NBW>(x[g]), s1 = NF == 2 ? dot_sum<NBW>(x[g], c) : 0.0;
             if constexpr (NF == 2) row16_sum2(s0, s1); else s0 = row16_sum(s0);
             if (ks == 0) {
-                xsum[wave * TS + 4 * g + ns] = s0;
-                if constexpr (NF == 2) xsum[NW * TS + wave * TS + 4 * g + ns] = s1;
+                xs[wave * TS + 4 * g + ns] = s0;
+                if constexpr (NF == 2) xs[NW * TS + wave * TS + 4 * g + ns] = s1;
             }
         }
-        __syncthreads();
+        lds_barrier();  // (LDS traffic only: __syncthreads() would also wait for the tiles in flight)
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             double ssum[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                ssum[f] = xsum[f * NW * TS + 4 * g + ns];
+                ssum[f] = xs[f * NW * TS + 4 * g + ns];
 #pragma unroll
-                for (int wv = 1; wv < NW; ++wv) ssum[f] += xsum[f * NW * TS + wv * TS + 4 * g + ns];  // (fixed order: every wave gets the same bits)
+                for (int wv = 1; wv < NW; ++wv) ssum[f] += xs[f * NW * TS + wv * TS + 4 * g + ns];  // (fixed order: every wave gets the same bits)
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const double r = w[g] * recip_fast(ssum[f]);
+                // (P mode: a padded sample has an all-zero column: keep its reciprocal finite, its multiplicity is 0)
+                const double r = w[g] * recip_fast(PMODE ? fmax(ssum[f], 1e-300) : ssum[f]);
 #pragma unroll
                 for (int I = 0; I < NBW; ++I) acc[f][I] = fma(x[g][I], r, acc[f][I]);
             }
@@ -713,7 +739,7 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                 const int64_t n = t * TS + 4 * g + ns;
                 if (n < N) {
                     const double sv = ks == 0 ? ssum[0] : ssum[NF - 1];
-                    const double ldv = fma(m2[g], LN2_OVER_S, log_pos(sv));
+                    const double ldv = PMODE ? lda[g] + log_pos(fmax(sv, 1e-300)) : fma(m2[g], LN2_OVER_S, log_pos(sv));
                     double* out = ks == 0 ? logden : logden1;
                     if (out) out[n] = ldv;
                     const double term = w[g] * (dn ? (ldv - dn[n]) : ldv);
@@ -722,6 +748,7 @@ k_lse_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
             }
         }
         cur ^= NBUF - 1;
+        cur2 ^= 1;
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -984,13 +1011,13 @@ static int stream_blocks(int num_cu, int64_t N) {
 // 257 .. 1024 states in one read: rows = allocated row count (a multiple of 64); returns the number of partial records.
 hipError_t launch_lse_split(hipStream_t s, int num_cu, int nf, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
                             const double* cw, double* logden, double* logden1, const double* dn, double* psum_part, double* obj_part,
-                            int* blocks_out) {
+                            int* blocks_out, const double* ld_anchor) {
     int nbw = (int)((rows + 127) / 128);
     if (nbw < 1 || nbw > 8 || nf < 1 || nf > 2) return hipErrorInvalidValue;
     if (nbw > 4) nbw = nbw <= 6 ? 6 : 8;  // (513 .. 768 / 769 .. 1024 rows: rows a wave does not have are never requested)
     const int64_t ntiles = (N + TS - 1) / TS;
-    const size_t tile = (size_t)nbw * 16 * TS * 8 + TS * 8;
-    const size_t lds = EXP_TABLE_BYTES + (size_t)(1 + nf) * 8 * TS * 8 + (size_t)8 * (nbw <= 4 ? 2 : 1) * tile;
+    const size_t tile = (size_t)nbw * 16 * TS * 8 + (ld_anchor ? 2 : 1) * TS * 8;
+    const size_t lds = EXP_TABLE_BYTES + (size_t)(ld_anchor ? 2 * nf : 1 + nf) * 8 * TS * 8 + (size_t)8 * (nbw <= 4 ? 2 : 1) * tile;
     const int blocks = (int)(ntiles < num_cu ? (ntiles < 1 ? 1 : ntiles) : num_cu);
     *blocks_out = blocks;
     auto go = [&](auto kern) -> hipError_t {
@@ -999,26 +1026,44 @@ hipError_t launch_lse_split(hipStream_t s, int num_cu, int nf, const double* u, 
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, u, ld, N, ntiles, rows, aden, cw, logden, logden1, dn, psum_part,
-                           obj_part);
+                           obj_part, ld_anchor);
         return hipGetLastError();
     };
+    if (ld_anchor) {  // P mode (the host-driven loop above 256 states: 17 .. 64 blocks of 16 rows)
+        if (nf == 1) {
+            switch (nbw) {
+                case 3: return go(k_lse_split<3, 1, true>);
+                case 4: return go(k_lse_split<4, 1, true>);
+                case 6: return go(k_lse_split<6, 1, true>);
+                case 8: return go(k_lse_split<8, 1, true>);
+                default: return hipErrorInvalidValue;
+            }
+        }
+        switch (nbw) {
+            case 3: return go(k_lse_split<3, 2, true>);
+            case 4: return go(k_lse_split<4, 2, true>);
+            case 6: return go(k_lse_split<6, 2, true>);
+            case 8: return go(k_lse_split<8, 2, true>);
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (nf == 1) {
         switch (nbw) {
-            case 1: return go(k_lse_split<1, 1>);
-            case 2: return go(k_lse_split<2, 1>);
-            case 3: return go(k_lse_split<3, 1>);
-            case 4: return go(k_lse_split<4, 1>);
-            case 6: return go(k_lse_split<6, 1>);
-            default: return go(k_lse_split<8, 1>);
+            case 1: return go(k_lse_split<1, 1, false>);
+            case 2: return go(k_lse_split<2, 1, false>);
+            case 3: return go(k_lse_split<3, 1, false>);
+            case 4: return go(k_lse_split<4, 1, false>);
+            case 6: return go(k_lse_split<6, 1, false>);
+            default: return go(k_lse_split<8, 1, false>);
         }
     }
     switch (nbw) {
-        case 1: return go(k_lse_split<1, 2>);
-        case 2: return go(k_lse_split<2, 2>);
-        case 3: return go(k_lse_split<3, 2>);
-        case 4: return go(k_lse_split<4, 2>);
-        case 6: return go(k_lse_split<6, 2>);
-        default: return go(k_lse_split<8, 2>);
+        case 1: return go(k_lse_split<1, 2, false>);
+        case 2: return go(k_lse_split<2, 2, false>);
+        case 3: return go(k_lse_split<3, 2, false>);
+        case 4: return go(k_lse_split<4, 2, false>);
+        case 6: return go(k_lse_split<6, 2, false>);
+        default: return go(k_lse_split<8, 2, false>);
     }
 }
 

@@ -262,6 +262,153 @@ k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rectangle between an NBI-block panel (64 / 128 states) and a 256-state panel on the resident probability matrix (P mode of the
+// host-driven loop above 256 states, round 5): k_gram_quad's tile stream -- four waves, one shared tile of (NBI + 16) x 16 rows,
+// each wave turns its quarter of the rows into operands P_kn / s_n in place, ONE barrier per tile -- and every wave issues the
+// blocks (I, J) with J = WV mod 4: NBI + 4 operand reads for 4 NBI matrix instructions per k-step.  A 128 x 256 rectangle is
+// 128 blocks for 384 staged rows (96 bytes per matrix instruction; the 64 x 128 rectangles of k_gram, one tile stream per wave,
+// stage 192 rows for 32 blocks: 192 bytes, above the ~150 the matrix pipe can absorb at this HBM rate): above 256 states the Gram
+// sweep reads the matrix 5.5 times at 1024 states instead of 11.5 (2.5 instead of 5.5 at 512).
+// Record: one per workgroup, block b = I * 16 + J (what unpack_gram expects of a rectangle).
+// ---------------------------------------------------------------------------------------------
+template <int NBI, int WV, bool WIDE>
+__device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, int64_t row_i0,
+                                               int64_t row_j0, const double* __restrict__ rinv, double* __restrict__ gram_part,
+                                               char* smem, int lane) {
+    constexpr int NBJ = 16, NBT = NBI + NBJ, ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
+    constexpr int U_BYTES = ROWS * TS * 8;
+    constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + one copy of the tile's 16 reciprocals per wave
+    constexpr int NBLK = NBI * NBJ, NMINE = NBLK / 4, NP = NBI + 4;
+    static_assert(NBT % 4 == 0 && NMINE >= QDMA + 2 && NMINE <= 32, "rectangle shape");
+    const int ks = lane & 15, ns = lane >> 4;
+    char* buf = smem + EXP_TABLE_BYTES;
+    const RowTwoPanels rows{row_i0, row_j0, NBI * 16};
+    const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
+    const int64_t G = gridDim.x;
+    v4d acc[NMINE];
+#pragma unroll
+    for (int b = 0; b < NMINE; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int rd_base = ks * (TS * 8);
+    int pos[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) pos[g] = ((4 * g + ns + (ks & 14)) & 15) * 8;
+
+    auto stage_piece_j = [&](int64_t tile, char* dst, int j) {
+        stage_piece<true>(P + rows(8 * j) * ld + tile * TS, so.off[j & 1], dst + j * 1024, lane);
+    };
+    const char* lsrc = reinterpret_cast<const char*>(rinv) + (lane & 7) * 16;
+    auto stage_l = [&](int64_t tile, char* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + tile * (TS * 8)),
+                                         (__attribute__((address_space(3))) void*)(dst + U_BYTES + WV * 1024), 16, 0, 0);
+    };
+    auto stage = [&](int64_t tile, char* dst) {
+#pragma unroll
+        for (int j = WV * QDMA; j < (WV + 1) * QDMA; ++j) stage_piece_j(tile, dst, j);
+        stage_l(tile, dst);
+    };
+    // operands of one group of four samples: the NBI row blocks of the short panel, then this wave's four column blocks
+    auto read_group = [&](const char* tb, int g, double (&x)[NP]) {
+#pragma unroll
+        for (int I = 0; I < NBI; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[NBI + q] = *reinterpret_cast<const double*>(tb + (NBI + WV + 4 * q) * (16 * TS * 8) + rd_base + pos[g]);
+    };
+    auto mfma = [&](int b, double x, double y) {
+        if (b < GRAM_AGPR_BLOCKS)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(x), "v"(y));
+        else
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(x), "v"(y));
+    };
+    double x[GROUPS * NQ], ldc[GROUPS];
+    auto read_own = [&](const char* tb) {
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            ldc[g] = *reinterpret_cast<const double*>(tb + U_BYTES + WV * 1024 + (4 * g + ns) * 8);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) x[g * NQ + i] = *reinterpret_cast<const double*>(tb + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]);
+        }
+    };
+    int64_t t = blockIdx.x;
+    int cur = 0;
+    if (t < ntiles) {
+        stage(t, buf);
+        wait_vm<0>();
+        read_own(buf);
+    }
+    for (; t < ntiles; t += G) {
+        char* cbuf = buf + cur * TILE_BYTES;
+        char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
+        const int64_t tnext = t + G < ntiles ? t + G : t;  // (past the end this tile is requested again and never looked at)
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const double rin = (t * TS + 4 * g + ns) < N ? ldc[g] : 0.0;  // 1 / s_n (times sqrt(c_n) when weighted); padded samples: 0
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i] * rin;
+        }
+        __syncthreads();  // every row of tile t holds operands; every wave is done with the other buffer
+        double p[2][NP];
+        read_group(cbuf, 0, p[0]);
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7");
+#pragma unroll
+            for (int I = 0; I < NBI; ++I)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mine = I * 4 + q;
+                    mfma(mine, p[g & 1][I], p[g & 1][NBI + q]);
+                    if (mine == 0 && g < GROUPS - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_group(cbuf, g + 1, p[(g + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (g == 0 && mine >= 1 && mine <= QDMA + 1) {  // one piece of the next tile behind each of the next blocks
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (mine <= QDMA)
+                            stage_piece_j(tnext, nbuf, WV * QDMA + mine - 1);
+                        else
+                            stage_l(tnext, nbuf);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (g == GROUPS - 1 && mine == 1) {  // the next tile was requested three groups ago: its rows into registers
+                        __builtin_amdgcn_sched_barrier(0);
+                        wait_vm<0>();
+                        read_own(nbuf);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // matrix result -> VALU read distance
+    double* rec = gram_part + (int64_t)blockIdx.x * NBLK * 256;
+#pragma unroll
+    for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rec[((I * NBJ + WV + 4 * q) * 4 + r) * 64 + lane] = acc[I * 4 + q][r];
+}
+
+template <int NBI, bool WIDE>
+__global__ void __launch_bounds__(256, 1)
+k_gram_rect(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, int64_t row_i0, int64_t row_j0,
+            const double* __restrict__ rinv, double* __restrict__ gram_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {
+        case 0: gram_rect_body<NBI, 0, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
+        case 1: gram_rect_body<NBI, 1, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
+        case 2: gram_rect_body<NBI, 2, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
+        default: gram_rect_body<NBI, 3, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused sweep for 129 .. 256 states (P mode): k_gram_quad's tile stream -- four waves, one shared tile, each wave its quarter of
 // the rows and every fourth block -- carrying what k_fused carries for one panel: the normalisers 1 / s_n of both candidates
 // (each wave's partial dot products over ITS rows meet in a 1 KB LDS table: one more barrier per tile), the per-state sums of
@@ -637,6 +784,23 @@ hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const d
     if (nbt == 16)
         return lc.pmode ? launch_gram_quad_t<16, true>(s, g, u, ld, N, anum, logden, gram_part, lc)
                         : launch_gram_quad_t<16, false>(s, g, u, ld, N, anum, logden, gram_part, lc);
+    return hipErrorInvalidValue;
+}
+// (the geometry is gram_quad_geometry(nbi + 16, ...): the same shared double buffer, one record per workgroup)
+hipError_t launch_gram_rect(hipStream_t s, int nbi, const LaunchGeom& g, const double* P, int64_t ld, int64_t N, int64_t ri, int64_t rj,
+                            const double* rinv, double* gram_part) {
+    auto launch = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, P, ld, N, ntiles, ri, rj, rinv, gram_part);
+        return hipGetLastError();
+    };
+    const bool wide = stage_offsets_wide(ld);
+    if (nbi == 8) return wide ? launch(k_gram_rect<8, true>) : launch(k_gram_rect<8, false>);
+    if (nbi == 4) return wide ? launch(k_gram_rect<4, true>) : launch(k_gram_rect<4, false>);
     return hipErrorInvalidValue;
 }
 template <int NBT>

@@ -37,7 +37,8 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
     // not fit, or a state moves more than 250 kT from the anchor (then: a new anchor), the classic sweep runs.
     const int64_t Kp = c->Kp;
     bool hp = c->opt_pmode && c->opt_host_pmode && Kp > 256 && !c->P_failed;
-    for (const auto& item : plan.items) hp = hp && !(item.diag && item.nbi > 8);
+    // ("host_pmode" 2, the default: 256-state panels and 128 x 256 rectangles; 1: the 128-state panels of the sweep on u)
+    const GramPlan plan_p = hp ? (c->opt_host_pmode >= 2 ? gram_plan_pmode(Kp) : plan) : GramPlan();
     std::vector<double> a0, an_host((size_t)Kp), cm((size_t)Kp, 1.0);
     auto anchor_here = [&]() -> int {  // P at the current f (whose log-denominators are in slot `cur`)
         if (!c->P && cache_malloc((void**)&c->P, (size_t)Kp * c->ld * sizeof(double)) != hipSuccess) {
@@ -66,6 +67,59 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
         rc = anchor_here();
         if (rc) return rc;
     }
+    // Pass B on the same matrix: an element of candidate 0 is P_kn exp(a_k - a0_k) -- one multiplication, no exponential, no
+    // shared shift (the eight waves of a workgroup meet once per tile instead of twice) -- and logden_n = logden_n(a0) + log(sum).
+    // `used` stays false (the classic sweep on u runs) when a candidate is not finite or outside the 250 kT window of the anchor.
+    auto pass_b_on_p = [&](const double* cands, double* ldA, double* ldB, double* ps2, bool& used) -> int {
+        used = false;
+        if (!hp || !split_sweep_ok(c, Kp) || c->u_poison) return MBAR_OK;
+        std::vector<double> h((size_t)2 * Kp, 0.0), a1((size_t)Kp);
+        build_aden(c, cands, an_host.data(), Kp);
+        build_aden(c, cands + K, a1.data(), Kp);
+        for (int64_t k = 0; k < Kp; ++k) {
+            if (std::isinf(a0[k])) {  // a state without samples (or padding): no element
+                if (!std::isinf(an_host[k]) || !std::isinf(a1[k])) return MBAR_OK;
+                continue;
+            }
+            const double d0 = an_host[k] - a0[k], d1 = a1[k] - an_host[k];
+            if (!(std::fabs(d0) < 250.0) || !(std::fabs(d1) < 300.0)) return MBAR_OK;
+            h[(size_t)k] = std::exp(d0);
+            h[(size_t)Kp + k] = std::exp(d1);
+        }
+        const size_t n_ps = (size_t)2 * Kp, total = n_ps + 2;
+        int r2 = ensure_red(c, total);
+        if (r2) return r2;
+        r2 = ensure(c, &c->part, &c->part_doubles, (size_t)c->num_cu * 2 * (Kp + 1));
+        if (r2) return r2;
+        r2 = ensure(c, &c->scratch, &c->scratch_doubles, (size_t)(c->num_cu / 32 + 2) * 2 * (Kp + 1));
+        if (r2) return r2;
+        std::copy(h.begin(), h.end(), c->hstage);
+        HIPCHK(c, hipMemcpyAsync(d_aden(c), c->hstage, h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (ldA == c->logden[0] || ldB == c->logden[0]) c->ld0_valid = false;
+        int blocks = 0;
+        double* obj_part = c->part + (size_t)c->num_cu * 2 * Kp;
+        {
+            ScopedTimer t(c, MBAR_TIMER_LSE);
+            HIPCHK(c, launch_lse_split(c->stream, c->num_cu, 2, c->P, c->ld, c->N, Kp, d_aden(c), c->cw, ldA, ldB, nullptr, c->part, obj_part,
+                                       &blocks, c->pm_ld0));
+        }
+        {
+            ScopedTimer t(c, MBAR_TIMER_REDUCE);
+            HIPCHK(c, launch_reduce(c->stream, c->part, blocks, (int64_t)n_ps, c->scratch, c->red));
+            HIPCHK(c, launch_reduce(c->stream, obj_part, blocks, 2, c->scratch, c->red + n_ps));
+        }
+        r2 = allreduce_dev(c, c->red, (int64_t)total, 0);
+        if (r2) return r2;
+        HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        r2 = sync_stream(c);
+        if (r2) return r2;
+        for (int64_t k = 0; k < K; ++k) {
+            ps2[k] = c->hred[(size_t)k];
+            ps2[(size_t)K + k] = c->hred[(size_t)Kp + k] * h[(size_t)Kp + k];  // (the second candidate's sums come without its ratio)
+        }
+        used = true;
+        return MBAR_OK;
+    };
     double tA = 0, tH = 0, tB = 0;
     const int64_t it0 = res.iterations;
     const double t0 = now_ms();
@@ -73,7 +127,8 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
         // ---- pass A: Gram at f with the known logden -> Hessian (mbar_solvers.py:581) ----
         const double t_a0 = now_ms();
         {
-            const size_t n_gram = plan.total_blocks * 256, total = n_gram;
+            const GramPlan& pl = hp ? plan_p : plan;
+            const size_t n_gram = pl.total_blocks * 256, total = n_gram;
             rc = ensure_red(c, total);
             if (rc) return rc;
             std::vector<double> an((size_t)c->Kp);
@@ -94,11 +149,11 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
             }
             if (hp) {
                 HIPCHK(c, launch_rinv_from_logden(c->stream, c->pm_ld0, c->logden[cur], c->cw, c->weighted, c->N, c->lden_eff));
-                rc = run_gram(c, d_anum(c), c->lden_eff, 0, plan, c->P);
+                rc = run_gram(c, d_anum(c), c->lden_eff, 0, pl, c->P);
             } else {
                 std::copy(an.begin(), an.end(), c->hstage + 2 * c->Kp);
                 HIPCHK(c, hipMemcpyAsync(d_anum(c), c->hstage + 2 * c->Kp, an.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                rc = run_gram(c, d_anum(c), c->logden[cur], 0, plan);
+                rc = run_gram(c, d_anum(c), c->logden[cur], 0, pl);
             }
             if (rc) return rc;
             rc = allreduce_dev(c, c->red, (int64_t)total, 0);
@@ -106,7 +161,7 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
             HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             rc = sync_stream(c);
             if (rc) return rc;
-            unpack_gram(plan, c->hred, K, gram.data());
+            unpack_gram(pl, c->hred, K, gram.data());
             if (hp)  // the per-state factors the P-mode sweep leaves out
                 for (int64_t i = 0; i < K; ++i)
                     for (int64_t j = 0; j < K; ++j) gram[(size_t)i * K + j] *= cm[i] * cm[j];
@@ -145,8 +200,13 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
         // ---- pass B: both candidates in one sweep (:589-594) ----
         const double t_b0 = now_ms();
         const int sA = (cur + 1) % 3, sB = (cur + 2) % 3;
-        rc = eval_core(c, cand.data(), 2, 0, c->logden[sA], c->logden[sB], psum2.data(), nullptr, nullptr);
+        bool on_p = false;
+        rc = pass_b_on_p(cand.data(), c->logden[sA], c->logden[sB], psum2.data(), on_p);
         if (rc) return rc;
+        if (!on_p) {
+            rc = eval_core(c, cand.data(), 2, 0, c->logden[sA], c->logden[sB], psum2.data(), nullptr, nullptr);
+            if (rc) return rc;
+        }
         const double t_b1 = now_ms();
         tA += t_a1 - t_a0; tH += t_b0 - t_a1; tB += t_b1 - t_b0;
         double gn_sci = 0.0, gn_nr = 0.0;

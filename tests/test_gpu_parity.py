@@ -423,7 +423,8 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
         assert light_seen >= 2, light_seen  # both candidates pass)
 
 
-@pytest.mark.parametrize("K,N", [(160, 6400), (256, 7680), (300, 6000), (600, 6000)])
+# (300 / 380 / 440 / 600 / 800 states: the 256-state panels of the P-mode plan + a remainder of 64 / 128 / 192 / 2 x 256 + 128 / 4 x 256 rows)
+@pytest.mark.parametrize("K,N", [(160, 6400), (256, 7680), (300, 6000), (380, 5700), (440, 6600), (600, 6000), (800, 8000)])
 def test_adaptive_solves_above_128_states_match_the_oracle(DM, K, N):
     """Adaptive solves beyond one Gram panel (129-256 states: paneled Gram sweeps; 257-512: row-split evaluation sweep; above:
     layout-agnostic sweeps) against the oracle's loop (mbar_solvers.py:575-640): free energies, iteration counts, the choice
@@ -446,10 +447,11 @@ def test_adaptive_solves_above_128_states_match_the_oracle(DM, K, N):
     with DM.from_host(u_kn) as dm:
         dm.set_Nk(N_k)
         cases = [dict(min_sc_iter=0), dict(min_sc_iter=2), dict(min_sc_iter=0, boot=True)]
-        if K > 256:  # the host-driven loop's Gram sweep on a resident probability matrix (default) and on u
+        if K > 256:  # the host-driven loop's sweeps on a resident probability matrix (default: 256-state panels; 1: 128-state) and on u
+            cases += [dict(min_sc_iter=0, host_pmode=1), dict(min_sc_iter=0, boot=True, host_pmode=1)]
             cases += [dict(min_sc_iter=0, host_pmode=0), dict(min_sc_iter=0, boot=True, host_pmode=0)]
         for case in cases:
-            dm.set_option("host_pmode", case.get("host_pmode", 1))
+            dm.set_option("host_pmode", case.get("host_pmode", 2))
             u_or = u_kn[:, rints] if case.get("boot") else u_kn
             hist = []
             r_or = oracle.adaptive(np.ascontiguousarray(u_or[sws]), Nf, np.zeros(len(sws)), tol=tol, min_sc_iter=case["min_sc_iter"],
