@@ -120,6 +120,9 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
         }
     };
 
+    // (The barriers of the tile loops in this file are lds_barrier(): LDS traffic only.  __syncthreads() also waits for every
+    // outstanding global request -- here the reciprocal / probability-matrix stores a wave issued just before it, a full round trip
+    // per tile that all four waves then stand in.)
     // Per tile: [own LDS-DMA landed] [own rows -> operands, in place] [ONE barrier] [request the next tile into the other
     // buffer, behind the first matrix instructions] [own blocks].  The barrier of tile t says "every wave has finished the
     // blocks of tile t - 1", which is what frees the other buffer; the request then has the whole block phase to land.
@@ -180,7 +183,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
                     if (WV * NQ + i < NBM)
                         *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i];
         }
-        __syncthreads();  // every row of tile t holds operands; every wave is done with the other buffer
+        lds_barrier();  // every row of tile t holds operands; every wave is done with the other buffer
         // ---- this wave's blocks, group by group; the operands of the next group are requested behind the first block, the
         // LDS-DMA pieces of the next tile behind the blocks that follow in group 0
         double p[2][NBT];
@@ -346,7 +349,7 @@ __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int
             for (int i = 0; i < NQ; ++i)
                 *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i] * rin;
         }
-        __syncthreads();  // every row of tile t holds operands; every wave is done with the other buffer
+        lds_barrier();  // every row of tile t holds operands; every wave is done with the other buffer
         double p[2][NP];
         read_group(cbuf, 0, p[0]);
 #pragma unroll
@@ -514,7 +517,7 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
             row16_sum2(d0, d1);
             if (ks < 2) xs[(WV * 2 + ks) * TS + 4 * g + ns] = ks == 0 ? d0 : d1;
         }
-        __syncthreads();  // (the four partial sums of every sample are in the table; every wave is done with the other buffer)
+        lds_barrier();  // (the four partial sums of every sample are in the table; every wave is done with the other buffer)
         // ---- reciprocals, per-state sums, operands in place
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
@@ -536,7 +539,7 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
                 if (n < N && ks < 2) (ks == 0 ? rinv0 : rinv1)[n] = ks == 0 ? r0 : r1;
             }
         }
-        __syncthreads();  // every row of tile t holds operands
+        lds_barrier();  // every row of tile t holds operands
         // ---- this wave's blocks (see k_gram_quad)
         double p[2][NBT];
         read_group(cbuf, 0, p[0]);
@@ -663,7 +666,7 @@ __device__ __forceinline__ void fused_quad_light_body(const double* __restrict__
             row16_sum2(d0, d1);
             if (ks < 2) xs[(WV * 2 + ks) * TS + 4 * g + ns] = ks == 0 ? d0 : d1;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const int sidx = 4 * g + ns;
@@ -682,7 +685,7 @@ __device__ __forceinline__ void fused_quad_light_body(const double* __restrict__
                 if (n < N && ks < 2) (ks == 0 ? rinv0 : rinv1)[n] = ks == 0 ? r0 : r1;
             }
         }
-        __syncthreads();  // (the table of partial normalisers is free again)
+        lds_barrier();  // (the table of partial normalisers is free again)
         wait_vm<0>();
         read_own(nbuf);
         cur ^= 1;
