@@ -20,6 +20,13 @@ namespace mbar {
 // Partial records: ONE per workgroup (NBLK blocks of 256 doubles, block b = (I, J), I <= J, row-major: the layout of the
 // single-panel kernel, so the reduction, the K x K solve and the host-side unpacking are the ones of K <= 128).
 // ---------------------------------------------------------------------------------------------
+// Block of the last group behind which a wave waits for its LDS-DMA of the next tile and takes its rows into registers: the
+// request went out behind the first blocks of group 0 (A/B: MBAR_QUAD_OWN_EARLY = behind block 1, three groups later)
+#ifdef MBAR_QUAD_OWN_EARLY
+#define QUAD_OWN_AT(n) 1
+#else
+#define QUAD_OWN_AT(n) ((n) - 4)
+#endif
 constexpr int quad_blocks_of(int nbt, int w) { return (nbt * (nbt + 1) / 2 - w + 3) / 4; }
 // A wave's blocks into the workgroup's record (the NBT panel's layout: block (I, J), I <= J, row-major): live blocks -- every
 // fourth of the NBM triangle -- from the accumulators, the blocks of the padding rows (every fourth of those) as zeros.
@@ -221,7 +228,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
                             *reinterpret_cast<double2*>(reinterpret_cast<char*>(Pout + rows(8 * j) * ld + t * TS) + so.off[j & 1]) = pv;
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (PREFETCH && g == GROUPS - 1 && mine == 1) {  // the next tile was requested three groups ago: its rows into registers
+                        if (PREFETCH && g == GROUPS - 1 && mine == QUAD_OWN_AT(NMINE)) {  // the next tile was requested three groups ago: its rows into registers
                             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
                             wait_vm<0>();
                             read_own(nbuf);
@@ -338,7 +345,15 @@ __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int
         wait_vm<0>();
         read_own(buf);
     }
+#ifdef MBAR_RECT_STAMPS
+    long long st_conv = 0, st_bar = 0, st_rd = 0, st_mf = 0, st_n = 0;
+#define RECT_STAMP(v) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); v = clock64(); } while (0)
+#else
+#define RECT_STAMP(v) do { } while (0)
+#endif
     for (; t < ntiles; t += G) {
+        [[maybe_unused]] long long s0, s1, s2, s3, s4;
+        RECT_STAMP(s0);
         char* cbuf = buf + cur * TILE_BYTES;
         char* nbuf = buf + (cur ^ 1) * TILE_BYTES;
         const int64_t tnext = t + G < ntiles ? t + G : t;  // (past the end this tile is requested again and never looked at)
@@ -349,9 +364,12 @@ __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int
             for (int i = 0; i < NQ; ++i)
                 *reinterpret_cast<double*>(cbuf + (WV * NQ + i) * (16 * TS * 8) + rd_base + pos[g]) = x[g * NQ + i] * rin;
         }
+        RECT_STAMP(s1);
         lds_barrier();  // every row of tile t holds operands; every wave is done with the other buffer
+        RECT_STAMP(s2);
         double p[2][NP];
         read_group(cbuf, 0, p[0]);
+        RECT_STAMP(s3);
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             __builtin_amdgcn_sched_barrier(0);
@@ -375,7 +393,7 @@ __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int
                             stage_l(tnext, nbuf);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (g == GROUPS - 1 && mine == 1) {  // the next tile was requested three groups ago: its rows into registers
+                    if (g == GROUPS - 1 && mine == QUAD_OWN_AT(NMINE)) {  // the next tile was requested three groups ago: its rows into registers
                         __builtin_amdgcn_sched_barrier(0);
                         wait_vm<0>();
                         read_own(nbuf);
@@ -384,9 +402,18 @@ __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+        RECT_STAMP(s4);
+#ifdef MBAR_RECT_STAMPS
+        st_conv += s1 - s0; st_bar += s2 - s1; st_rd += s3 - s2; st_mf += s4 - s3; ++st_n;
+#endif
         cur ^= 1;
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // matrix result -> VALU read distance
+#ifdef MBAR_RECT_STAMPS
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
+        printf("[rect stamps] block %d wave %d: %lld tiles, per tile: operands %lld, barrier %lld, first operands %lld, blocks %lld clocks\n",
+               (int)blockIdx.x, WV, st_n, st_conv / st_n, st_bar / st_n, st_rd / st_n, st_mf / st_n);
+#endif
     double* rec = gram_part + (int64_t)blockIdx.x * NBLK * 256;
 #pragma unroll
     for (int I = 0; I < NBI; ++I)
@@ -567,7 +594,7 @@ __device__ __forceinline__ void fused_quad_body(const double* __restrict__ P, in
                                 stage_w(tnext, nbuf);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (g == GROUPS - 1 && mine == 1) {
+                        if (g == GROUPS - 1 && mine == QUAD_OWN_AT(NMINE)) {
                             __builtin_amdgcn_sched_barrier(0);
                             wait_vm<0>();
                             read_own(nbuf);
