@@ -36,7 +36,8 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
     // anyway; the per-state factors exp(a_k - a0_k) are applied to the K x K result on the host.  One more K x N array; if it does
     // not fit, or a state moves more than 250 kT from the anchor (then: a new anchor), the classic sweep runs.
     const int64_t Kp = c->Kp;
-    bool hp = c->opt_pmode && c->opt_host_pmode && Kp > 256 && !c->P_failed;
+    const bool hp_possible = c->opt_pmode && c->opt_host_pmode && Kp > 256;  // (options: the same on every rank)
+    bool hp = hp_possible && !c->P_failed;
     // ("host_pmode" 2, the default: 256-state panels and 128 x 256 rectangles; 1: the 128-state panels of the sweep on u)
     const GramPlan plan_p = hp ? (c->opt_host_pmode >= 2 ? gram_plan_pmode(Kp) : plan) : GramPlan();
     std::vector<double> a0, an_host((size_t)Kp), cm((size_t)Kp, 1.0);
@@ -66,6 +67,12 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
     if (hp) {
         rc = anchor_here();
         if (rc) return rc;
+    }
+    if (hp_possible && c->nranks > 1) {  // a rank whose matrix did not fit must not sweep u while its peers sweep P: the reduced
+        bool ok = hp;                    // blocks differ by the per-state factors (and, with the 256-state panels, in number)
+        rc = agree_all_ok(c, ok);
+        if (rc) return rc;
+        hp = ok;
     }
     // Pass B on the same matrix: an element of candidate 0 is P_kn exp(a_k - a0_k) -- one multiplication, no exponential, no
     // shared shift (the eight waves of a workgroup meet once per tile instead of twice) -- and logden_n = logden_n(a0) + log(sum).
