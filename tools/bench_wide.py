@@ -163,7 +163,7 @@ def large():
             fc, rc = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0)
             dtc = time.perf_counter() - t1
             print(f"adaptive K={K} N={N}: {1e3 * dt:8.3f} ms per iteration; Gram sweep {per['gram'][0]:7.3f} ms x{per['gram'][1]} = "
-                  f"{flop / (per['gram'][0] * 1e-3) * 1e-12 / PEAK:5.3f} of the fp64 matrix peak, evaluation sweep {per['lse'][0]:7.3f} ms x{per['lse'][1]} "
+                  f"{flop / (tm['gram'][0] / n * 1e-3) * 1e-12 / PEAK:5.3f} of the fp64 matrix peak over an iteration's launches, evaluation sweep {per['lse'][0]:7.3f} ms x{per['lse'][1]} "
                   f"({8.0 * K * N / (per['lse'][0] * 1e-3) * 1e-12:4.2f} TB/s of one read), other {per['other'][0]:7.3f} ms x{per['other'][1]}; device time per iteration "
                   f"{sum(tm[k][0] for k in ('gram', 'lse', 'other')) / n:8.3f} ms; solve from f=0: {rc['iterations']} iterations {1e3 * dtc:8.2f} ms success={rc['success']}", flush=True)
 
