@@ -8,6 +8,7 @@
 
 #include <dlfcn.h>
 #include <sched.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -17,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <memory>

@@ -77,34 +77,150 @@ bool chol_solve(std::vector<double>& A, std::vector<double>& b, int m) {
     return true;
 }
 
-// The same factorisation for the state counts whose K x K solve stays on the host (more than 256 states): blocks of CHOL_BLOCK
-// columns, the rows below the diagonal block shared out over a team of host threads in chunks of eight (one cache line of a block
-// column).  A row below the block depends on the block's own factor only (phase 1: its entries in the block's columns -- a
-// triangular solve against the diagonal block) and then on the finished block columns of the rows above it (phase 2: the
-// rank-CHOL_BLOCK update of its trailing entries).  Phase 2 of one block and phase 1 of the next touch the same rows, so a thread
-// runs them back to back and a block costs ONE barrier; the caller's thread updates and factors the next diagonal block first and
-// publishes it while the others are still in phase 2.  Every entry receives the same operations in the same order whatever the
-// number of threads: results do not depend on it.  (The rank-8 row update is where the flops are: compiled a second and third time
-// for AVX2 + FMA and AVX-512 and chosen at run time -- the library itself is built for baseline x86-64.)
-#define MBAR_ROW_UPDATE8_BODY                                                                                                  \
-    const double *c0 = cb, *c1 = cb + ms, *c2 = cb + 2 * ms, *c3 = cb + 3 * ms, *c4 = cb + 4 * ms, *c5 = cb + 5 * ms,         \
-                 *c6 = cb + 6 * ms, *c7 = cb + 7 * ms;                                                                         \
-    const double l0 = c0[i], l1 = c1[i], l2 = c2[i], l3 = c3[i], l4 = c4[i], l5 = c5[i], l6 = c6[i], l7 = c7[i];               \
-    for (int k = k0; k <= k1; ++k)                                                                                             \
-        row[k] -= ((l0 * c0[k] + l1 * c1[k]) + (l2 * c2[k] + l3 * c3[k])) + ((l4 * c4[k] + l5 * c5[k]) + (l6 * c6[k] + l7 * c7[k]));
-void row_update8_base(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
-    MBAR_ROW_UPDATE8_BODY
-}
-__attribute__((target("avx2,fma")))
-void row_update8_avx2(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
-    MBAR_ROW_UPDATE8_BODY
-}
-__attribute__((target("avx512f")))
-void row_update8_avx512(double* __restrict__ row, const double* __restrict__ cb, size_t ms, int i, int k0, int k1) {
-    MBAR_ROW_UPDATE8_BODY
-}
-#undef MBAR_ROW_UPDATE8_BODY
+// The same factorisation for the state counts whose K x K solve stays on the host (more than 256 states): right-looking, blocks of
+// CHOL_BLOCK columns, on a 64-byte-aligned copy of the lower triangle whose rows are padded to whole cache lines.  The rows below
+// the diagonal block are shared out over a team of host threads in chunks of eight.  A row below the block depends on the block's
+// own factor only (phase 1: its entries in the block's columns -- a triangular solve against the diagonal block) and then on the
+// finished block columns of the rows above it (phase 2: the rank-CHOL_BLOCK update of its trailing entries).  Phase 2 of one block
+// and phase 1 of the next touch the same rows, so a thread runs them back to back and a block costs ONE barrier; the caller's
+// thread updates and factors the next diagonal block first and publishes it while the others are still in phase 2.  Every entry
+// receives the same operations in the same order whatever the number of threads: results do not depend on it.
+// Round 5: both phases work on SEVERAL rows at once.  Phase 1 was a chain of 32 dependent divide-and-update steps per row (2.5
+// GFLOP/s: a third of the factorisation's time for a tenth of its arithmetic); eight rows now walk that chain side by side, one
+// vector lane each, multiplying by the pivots' reciprocals.  Phase 2 updates four rows against four block columns per pass -- 16
+// multipliers stay in registers, every vector of a row and of a column that is loaded is used four times (before: one row against
+// eight columns, nine loads per eight multiply-adds, rows not aligned).  511 unknowns, five threads of the MI355X boxes' host:
+// 1.15 -> see profiles/r5_host_cholesky.txt.  (The kernels are compiled a second and third time for AVX2 + FMA and AVX-512 and
+// chosen at run time -- the library itself is built for baseline x86-64.)
+typedef double v8d __attribute__((vector_size(64)));
+#define MBAR_LD8(p) ({ v8d v_; std::memcpy(&v_, (p), 64); v_; })
+#define MBAR_ST8(p, v) do { v8d v_ = (v); std::memcpy((p), &v_, 64); } while (0)
+#define MBAR_BC8(x) ({ const double x_ = (x); v8d{x_, x_, x_, x_, x_, x_, x_, x_}; })
 constexpr int CHOL_BLOCK = 32;
+// rows i .. i + 3 (row[r]; rows past the matrix: a scratch row, their multipliers are zero), entries k0 .. kend - 1 (multiples of 8;
+// the overshoot past a row's diagonal lands in the unused upper triangle): row_r[k] -= sum_c L[i + r][c] L[k][c] over the block's
+// columns c, taken from the block-column buffer cb[c * ms + .] in ascending c
+#define MBAR_TRAIL4_BODY                                                                                                       \
+    for (int c = 0; c < CHOL_BLOCK; c += 4) {                                                                                  \
+        v8d l[4][4];                                                                                                           \
+        for (int r = 0; r < 4; ++r)                                                                                            \
+            for (int q = 0; q < 4; ++q) l[r][q] = MBAR_BC8(r < nr ? cb[(size_t)(c + q) * ms + i + r] : 0.0);                   \
+        const double *c0 = cb + (size_t)c * ms, *c1 = c0 + ms, *c2 = c1 + ms, *c3 = c2 + ms;                                   \
+        for (int k = k0; k < kend; k += 8) {                                                                                   \
+            const v8d x0 = MBAR_LD8(c0 + k), x1 = MBAR_LD8(c1 + k), x2 = MBAR_LD8(c2 + k), x3 = MBAR_LD8(c3 + k);              \
+            for (int r = 0; r < 4; ++r) {                                                                                      \
+                v8d a = MBAR_LD8(row[r] + k);                                                                                  \
+                a -= l[r][0] * x0;                                                                                             \
+                a -= l[r][1] * x1;                                                                                             \
+                a -= l[r][2] * x2;                                                                                             \
+                a -= l[r][3] * x3;                                                                                             \
+                MBAR_ST8(row[r] + k, a);                                                                                       \
+            }                                                                                                                  \
+        }                                                                                                                      \
+    }
+void trail4_base(double* const* row, const double* cb, size_t ms, int i, int nr, int k0, int kend) { MBAR_TRAIL4_BODY }
+__attribute__((target("avx2,fma")))
+void trail4_avx2(double* const* row, const double* cb, size_t ms, int i, int nr, int k0, int kend) { MBAR_TRAIL4_BODY }
+__attribute__((target("avx512f")))
+void trail4_avx512(double* const* row, const double* cb, size_t ms, int i, int nr, int k0, int kend) { MBAR_TRAIL4_BODY }
+#undef MBAR_TRAIL4_BODY
+// rows i0 .. i0 + nr - 1 (nr <= 8, i0 a multiple of 8) against the diagonal block at column j0 (jb columns; Lt[c * B + k] =
+// L[j0 + k][j0 + c], inv[c] = 1 / L[j0 + c][j0 + c]): x L_block^T = A[rows, block], one row per vector lane; the result also goes
+// into the block-column buffer (cb[c * ms + row], the transposed copy phase 2 reads along)
+#define MBAR_SOLVE8_BODY                                                                                                       \
+    v8d xt[CHOL_BLOCK];                                                                                                        \
+    for (int c = 0; c < jb; ++c) {                                                                                             \
+        double tmp[8];                                                                                                         \
+        for (int r = 0; r < 8; ++r) tmp[r] = r < nr ? row0[(size_t)r * S + j0 + c] : 0.0;                                      \
+        xt[c] = MBAR_LD8(tmp);                                                                                                 \
+    }                                                                                                                          \
+    for (int c = 0; c < jb; ++c) {                                                                                             \
+        const v8d v = xt[c] * MBAR_BC8(inv[c]);                                                                                \
+        xt[c] = v;                                                                                                             \
+        const double* lt = Lt + c * CHOL_BLOCK;                                                                                \
+        for (int k = c + 1; k < jb; ++k) xt[k] -= v * MBAR_BC8(lt[k]);                                                         \
+    }                                                                                                                          \
+    for (int c = 0; c < jb; ++c) {                                                                                             \
+        double tmp[8];                                                                                                         \
+        MBAR_ST8(tmp, xt[c]);                                                                                                  \
+        MBAR_ST8(cb + (size_t)c * ms + i0, xt[c]);                                                                             \
+        for (int r = 0; r < nr; ++r) row0[(size_t)r * S + j0 + c] = tmp[r];                                                    \
+    }
+void solve8_base(double* row0, size_t S, int nr, int j0, int jb, const double* Lt, const double* inv, double* cb, size_t ms, int i0) { MBAR_SOLVE8_BODY }
+__attribute__((target("avx2,fma")))
+void solve8_avx2(double* row0, size_t S, int nr, int j0, int jb, const double* Lt, const double* inv, double* cb, size_t ms, int i0) { MBAR_SOLVE8_BODY }
+__attribute__((target("avx512f")))
+void solve8_avx512(double* row0, size_t S, int nr, int j0, int jb, const double* Lt, const double* inv, double* cb, size_t ms, int i0) { MBAR_SOLVE8_BODY }
+#undef MBAR_SOLVE8_BODY
+// The team of host threads behind the blocked factorisation: created on first use and parked on a condition variable between
+// calls (the host-driven loop factors once per iteration: creating and joining four to fifteen threads every time cost more than
+// the factorisation of 511 unknowns itself).  run(T, fn): fn(0) on the caller's thread, fn(1 .. T-1) on workers; one job at a time.
+class HostTeam {
+public:
+    void run(int T, const std::function<void(int)>& fn) {
+        if (T <= 1) {
+            fn(0);
+            return;
+        }
+        std::lock_guard<std::mutex> one_job(run_mu_);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            if (pid_ != getpid()) {  // (a forked child has none of the parent's threads: start over, leaking the parent's handles)
+                workers_ = new std::vector<std::thread>();
+                pid_ = getpid();
+            }
+            while ((int)workers_->size() < T - 1) {
+                const int id = (int)workers_->size() + 1;
+                workers_->emplace_back([this, id] { worker(id); });
+            }
+            job_ = &fn;
+            active_ = T;
+            remaining_ = T - 1;
+            ++generation_;
+        }
+        cv_go_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return remaining_ == 0; });
+        job_ = nullptr;
+    }
+    ~HostTeam() {
+        if (!workers_ || pid_ != getpid()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_go_.notify_all();
+        for (auto& w : *workers_) w.join();
+        delete workers_;
+    }
+
+private:
+    void worker(int id) {
+        int seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_go_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            if (id >= active_) continue;
+            const std::function<void(int)>* f = job_;
+            lk.unlock();
+            (*f)(id);
+            lk.lock();
+            if (--remaining_ == 0) cv_done_.notify_one();
+        }
+    }
+    std::mutex run_mu_, mu_;
+    std::condition_variable cv_go_, cv_done_;
+    std::vector<std::thread>* workers_ = nullptr;
+    const std::function<void(int)>* job_ = nullptr;
+    int generation_ = 0, active_ = 0, remaining_ = 0;
+    bool stop_ = false;
+    pid_t pid_ = 0;
+};
+HostTeam g_team;
+
 constexpr int CHOL_BLOCKED_MIN = 320;   // unknowns from which the blocked form is used ...
 constexpr int CHOL_THREADED_MIN = 448;  // ... and from which it is worth a team (below: one thread, same code)
 int host_team_size(int m) {
@@ -125,113 +241,137 @@ bool chol_solve_blocked(std::vector<double>& A, std::vector<double>& b, int m, i
     for (int j = 0; j < m; ++j) dmax = std::max(dmax, A[(size_t)j * m + j]);
     const double thr = dmax * std::numeric_limits<double>::epsilon() * m;
     constexpr int B = CHOL_BLOCK;
-    const size_t ms = ((size_t)m + 7) & ~(size_t)7;  // padded length of a block column: chunks of 8 rows = whole cache lines
+    // The right-hand side rides along as one more row BELOW the matrix (row mv, in a chunk of its own): what the two phases leave
+    // in it is y = L^-1 b -- the forward substitution, done by the team as part of the factorisation.
+    const int mv = (m + 7) & ~7;
+    const size_t ms = (size_t)mv + 8;  // padded length of a row / of a block column: whole cache lines
+    const size_t S = ms;
     struct Free { void operator()(void* q) const { std::free(q); } };
-    std::unique_ptr<double, Free> colmem((double*)std::aligned_alloc(64, 2 * (size_t)B * ms * sizeof(double)));
-    if (!colmem) return false;
-    double* const colbuf[2] = {colmem.get(), colmem.get() + (size_t)B * ms};  // colbuf[block & 1][c * ms + i] = L[i][j0 + c]
-    double Lt[B * B];  // the current diagonal block's factor, transposed: Lt[c * B + k] = L[j0 + k][j0 + c]
-    const auto update8 = __builtin_cpu_supports("avx512f") ? row_update8_avx512
-                         : (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? row_update8_avx2 : row_update8_base;
+    // [the lower triangle, rows padded][two block-column buffers][one scratch row per thread]
     const int T = std::max(1, threads);
+    // (the workspace outlives the call: a fresh 2-8 MB allocation is page-faulted in on first touch, which costs as much as a
+    // third of the factorisation -- the host-driven loop calls this once per iteration from the same thread)
+    static thread_local std::unique_ptr<double, Free> mem;
+    static thread_local size_t mem_doubles = 0;
+    const size_t want = (size_t)(mv + 1) * S + 2 * (size_t)B * ms + (size_t)T * S;
+    if (mem_doubles < want) {
+        mem.reset((double*)std::aligned_alloc(64, ((want * sizeof(double) + 63) / 64) * 64));
+        mem_doubles = mem ? want : 0;
+        if (!mem) return false;
+    }
+    double* const L = mem.get();
+    double* const colbuf[2] = {L + (size_t)(mv + 1) * S, L + (size_t)(mv + 1) * S + (size_t)B * ms};  // colbuf[block & 1][c * ms + i] = L[i][j0 + c]
+    double* const scratch = colbuf[1] + (size_t)B * ms;
+    std::memset(colbuf[0], 0, (2 * (size_t)B * ms + (size_t)T * S) * sizeof(double));
+    double Lt[B * B], inv[B];  // the current diagonal block's factor, transposed: Lt[c * B + k] = L[j0 + k][j0 + c]; reciprocal pivots
+    const bool avx512 = __builtin_cpu_supports("avx512f"), avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    const auto trail4 = avx512 ? trail4_avx512 : avx2 ? trail4_avx2 : trail4_base;
+    const auto solve8 = avx512 ? solve8_avx512 : avx2 ? solve8_avx2 : solve8_base;
     const int nblk = (m + B - 1) / B;
-    std::atomic<int> diag_ready{-1}, arrived{0}, failed{0};
+    const int vchunk = mv / 8;  // the chunk of the right-hand side's row
+    std::atomic<int> diag_ready{-1}, arrived{0}, failed{0}, copied{0};
     auto spin_until = [&](auto&& cond) {
         int spins = 0;
         while (!cond())
             if (++spins > 8192) std::this_thread::yield();
     };
-    // rows [i_lo, i_hi) owned by thread t: chunks of eight by absolute row index, dealt round-robin
-    auto for_my_rows = [&](int t, int i_lo, auto&& fn) {
-        for (int q = i_lo / 8; q * 8 < m; ++q) {
-            if (q % T != t) continue;
-            for (int i = std::max(q * 8, i_lo); i < std::min(q * 8 + 8, m); ++i) fn(i);
-        }
+    // chunks of eight rows by absolute row index, dealt round-robin: fn(first row, rows) for thread t's chunks from row i_lo on
+    auto for_my_chunks = [&](int t, int i_lo, auto&& fn) {
+        for (int q = i_lo / 8; q <= vchunk; ++q)
+            if (q % T == t) fn(q * 8, q == vchunk ? 1 : std::min(8, m - q * 8));
     };
-    auto phase2_row = [&](int i, int bi_prev) {  // trailing entries of row i: columns j1(prev) .. i
+    // trailing entries (columns from the end of block bi_prev on) of the rows i0 .. i0 + n - 1, n <= 8, in groups of four
+    auto phase2_rows = [&](int t, int i0, int n, int bi_prev) {
         const int k0 = (bi_prev + 1) * B;
-        double* row = A.data() + (size_t)i * m;
         const double* cb = colbuf[bi_prev & 1];
-        for (int c = 0; c < B; c += 8) update8(row, cb + (size_t)c * ms, ms, i, k0, i);
-    };
-    auto phase1_row = [&](int i, int bi) {  // row i of the triangular solve x L_block^T = A[i, block], column by column
-        const int j0 = bi * B, jb = std::min(B, m - j0);
-        double* rb = A.data() + (size_t)i * m + j0;
-        double* cb = colbuf[bi & 1];
-        for (int c = 0; c < jb; ++c) {
-            const double v = rb[c] / Lt[c * B + c];
-            rb[c] = v;
-            cb[(size_t)c * ms + i] = v;
-            const double* lt = Lt + c * B;  // lt[k] = L[j0 + k][j0 + c]
-            for (int k = c + 1; k < jb; ++k) rb[k] -= v * lt[k];
+        for (int g = 0; g < n; g += 4) {
+            const int i = i0 + g, nr = std::min(4, n - g);
+            double* row[4];
+            for (int r = 0; r < 4; ++r) row[r] = r < nr ? L + (size_t)(i + r) * S : scratch + (size_t)t * S;
+            trail4(row, cb, ms, i, nr, k0, std::min((i + nr + 7) & ~7, mv));
         }
     };
     auto factor_diag = [&](int bi) -> bool {  // plain column Cholesky of the B x B block, then its transpose for phase 1
         const int j0 = bi * B, j1 = std::min(j0 + B, m);
         for (int c = j0; c < j1; ++c) {
-            double* rc_ = A.data() + (size_t)c * m;
+            double* rc_ = L + (size_t)c * S;
             double d = rc_[c];
             for (int k = j0; k < c; ++k) d -= rc_[k] * rc_[k];
             if (!(d > thr) || !std::isfinite(d)) return false;
             d = std::sqrt(d);
             rc_[c] = d;
+            inv[c - j0] = 1.0 / d;
             for (int i = c + 1; i < j1; ++i) {
-                double* ri = A.data() + (size_t)i * m;
+                double* ri = L + (size_t)i * S;
                 double v = ri[c];
                 for (int k = j0; k < c; ++k) v -= ri[k] * rc_[k];
-                ri[c] = v / d;
+                ri[c] = v * inv[c - j0];
             }
         }
         for (int c = 0; c < j1 - j0; ++c)
-            for (int k = c; k < j1 - j0; ++k) Lt[c * B + k] = A[(size_t)(j0 + k) * m + j0 + c];
+            for (int k = c; k < j1 - j0; ++k) Lt[c * B + k] = L[(size_t)(j0 + k) * S + j0 + c];
         return true;
     };
+    const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
+    double tp_diag = 0, tp_p1 = 0, tp_p2 = 0, tp_wait = 0;  // (thread 0's phases, MBAR_DEBUG_TIMING)
     auto run = [&](int t) {
+        const bool tm = dbg && t == 0;
+        double q0 = tm ? now_ms() : 0.0, q1;
+        auto lap = [&](double& into) { if (tm) { q1 = now_ms(); into += q1 - q0; q0 = q1; } };
+        // own chunks of the lower triangle into the aligned copy (first touch by the thread that works on them)
+        for_my_chunks(t, 0, [&](int i0, int n) {
+            for (int i = i0; i < i0 + n; ++i) {
+                double* dst = L + (size_t)i * S;
+                const size_t len = i == mv ? (size_t)m : (size_t)(i + 1);
+                std::memcpy(dst, i == mv ? b.data() : A.data() + (size_t)i * m, len * sizeof(double));
+                std::memset(dst + len, 0, (S - len) * sizeof(double));
+            }
+        });
+        copied.fetch_add(1, std::memory_order_acq_rel);
+        spin_until([&]() { return copied.load(std::memory_order_acquire) >= T; });
+        lap(tp_wait);
         for (int bi = 0; bi < nblk; ++bi) {
             const int j1 = std::min((bi + 1) * B, m);
             if (t == 0) {
                 if (bi > 0)
-                    for (int i = bi * B; i < j1; ++i) phase2_row(i, bi - 1);  // the next diagonal block's rows first
+                    for (int i0 = bi * B; i0 < j1; i0 += 8) phase2_rows(0, i0, std::min(8, j1 - i0), bi - 1);  // the next diagonal block's rows first
+                lap(tp_p2);
                 if (!factor_diag(bi)) {
                     failed.store(1, std::memory_order_release);
                     return;
                 }
                 diag_ready.store(bi, std::memory_order_release);
+                lap(tp_diag);
             }
-            if (j1 >= m) return;  // (the last block has no rows below it)
-            if (bi > 0) for_my_rows(t, j1, [&](int i) { phase2_row(i, bi - 1); });
+            const int i_lo = j1 >= m ? mv : j1;  // (below the last block: the right-hand side's row only)
+            if (bi > 0) for_my_chunks(t, i_lo, [&](int i0, int n) { phase2_rows(t, i0, n, bi - 1); });
+            lap(tp_p2);
             if (t != 0) {
                 spin_until([&]() { return diag_ready.load(std::memory_order_acquire) >= bi || failed.load(std::memory_order_acquire); });
                 if (failed.load(std::memory_order_acquire)) return;
             }
-            for_my_rows(t, j1, [&](int i) { phase1_row(i, bi); });
+            for_my_chunks(t, i_lo, [&](int i0, int n) { solve8(L + (size_t)i0 * S, S, n, bi * B, j1 - bi * B, Lt, inv, colbuf[bi & 1], ms, i0); });
+            lap(tp_p1);
             arrived.fetch_add(1, std::memory_order_acq_rel);
             spin_until([&]() { return arrived.load(std::memory_order_acquire) >= T * (bi + 1) || failed.load(std::memory_order_acquire); });
+            lap(tp_wait);
             if (failed.load(std::memory_order_acquire)) return;
         }
     };
-    const bool dbg = std::getenv("MBAR_DEBUG_TIMING") != nullptr;
     const double t_begin = dbg ? now_ms() : 0.0;
-    {
-        std::vector<std::thread> team;
-        for (int t = 1; t < T; ++t) team.emplace_back(run, t);
-        run(0);
-        for (auto& th : team) th.join();
-    }
-    if (dbg) std::fprintf(stderr, "[mbar] blocked Cholesky m=%d, %d threads: factorisation %.3f ms\n", m, T, now_ms() - t_begin);
+    g_team.run(T, run);
+    const double t_fact = dbg ? now_ms() : 0.0;
     if (failed.load()) return false;
-    for (int i = 0; i < m; ++i) {  // L y = b
-        double s = b[i];
-        const double* row = A.data() + (size_t)i * m;
-        for (int k = 0; k < i; ++k) s -= row[k] * b[k];
-        b[i] = s / row[i];
-    }
+    std::memcpy(b.data(), L + (size_t)mv * S, (size_t)m * sizeof(double));  // y = L^-1 b
     for (int i = m - 1; i >= 0; --i) {  // L^T x = y, along the rows of L
-        const double* row = A.data() + (size_t)i * m;
+        const double* row = L + (size_t)i * S;
         const double xi = b[i] / row[i];
         b[i] = xi;
         for (int k = 0; k < i; ++k) b[k] -= row[k] * xi;
     }
+    if (dbg)
+        std::fprintf(stderr, "[mbar] blocked Cholesky m=%d, %d threads: factorisation %.3f ms (thread 0: diagonal blocks %.3f, rows against the block %.3f, trailing updates %.3f, copy + waiting %.3f), substitutions %.3f ms\n",
+                     m, T, t_fact - t_begin, tp_diag, tp_p1, tp_p2, tp_wait, now_ms() - t_fact);
     for (int i = 0; i < m; ++i)
         if (!std::isfinite(b[i])) return false;
     return true;

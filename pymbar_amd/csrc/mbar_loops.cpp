@@ -127,7 +127,7 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
         used = true;
         return MBAR_OK;
     };
-    double tA = 0, tH = 0, tB = 0;
+    double tA = 0, tH = 0, tB = 0, tA_unpack = 0, tH_solve = 0;
     const int64_t it0 = res.iterations;
     const double t0 = now_ms();
     for (int64_t it = it0; it < maxiter && !done; ++it) {
@@ -168,10 +168,12 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
             HIPCHK(c, hipMemcpyAsync(c->hred, c->red, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             rc = sync_stream(c);
             if (rc) return rc;
+            const double t_u0 = dbg ? now_ms() : 0.0;
             unpack_gram(pl, c->hred, K, gram.data());
             if (hp)  // the per-state factors the P-mode sweep leaves out
                 for (int64_t i = 0; i < K; ++i)
                     for (int64_t j = 0; j < K; ++j) gram[(size_t)i * K + j] *= cm[i] * cm[j];
+            if (dbg) tA_unpack += now_ms() - t_u0;
         }
         const double t_a1 = now_ms();
         for (int i = 0; i < m; ++i) {
@@ -180,7 +182,9 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
             for (int j = 0; j < m; ++j) H[(size_t)i * m + j] = -gram[(size_t)ki * K + c->sampled[j]];
             H[(size_t)i * m + i] += psum[ki];
         }
+        const double t_s0 = dbg ? now_ms() : 0.0;
         newton_direction(H, g, m, x);  // :582-583
+        if (dbg) tH_solve += now_ms() - t_s0;
         double* f_sci = cand.data();
         double* f_nr = cand.data() + K;
         std::copy(f.begin(), f.end(), f_sci);
@@ -278,8 +282,8 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
     }
     const int64_t nit = res.iterations - it0;
     if (dbg && nit > 0)
-        std::fprintf(stderr, "[mbar] adaptive (host loop): %lld it, per it: passA %.3f ms, host solve %.3f ms, passB %.3f ms, total %.3f ms\n",
-                     (long long)nit, tA / nit, tH / nit, tB / nit, (now_ms() - t0) / nit);
+        std::fprintf(stderr, "[mbar] adaptive (host loop): %lld it, per it: passA %.3f ms (of it unpacking %.3f), host solve %.3f ms (of it the factorisation + substitutions %.3f), passB %.3f ms, total %.3f ms\n",
+                     (long long)nit, tA / nit, tA_unpack / nit, tH / nit, tH_solve / nit, tB / nit, (now_ms() - t0) / nit);
     return MBAR_OK;
 }
 

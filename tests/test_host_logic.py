@@ -411,7 +411,8 @@ def _mbar_like_hessian(m, rng, disconnected=False):
     return np.diag(W.sum(0)) - W.T @ W
 
 
-@pytest.mark.parametrize("m", [2, 5, 40, 130, 330, 401])
+# (321: the first blocked size; 353: 352 unknowns = eleven full blocks, only the right-hand side's row below the last; 330 / 401 / 520: a partial last block)
+@pytest.mark.parametrize("m", [2, 5, 40, 130, 321, 330, 353, 401, 520])
 def test_host_newton_direction_matches_lstsq(m):
     """The K x K step of the host-driven loop (``mbar_host_newton_direction``): lstsq(H, g) minus its first component
     (mbar_solvers.py:582-583) -- plain Cholesky below 320 unknowns, column blocks shared out over host threads above; the
@@ -427,7 +428,7 @@ def test_host_newton_direction_matches_lstsq(m):
     scale = np.abs(ref).max()
     x = _lib.host_newton_direction(H, g)
     assert x[0] == 0.0 and np.abs(x - ref).max() <= 1e-10 * scale
-    teams = [_lib.host_newton_direction(H, g, threads=t) for t in (1, 2, 5)]
+    teams = [_lib.host_newton_direction(H, g, threads=t) for t in (1, 2, 5, 7)]
     for xt in teams:
         assert np.array_equal(xt, teams[0]) and np.abs(xt - ref).max() <= 1e-10 * scale
     x_old = _lib.host_newton_direction(H, g, threads=-1)  # the panels-of-4 factorisation
