@@ -75,7 +75,10 @@ int mbar_ctx_synchronize(mbar_ctx* ctx);
 int mbar_cache_trim(void);
 /* Environment variables read by the library (diagnostics; none changes a result):
  *   MBAR_CACHE_MB        bound of the block cache above (MBAR_CACHE_IDLE_MB: what it keeps once no context is left)
- *   MBAR_HOST_THREADS    team size of the host-side K x K factorisation (default: all cores, at most 16)
+ *   MBAR_HOST_THREADS    team size of the host-side K x K factorisation (default: one thread per 96 unknowns, at most 16 and at
+ *                        most the cores that share the L3 cache with the caller's core; the team's worker threads are created on
+ *                        first use, parked between calls and kept on those cores -- the caller's own thread is never touched)
+ *   MBAR_HOST_TEAM_AFFINITY  0 = leave the placement of the team's workers to the scheduler
  *   MBAR_DEBUG_TIMING    per-iteration wall-clock split of the host-driven loops and of the host factorisation on stderr
  *   MBAR_DEBUG_STAMPS    in-kernel time stamps on stderr: the phases of k_select_newton (selection / set-up / elimination /
  *                        candidates, shader clocks) and of k_sci_small (tables, update, first tile, sweep per wave, fold) */

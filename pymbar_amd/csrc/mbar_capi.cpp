@@ -412,6 +412,41 @@ void unpack_gram(const GramPlan& plan, const double* blocks, int64_t K, double* 
     }
 }
 
+// The host-driven loop's Newton matrix straight from the reduced blocks (one pass instead of blocks -> K x K matrix -> scaling ->
+// m x m matrix): H[i][j] = -G[k_i][k_j] f[k_i] f[k_j] over the states with samples (pos[k] = position of state k among them, -1:
+// none; f: the per-state factors the P-mode sweep leaves out, or nullptr), both triangles; the blocks are dealt over the host team.
+void unpack_gram_to_hessian(const GramPlan& plan, const double* blocks, int64_t K, const double* factor, const int* pos, int m, double* H,
+                            int threads) {
+    struct Blk { const double* p; int64_t gi0, gj0; bool tri; };
+    std::vector<Blk> list;
+    list.reserve(plan.total_blocks);
+    for (const auto& it : plan.items) {
+        int b = 0;
+        for (int I = 0; I < it.nbi; ++I)
+            for (int J = it.diag ? I : 0; J < it.nbj; ++J) list.push_back({blocks + (it.off + b++) * 256, it.ri + 16 * I, it.rj + 16 * J, it.diag && I == J});
+    }
+    const int T = std::max(1, std::min<int>(threads, (int)list.size() / 64));
+    host_team_run(T, [&](int t) {
+        for (size_t n = t; n < list.size(); n += T) {
+            const Blk& bk = list[n];
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gi = bk.gi0 + r;
+                const int i = gi < K ? pos[gi] : -1;
+                if (i < 0) continue;
+                const double fi = factor ? -factor[gi] : -1.0;
+                for (int q = bk.tri ? r : 0; q < 16; ++q) {
+                    const int64_t gj = bk.gj0 + q;
+                    const int j = gj < K ? pos[gj] : -1;
+                    if (j < 0) continue;
+                    const double v = bk.p[r * 16 + q] * (factor ? fi * factor[gj] : fi);
+                    H[(size_t)i * m + j] = v;
+                    H[(size_t)j * m + i] = v;
+                }
+            }
+        }
+    });
+}
+
 int ensure_red(mbar_ctx* c, size_t want) {
     if (c->red_doubles >= want) return MBAR_OK;
     {

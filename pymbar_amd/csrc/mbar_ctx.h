@@ -418,6 +418,8 @@ int quad_live_blocks(const mbar_ctx* c);
 int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan, const double* pmat = nullptr);
 void gram_operand_sums(const double* G, int64_t K, const double* w, double* out);
 void unpack_gram(const GramPlan& plan, const double* blocks, int64_t K, double* G);
+void unpack_gram_to_hessian(const GramPlan& plan, const double* blocks, int64_t K, const double* factor, const int* pos, int m, double* H,
+                            int threads);
 int ensure_red(mbar_ctx* c, size_t want);
 int64_t lse_rows(const mbar_ctx* c);
 int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0, double* ld1, double* psum,
@@ -425,7 +427,9 @@ int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0,
 double now_ms();
 bool chol_solve(std::vector<double>& A, std::vector<double>& b, int m);
 int host_team_size(int m);
-bool chol_solve_blocked(std::vector<double>& A, std::vector<double>& b, int m, int threads);
+bool chol_solve_blocked(const double* A, size_t lda, std::vector<double>& b, int m, int threads);
+void host_team_run(int threads, const std::function<void(int)>& fn);  // fn(0) on the caller, fn(1 .. threads-1) on the parked team
+int host_team_size(int m);
 void jacobi_eigh(std::vector<double> A, int m, std::vector<double>& w, std::vector<double>& V);
 void newton_direction(const std::vector<double>& H, const std::vector<double>& g, int m, std::vector<double>& x);
 int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t maxiter, int64_t min_sc_iter, double gamma,

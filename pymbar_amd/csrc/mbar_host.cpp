@@ -173,6 +173,7 @@ public:
                 const int id = (int)workers_->size() + 1;
                 workers_->emplace_back([this, id] { worker(id); });
             }
+            gather_near_caller();
             job_ = &fn;
             active_ = T;
             remaining_ = T - 1;
@@ -183,6 +184,13 @@ public:
         std::unique_lock<std::mutex> lk(mu_);
         cv_done_.wait(lk, [&] { return remaining_ == 0; });
         job_ = nullptr;
+    }
+    // team size for a caller that would like T threads: no more than the caller's core + the free cores of its L3 domain
+    int suggest(int T) {
+        if (T <= 1) return T;
+        std::lock_guard<std::mutex> lk(mu_);
+        (void)refresh_near();
+        return near_.empty() ? T : std::min<int>(T, (int)near_.size() + 1);
     }
     ~HostTeam() {
         if (!workers_ || pid_ != getpid()) return;
@@ -196,6 +204,80 @@ public:
     }
 
 private:
+    // The team exchanges a block column (0.1-0.3 MB) per block: between cores of different L3 domains (8 cores each on the EPYC hosts
+    // of the MI355X boxes) that goes through memory.  The workers are therefore kept on the CPUs that share the L3 cache with the
+    // CPU the caller is on right now (one worker per physical core while they last); the caller's own thread is never touched.
+    // Skipped when the domain cannot be read or the process may not run on enough of its CPUs.  MBAR_HOST_TEAM_AFFINITY=0: off.
+    // (call with mu_ held) CPUs for the workers near the caller's current CPU -> near_; true if they changed
+    bool refresh_near() {
+        static const bool enabled = [] { const char* e = std::getenv("MBAR_HOST_TEAM_AFFINITY"); return !e || std::atoi(e) != 0; }();
+        if (!enabled) return false;
+        const int cpu = sched_getcpu();
+        if (cpu < 0) return false;
+        auto read_list = [](const std::string& path, std::vector<int>& out) {
+            out.clear();
+            FILE* fh = std::fopen(path.c_str(), "r");
+            if (!fh) return;
+            char buf[4096];
+            if (std::fgets(buf, sizeof(buf), fh)) {
+                for (char* p = buf; *p;) {
+                    char* end;
+                    const long a = std::strtol(p, &end, 10);
+                    if (end == p) break;
+                    long b2 = a;
+                    if (*end == '-') b2 = std::strtol(end + 1, &end, 10);
+                    for (long v = a; v <= b2 && v < CPU_SETSIZE; ++v) out.push_back((int)v);
+                    p = (*end == ',') ? end + 1 : end;
+                    if (*end != ',') break;
+                }
+            }
+            std::fclose(fh);
+        };
+        const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string(cpu);
+        std::vector<int> dom;
+        read_list(base + "/cache/index3/shared_cpu_list", dom);
+        if (dom.empty()) return false;
+        const int key = dom.front();
+        if (key == near_key_) return false;
+        near_key_ = key;
+        near_.clear();
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+        // one CPU per physical core first (the first sibling of every core of the domain), the caller's core last
+        std::vector<int> firsts, sib;
+        for (int cid : dom) {
+            if (!CPU_ISSET(cid, &allowed)) continue;
+            read_list("/sys/devices/system/cpu/cpu" + std::to_string(cid) + "/topology/thread_siblings_list", sib);
+            if (!sib.empty() && sib.front() != cid) continue;
+            if (!sib.empty() && std::find(sib.begin(), sib.end(), cpu) != sib.end()) continue;  // (the caller's core)
+            firsts.push_back(cid);
+        }
+        near_ = firsts;
+        return true;
+    }
+    void gather_near_caller() {
+        (void)refresh_near();
+        if (near_.empty() || (pin_key_ == near_key_ && pinned_workers_ == workers_->size())) return;
+        pin_key_ = near_key_;
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+        for (size_t w = 0; w < workers_->size(); ++w) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (w < near_.size()) {
+                CPU_SET(near_[w], &set);
+            } else {  // more workers than free cores in the domain: the rest may run anywhere the process may
+                set = allowed;
+            }
+            (void)pthread_setaffinity_np((*workers_)[w].native_handle(), sizeof(set), &set);
+        }
+        pinned_workers_ = workers_->size();
+    }
+    std::vector<int> near_;
+    int near_key_ = -1, pin_key_ = -2;
+    size_t pinned_workers_ = 0;
     void worker(int id) {
         int seen = 0;
         std::unique_lock<std::mutex> lk(mu_);
@@ -221,7 +303,7 @@ private:
 };
 HostTeam g_team;
 
-constexpr int CHOL_BLOCKED_MIN = 320;   // unknowns from which the blocked form is used ...
+constexpr int CHOL_BLOCKED_MIN = 64;    // unknowns from which the blocked form is used (round 5: it wins from here on, 4.5x at 255) ...
 constexpr int CHOL_THREADED_MIN = 448;  // ... and from which it is worth a team (below: one thread, same code)
 int host_team_size(int m) {
     if (m < CHOL_THREADED_MIN) return 1;
@@ -234,11 +316,13 @@ int host_team_size(int m) {
     }
     if (const char* e = std::getenv("MBAR_HOST_THREADS")) t = std::atoi(e);
     t = std::max(1, std::min(t, 16));
-    return std::min(t, std::max(1, m / 96));
+    return g_team.suggest(std::min(t, std::max(1, m / 96)));
 }
-bool chol_solve_blocked(std::vector<double>& A, std::vector<double>& b, int m, int threads) {
+void host_team_run(int threads, const std::function<void(int)>& fn) { g_team.run(threads, fn); }
+// A: m x m, row pitch lda, only its lower triangle is read (and nothing of it written); b: in the right-hand side, out the solution.
+bool chol_solve_blocked(const double* A, size_t lda, std::vector<double>& b, int m, int threads) {
     double dmax = 0.0;
-    for (int j = 0; j < m; ++j) dmax = std::max(dmax, A[(size_t)j * m + j]);
+    for (int j = 0; j < m; ++j) dmax = std::max(dmax, A[(size_t)j * lda + j]);
     const double thr = dmax * std::numeric_limits<double>::epsilon() * m;
     constexpr int B = CHOL_BLOCK;
     // The right-hand side rides along as one more row BELOW the matrix (row mv, in a chunk of its own): what the two phases leave
@@ -323,7 +407,7 @@ bool chol_solve_blocked(std::vector<double>& A, std::vector<double>& b, int m, i
             for (int i = i0; i < i0 + n; ++i) {
                 double* dst = L + (size_t)i * S;
                 const size_t len = i == mv ? (size_t)m : (size_t)(i + 1);
-                std::memcpy(dst, i == mv ? b.data() : A.data() + (size_t)i * m, len * sizeof(double));
+                std::memcpy(dst, i == mv ? b.data() : A + (size_t)i * lda, len * sizeof(double));
                 std::memset(dst + len, 0, (S - len) * sizeof(double));
             }
         });
@@ -424,12 +508,17 @@ void newton_direction(const std::vector<double>& H, const std::vector<double>& g
     x.assign(m, 0.0);
     if (m <= 1) return;
     const int r = m - 1;
-    std::vector<double> A((size_t)r * r), b(r);
-    for (int i = 0; i < r; ++i) {
-        b[i] = g[i + 1];
-        for (int j = 0; j < r; ++j) A[(size_t)i * r + j] = H[(size_t)(i + 1) * m + (j + 1)];
+    std::vector<double> b(g.begin() + 1, g.end());
+    bool ok;
+    if (r >= CHOL_BLOCKED_MIN) {  // (the blocked form works on its own aligned copy of the lower triangle: straight from H)
+        ok = chol_solve_blocked(H.data() + m + 1, (size_t)m, b, r, host_team_size(r));
+    } else {
+        std::vector<double> A((size_t)r * r);
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < r; ++j) A[(size_t)i * r + j] = H[(size_t)(i + 1) * m + (j + 1)];
+        ok = chol_solve(A, b, r);
     }
-    if (r >= CHOL_BLOCKED_MIN ? chol_solve_blocked(A, b, r, host_team_size(r)) : chol_solve(A, b, r)) {
+    if (ok) {
         for (int i = 0; i < r; ++i) x[i + 1] = b[i];
         return;
     }
@@ -539,7 +628,7 @@ int mbar_host_newton_direction(const double* H, const double* g, int m, int thre
             b[i] = gv[i + 1];
             for (int j = 0; j < r; ++j) A[(size_t)i * r + j] = Hv[(size_t)(i + 1) * m + (j + 1)];
         }
-        if (r > 0 && (threads > 0 ? chol_solve_blocked(A, b, r, threads) : chol_solve(A, b, r))) {
+        if (r > 0 && (threads > 0 ? chol_solve_blocked(A.data(), (size_t)r, b, r, threads) : chol_solve(A, b, r))) {
             x[0] = 0.0;
             for (int i = 0; i < r; ++i) x[i + 1] = b[i];
             return MBAR_OK;

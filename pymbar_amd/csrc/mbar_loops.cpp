@@ -20,7 +20,9 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
     const int m = (int)c->sampled.size();
     const int first = c->sampled[0];
     std::vector<double> f_old(K), cand(2 * (size_t)K), psum2(2 * (size_t)K);
-    std::vector<double> gram((size_t)K * K), H((size_t)m * m), g(m), x;
+    std::vector<double> H((size_t)m * m), g(m), x;
+    std::vector<int> pos((size_t)K, -1);  // position of a state among those with samples
+    for (int i = 0; i < m; ++i) pos[(size_t)c->sampled[i]] = i;
     psum.assign(K, 0.0);
     int cur = 0;  // logden slot of the current f
     // initial gradient (mbar_solvers.py:570)
@@ -169,17 +171,14 @@ int adaptive_host_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_t 
             rc = sync_stream(c);
             if (rc) return rc;
             const double t_u0 = dbg ? now_ms() : 0.0;
-            unpack_gram(pl, c->hred, K, gram.data());
-            if (hp)  // the per-state factors the P-mode sweep leaves out
-                for (int64_t i = 0; i < K; ++i)
-                    for (int64_t j = 0; j < K; ++j) gram[(size_t)i * K + j] *= cm[i] * cm[j];
+            // H = -Gram (with the per-state factors the P-mode sweep leaves out), m x m over the sampled states; + diag below
+            unpack_gram_to_hessian(pl, c->hred, K, hp ? cm.data() : nullptr, pos.data(), m, H.data(), host_team_size(m));
             if (dbg) tA_unpack += now_ms() - t_u0;
         }
         const double t_a1 = now_ms();
         for (int i = 0; i < m; ++i) {
             const int ki = c->sampled[i];
             g[i] = psum[ki] - c->Nk[ki];
-            for (int j = 0; j < m; ++j) H[(size_t)i * m + j] = -gram[(size_t)ki * K + c->sampled[j]];
             H[(size_t)i * m + i] += psum[ki];
         }
         const double t_s0 = dbg ? now_ms() : 0.0;

@@ -21,6 +21,37 @@ def hessian(m):
 
 
 print(f"host: {os.cpu_count()} logical CPUs", flush=True)
+if "--small" in sys.argv:  # where the blocked form starts to pay: threads = -1 is the unblocked panels-of-4 factorisation
+    for m in (65, 129, 193, 257, 321, 385, 449):
+        H = hessian(m)
+        g = rng.normal(size=m) * 1e-2
+        g -= g.mean()
+        out = []
+        for th in (-1, 1, 2, 4):
+            ts = []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                _lib.host_newton_direction(H, g, threads=th)
+                ts.append(time.perf_counter() - t0)
+            out.append(f"{'panels of 4' if th < 0 else str(th) + ' threads'} {1e3 * min(ts):6.3f} ms")
+        print(f"{m - 1} unknowns: " + " | ".join(out), flush=True)
+    sys.exit(0)
+if "--cadence" in sys.argv:  # one call every ~6 ms, like the loop (the team asleep, its caches cold): median of 15
+    for m in (512, 1024):
+        H = hessian(m)
+        g = rng.normal(size=m) * 1e-2
+        g -= g.mean()
+        out = []
+        for th in (1, 2, 5, 8, 10, 16):
+            ts = []
+            for _ in range(15):
+                time.sleep(0.006)
+                t0 = time.perf_counter()
+                _lib.host_newton_direction(H, g, threads=th)
+                ts.append(time.perf_counter() - t0)
+            out.append(f"{th} threads {1e3 * sorted(ts)[7]:6.3f} ms")
+        print(f"{m - 1} unknowns, one call per 6 ms: " + " | ".join(out), flush=True)
+    sys.exit(0)
 for m in (512, 768, 1024):
     H = hessian(m)
     g = rng.normal(size=m) * 1e-2
