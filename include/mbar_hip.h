@@ -128,6 +128,7 @@ int mbar_device_synchronize(int device);
  *                    BOTH of its sweeps on it (one multiplication per element instead of an exponential): 2 = Gram sweep in
  *                    256-state panels, one read each, + 128 x 256 rectangles (default); 1 = in the 128-state panels and 64 x 128
  *                    rectangles of the sweep on u; 0 = both sweeps on u (what runs when P does not fit)
+ *   "rect_waves"     8 = the 128 x 256 rectangles of that Gram sweep run two waves per SIMD (default); 4 = one
  *   "pcache"         1 = the resident probability matrix outlives the solve that built it: a later adaptive solve on the same
  *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
  *                    one fused sweep instead of the build sweep (default); 0 = every solve builds (cold-solve timings)

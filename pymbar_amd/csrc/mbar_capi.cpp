@@ -314,7 +314,11 @@ int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t r
     for (const auto& it : plan.items) {
         if (!it.diag && it.nbj == 16) {  // P mode: rectangle against a 256-state panel, four waves on one shared tile stream
             if (!pmat) return fail(c, MBAR_ERR_STATE, "run_gram: the 256-column rectangles exist on the probability matrix only");
-            const LaunchGeom g = gram_quad_geometry(it.nbi + 16, c->num_cu, ntiles, c->opt_grid);
+            LaunchGeom g = gram_quad_geometry(it.nbi + 16, c->num_cu, ntiles, c->opt_grid);
+            if (it.nbi == 8 && c->opt_rect_waves == 8) {  // two waves per SIMD, 16 blocks each (+ their copies of the tile's reciprocals)
+                g.waves = 8;
+                g.lds_bytes += 2 * 4 * 1024;
+            }
             const size_t rec = (size_t)it.nblk * 256;
             int rc = ensure(c, &c->part, &c->part_doubles, (size_t)g.nwaves * rec);
             if (rc) return rc;
@@ -786,6 +790,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "direct_results") c->opt_direct_results = value;
     else if (k == "sci_merged") c->opt_sci_merged = value;
     else if (k == "host_pmode") c->opt_host_pmode = value;
+    else if (k == "rect_waves") c->opt_rect_waves = value == 8 ? 8 : 4;
     else if (k == "sci_pingpong") {
         c->opt_sci_pingpong = value;
         (void)drop_graphs(c);

@@ -254,6 +254,9 @@ private:
             firsts.push_back(cid);
         }
         near_ = firsts;
+        near_domain_.clear();
+        for (int cid : dom)
+            if (CPU_ISSET(cid, &allowed)) near_domain_.push_back(cid);
         return true;
     }
     void gather_near_caller() {
@@ -263,19 +266,18 @@ private:
         cpu_set_t allowed;
         CPU_ZERO(&allowed);
         if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+        // (the whole domain for every worker, not one CPU each: on a shared host the scheduler must be able to step around a core
+        // somebody else keeps busy -- a worker nailed to such a core stalls the whole team at its barriers)
+        cpu_set_t domain;
+        CPU_ZERO(&domain);
+        for (int cid : near_domain_) CPU_SET(cid, &domain);
         for (size_t w = 0; w < workers_->size(); ++w) {
-            cpu_set_t set;
-            CPU_ZERO(&set);
-            if (w < near_.size()) {
-                CPU_SET(near_[w], &set);
-            } else {  // more workers than free cores in the domain: the rest may run anywhere the process may
-                set = allowed;
-            }
+            const cpu_set_t& set = w < near_.size() ? domain : allowed;  // (more workers than cores in the domain: the rest anywhere)
             (void)pthread_setaffinity_np((*workers_)[w].native_handle(), sizeof(set), &set);
         }
         pinned_workers_ = workers_->size();
     }
-    std::vector<int> near_;
+    std::vector<int> near_, near_domain_;  // free physical cores of the caller's L3 domain (their first CPUs) / all of its allowed CPUs
     int near_key_ = -1, pin_key_ = -2;
     size_t pinned_workers_ = 0;
     void worker(int id) {

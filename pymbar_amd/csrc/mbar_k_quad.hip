@@ -281,15 +281,17 @@ k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
 // sweep reads the matrix 5.5 times at 1024 states instead of 11.5 (2.5 instead of 5.5 at 512).
 // Record: one per workgroup, block b = I * 16 + J (what unpack_gram expects of a rectangle).
 // ---------------------------------------------------------------------------------------------
-template <int NBI, int WV, bool WIDE>
+template <int NBI, int NWV, int WV, bool WIDE>
 __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, int64_t row_i0,
                                                int64_t row_j0, const double* __restrict__ rinv, double* __restrict__ gram_part,
                                                char* smem, int lane) {
-    constexpr int NBJ = 16, NBT = NBI + NBJ, ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
+    // NWV waves (4: one per SIMD; 8: two per SIMD, 16 blocks each -- while one of a SIMD's two waves stands in the barrier or waits
+    // for its first operands, the other's matrix instructions keep the pipe busy)
+    constexpr int NBJ = 16, NBT = NBI + NBJ, ROWS = NBT * 16, NQ = NBT / NWV, QDMA = ROWS / NWV / 8, NJW = NBJ / NWV;
     constexpr int U_BYTES = ROWS * TS * 8;
-    constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + one copy of the tile's 16 reciprocals per wave
-    constexpr int NBLK = NBI * NBJ, NMINE = NBLK / 4, NP = NBI + 4;
-    static_assert(NBT % 4 == 0 && NMINE >= QDMA + 2 && NMINE <= 32, "rectangle shape");
+    constexpr int TILE_BYTES = U_BYTES + NWV * 1024;  // + one copy of the tile's 16 reciprocals per wave
+    constexpr int NBLK = NBI * NBJ, NMINE = NBLK / NWV, NP = NBI + NJW;
+    static_assert(NBT % NWV == 0 && NBJ % NWV == 0 && NMINE >= QDMA + 2 && NMINE <= 32, "rectangle shape");
     const int ks = lane & 15, ns = lane >> 4;
     char* buf = smem + EXP_TABLE_BYTES;
     const RowTwoPanels rows{row_i0, row_j0, NBI * 16};
@@ -321,7 +323,7 @@ __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int
 #pragma unroll
         for (int I = 0; I < NBI; ++I) x[I] = *reinterpret_cast<const double*>(tb + I * (16 * TS * 8) + rd_base + pos[g]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) x[NBI + q] = *reinterpret_cast<const double*>(tb + (NBI + WV + 4 * q) * (16 * TS * 8) + rd_base + pos[g]);
+        for (int q = 0; q < NJW; ++q) x[NBI + q] = *reinterpret_cast<const double*>(tb + (NBI + WV + NWV * q) * (16 * TS * 8) + rd_base + pos[g]);
     };
     auto mfma = [&](int b, double x, double y) {
         if (b < GRAM_AGPR_BLOCKS)
@@ -377,8 +379,8 @@ __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int
 #pragma unroll
             for (int I = 0; I < NBI; ++I)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int mine = I * 4 + q;
+                for (int q = 0; q < NJW; ++q) {
+                    const int mine = I * NJW + q;
                     mfma(mine, p[g & 1][I], p[g & 1][NBI + q]);
                     if (mine == 0 && g < GROUPS - 1) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -418,24 +420,25 @@ __device__ __forceinline__ void gram_rect_body(const double* __restrict__ P, int
 #pragma unroll
     for (int I = 0; I < NBI; ++I)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NJW; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rec[((I * NBJ + WV + 4 * q) * 4 + r) * 64 + lane] = acc[I * 4 + q][r];
+            for (int r = 0; r < 4; ++r) rec[((I * NBJ + WV + NWV * q) * 4 + r) * 64 + lane] = acc[I * NJW + q][r];
 }
 
-template <int NBI, bool WIDE>
-__global__ void __launch_bounds__(256, 1)
+template <int NBI, int NWV, bool WIDE>
+__global__ void __launch_bounds__(64 * NWV, 1)
 k_gram_rect(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, int64_t row_i0, int64_t row_j0,
             const double* __restrict__ rinv, double* __restrict__ gram_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    switch (wave) {
-        case 0: gram_rect_body<NBI, 0, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
-        case 1: gram_rect_body<NBI, 1, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
-        case 2: gram_rect_body<NBI, 2, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
-        default: gram_rect_body<NBI, 3, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
+#define MBAR_CASE(W_) case W_: gram_rect_body<NBI, NWV, W_, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); break;
+    if constexpr (NWV == 8) {
+        switch (wave) { MBAR_CASE(0) MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) default: gram_rect_body<NBI, NWV, 7, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); }
+    } else {
+        switch (wave) { MBAR_CASE(0) MBAR_CASE(1) MBAR_CASE(2) default: gram_rect_body<NBI, NWV, 3, WIDE>(P, ld, N, ntiles, row_i0, row_j0, rinv, gram_part, smem, lane); }
     }
+#undef MBAR_CASE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -825,12 +828,13 @@ hipError_t launch_gram_rect(hipStream_t s, int nbi, const LaunchGeom& g, const d
             if (e != hipSuccess) return e;
         }
         const int64_t ntiles = (N + TS - 1) / TS;
-        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, P, ld, N, ntiles, ri, rj, rinv, gram_part);
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(64 * g.waves), g.lds_bytes, s, P, ld, N, ntiles, ri, rj, rinv, gram_part);
         return hipGetLastError();
     };
     const bool wide = stage_offsets_wide(ld);
-    if (nbi == 8) return wide ? launch(k_gram_rect<8, true>) : launch(k_gram_rect<8, false>);
-    if (nbi == 4) return wide ? launch(k_gram_rect<4, true>) : launch(k_gram_rect<4, false>);
+    if (nbi == 8 && g.waves == 8) return wide ? launch(k_gram_rect<8, 8, true>) : launch(k_gram_rect<8, 8, false>);
+    if (nbi == 8) return wide ? launch(k_gram_rect<8, 4, true>) : launch(k_gram_rect<8, 4, false>);
+    if (nbi == 4) return wide ? launch(k_gram_rect<4, 4, true>) : launch(k_gram_rect<4, 4, false>);
     return hipErrorInvalidValue;
 }
 template <int NBT>

@@ -147,6 +147,8 @@ def large():
         with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
             dm.set_Nk(N_k)
             dm.set_option("timing", 1)
+            if "RECT_WAVES" in os.environ:
+                dm.set_option("rect_waves", int(os.environ["RECT_WAVES"]))  # 4: one wave per SIMD in the 128 x 256 rectangles
             if "HOST_PMODE" in os.environ:
                 dm.set_option("host_pmode", int(os.environ["HOST_PMODE"]))  # 0: Gram sweep on u (exponentials per panel)
             dm.solve_adaptive(np.zeros(K), maxiter=2, min_sc_iter=0, check_convergence=False)
