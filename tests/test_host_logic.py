@@ -435,6 +435,40 @@ def test_host_newton_direction_matches_lstsq(m):
     assert np.abs(x_old - ref).max() <= 1e-10 * scale
 
 
+def test_host_team_survives_a_fork():
+    """The factorisation's worker threads are parked between calls; a forked child has none of them and must start its own team on
+    first use instead of waiting for threads that do not exist in it."""
+    import os
+
+    from pymbar_amd import _lib
+
+    rng = np.random.default_rng(3)
+    H = _mbar_like_hessian(500, rng)
+    g = rng.normal(size=500) * 1e-2
+    g -= g.mean()
+    x_parent = _lib.host_newton_direction(H, g, threads=4)
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:  # child
+        code = 1
+        try:
+            x_child = _lib.host_newton_direction(H, g, threads=4)
+            code = 0 if np.array_equal(x_child, x_parent) else 2
+        finally:
+            os.write(w, bytes([code]))
+            os._exit(code)
+    os.close(w)
+    import select
+
+    ready, _, _ = select.select([r], [], [], 60.0)
+    if not ready:
+        os.kill(pid, 9)
+    os.waitpid(pid, 0)
+    assert ready, "the forked child hung in the host factorisation"
+    assert os.read(r, 1) == bytes([0])
+    assert np.array_equal(_lib.host_newton_direction(H, g, threads=4), x_parent)  # (and the parent's team is still there)
+
+
 def test_host_newton_direction_falls_back_to_the_pseudo_inverse():
     """Disconnected groups of states: the gauge-fixed block is singular, the Cholesky factorisations (both forms) report the
     breakdown and the minimum-norm solution of lstsq is returned instead."""
