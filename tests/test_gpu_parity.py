@@ -423,8 +423,9 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
         assert light_seen >= 2, light_seen  # both candidates pass)
 
 
-# (300 / 380 / 440 / 600 / 800 states: the 256-state panels of the P-mode plan + a remainder of 64 / 128 / 192 / 2 x 256 + 128 / 4 x 256 rows)
-@pytest.mark.parametrize("K,N", [(160, 6400), (256, 7680), (300, 6000), (380, 5700), (440, 6600), (600, 6000), (800, 8000)])
+# (300 / 380 / 440 / 600 / 800 states: the 256-state panels of the P-mode plan + a remainder of 64 / 128 / 192 / 2 x 256 + 128 / 4 x 256 rows;
+# 1100: beyond the row-split evaluation kernel -- Gram sweep on the probability matrix, evaluation by the layout-agnostic pair on u)
+@pytest.mark.parametrize("K,N", [(160, 6400), (256, 7680), (300, 6000), (380, 5700), (440, 6600), (600, 6000), (800, 8000), (1100, 5500)])
 def test_adaptive_solves_above_128_states_match_the_oracle(DM, K, N):
     """Adaptive solves beyond one Gram panel (129-256 states: paneled Gram sweeps; 257-512: row-split evaluation sweep; above:
     layout-agnostic sweeps) against the oracle's loop (mbar_solvers.py:575-640): free energies, iteration counts, the choice
