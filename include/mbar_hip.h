@@ -218,6 +218,10 @@ int mbar_ctx_set_sample_weights(mbar_ctx* ctx, const double* c_n);
  * no context.  Same-seed determinism (tests/test_mbar.py:533-545 of the reference) holds by construction. */
 int mbar_ctx_draw_bootstrap_weights(mbar_ctx* ctx, uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states,
                                     const int64_t* order, int64_t n_global0);
+/* The layout (cumN[K_states + 1], order[cumN[K_states]] or NULL) validated and uploaded ONCE; mbar_ctx_draw_bootstrap_weights with
+ * cumN = NULL (K_states, order ignored / NULL) then draws on it -- no host pass over N integers per replicate (with arrays in the
+ * call their content is digested on every call to see whether the device copy is still the right one). */
+int mbar_ctx_set_bootstrap_layout(mbar_ctx* ctx, const int64_t* cumN, int64_t K_states, const int64_t* order);
 int mbar_bootstrap_draws(uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states, const int64_t* order,
                          int64_t* rints_out);
 

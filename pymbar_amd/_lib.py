@@ -81,6 +81,7 @@ SIGNATURES = {
     "mbar_ctx_set_sample_weights": (C.c_int, [_ctx, _dp]),
     "mbar_ctx_weights_from_vec": (C.c_int, [_ctx, C.c_double]),
     "mbar_ctx_draw_bootstrap_weights": (C.c_int, [_ctx, C.c_uint64, C.c_int64, _ip, C.c_int64, _ip, C.c_int64]),
+    "mbar_ctx_set_bootstrap_layout": (C.c_int, [_ctx, _ip, C.c_int64, _ip]),
     "mbar_bootstrap_draws": (C.c_int, [C.c_uint64, C.c_int64, _ip, C.c_int64, _ip, _ip]),
     "mbar_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mbar_ctx_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),

@@ -1060,42 +1060,79 @@ int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
     return MBAR_OK;
 }
 
+// The layout of the bootstrap draws (runs of the states + optional position -> sample map) on the device: validated and uploaded
+// ONCE per layout.  The per-replicate call then passes cumN = NULL and touches no host array of N integers.
+static int upload_bootstrap_layout(mbar_ctx* c, const int64_t* cumN, int64_t K_states, const int64_t* order, const uint64_t dg[2]) {
+    const int64_t total = cumN[K_states];
+    const size_t words = (size_t)(K_states + 1) + (order ? (size_t)total : 0);
+    if (order)
+        for (int64_t p = 0; p < total; ++p)
+            if (order[p] < 0 || order[p] >= total) return fail(c, MBAR_ERR_ARG, "bootstrap layout: order entry out of range");
+    if (c->boot_idx && c->boot_idx_words < words) {
+        (void)cache_free(c->boot_idx);
+        c->boot_idx = nullptr;
+    }
+    if (!c->boot_idx) HIPCHK(c, cache_malloc((void**)&c->boot_idx, words * sizeof(int64_t)));
+    HIPCHK(c, hipMemcpyAsync(c->boot_idx, cumN, (size_t)(K_states + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    if (order)
+        HIPCHK(c, hipMemcpyAsync(c->boot_idx + K_states + 1, order, (size_t)total * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the host arrays may go away)
+    c->boot_idx_words = words;
+    c->boot_layout_digest[0] = dg[0];
+    c->boot_layout_digest[1] = dg[1];
+    c->boot_states = K_states;
+    c->boot_total = total;
+    c->boot_has_order = order != nullptr;
+    return MBAR_OK;
+}
+
+static int check_bootstrap_layout(mbar_ctx* c, const int64_t* cumN, int64_t K_states) {
+    if (K_states < 1) return fail(c, MBAR_ERR_ARG, "bootstrap layout: K_states must be >= 1");
+    if (cumN[0] != 0) return fail(c, MBAR_ERR_ARG, "bootstrap layout: cumN[0] must be 0");
+    for (int64_t k = 0; k < K_states; ++k)
+        if (cumN[k + 1] < cumN[k]) return fail(c, MBAR_ERR_ARG, "bootstrap layout: cumN must not decrease");
+    return MBAR_OK;
+}
+
+int mbar_ctx_set_bootstrap_layout(mbar_ctx* c, const int64_t* cumN, int64_t K_states, const int64_t* order) {
+    if (!c || !cumN) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    int rc = check_bootstrap_layout(c, cumN, K_states);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t none[2] = {0, 0};  // (no content digest: a later call that passes its arrays again uploads again)
+    return upload_bootstrap_layout(c, cumN, K_states, order, none);
+}
+
 int mbar_ctx_draw_bootstrap_weights(mbar_ctx* c, uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states,
                                     const int64_t* order, int64_t n_global0) {
-    if (!c || !cumN) return fail(c, MBAR_ERR_ARG, "NULL argument");
-    if (K_states < 1 || replicate < 0 || n_global0 < 0) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: bad argument");
-    const int64_t total = cumN[K_states];
-    if (cumN[0] != 0 || total < n_global0 + c->N) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: the runs do not cover this shard");
-    for (int64_t k = 0; k < K_states; ++k)
-        if (cumN[k + 1] < cumN[k]) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: cumN must not decrease");
+    if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
+    if (replicate < 0 || n_global0 < 0) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    // the layout (runs + order) goes to the device once per layout, not once per replicate
-    const size_t words = (size_t)(K_states + 1) + (order ? (size_t)total : 0);
-    uint64_t dg[2] = {0, 0};
-    {
-        uint64_t a[2], b[2] = {0, 0};
+    if (!cumN) {  // the layout of mbar_ctx_set_bootstrap_layout (or of an earlier call with arrays)
+        if (!c->boot_idx || c->boot_states < 1)
+            return fail(c, MBAR_ERR_STATE, "mbar_ctx_draw_bootstrap_weights: no layout on this context (mbar_ctx_set_bootstrap_layout first)");
+        if (order) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: order without cumN");
+    } else {
+        int rc = check_bootstrap_layout(c, cumN, K_states);
+        if (rc) return rc;
+        // arrays handed over with the call: uploaded only when their content differs from what is there (a digest of the order
+        // array is a host pass over N integers -- callers with many replicates use mbar_ctx_set_bootstrap_layout + cumN = NULL)
+        const int64_t total_in = cumN[K_states];
+        const size_t words = (size_t)(K_states + 1) + (order ? (size_t)total_in : 0);
+        uint64_t dg[2], a[2], b[2] = {0, 0};
         (void)mbar_host_digest(cumN, (int64_t)((K_states + 1) * sizeof(int64_t)), 1, a);
-        if (order) (void)mbar_host_digest(order, (int64_t)((size_t)total * sizeof(int64_t)), 0, b);
-        dg[0] = a[0] ^ (b[0] * 0x9E3779B97F4A7C15ull) ^ (uint64_t)words;
+        if (order) (void)mbar_host_digest(order, (int64_t)((size_t)total_in * sizeof(int64_t)), 0, b);
+        dg[0] = (a[0] ^ (b[0] * 0x9E3779B97F4A7C15ull) ^ (uint64_t)words) | 1u;  // (never the "no digest" value of set_bootstrap_layout)
         dg[1] = a[1] ^ (b[1] * 0xC2B2AE3D27D4EB4Full) ^ (order ? 1u : 0u);
-    }
-    if (!c->boot_idx || c->boot_idx_words != words || c->boot_layout_digest[0] != dg[0] || c->boot_layout_digest[1] != dg[1]) {
-        if (order)
-            for (int64_t p = 0; p < total; ++p)
-                if (order[p] < 0 || order[p] >= total) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: order entry out of range");
-        if (c->boot_idx && c->boot_idx_words < words) {
-            (void)cache_free(c->boot_idx);
-            c->boot_idx = nullptr;
+        if (!c->boot_idx || c->boot_idx_words != words || c->boot_layout_digest[0] != dg[0] || c->boot_layout_digest[1] != dg[1]) {
+            rc = upload_bootstrap_layout(c, cumN, K_states, order, dg);
+            if (rc) return rc;
         }
-        if (!c->boot_idx) HIPCHK(c, cache_malloc((void**)&c->boot_idx, words * sizeof(int64_t)));
-        HIPCHK(c, hipMemcpyAsync(c->boot_idx, cumN, (size_t)(K_states + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        if (order)
-            HIPCHK(c, hipMemcpyAsync(c->boot_idx + K_states + 1, order, (size_t)total * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // (the host arrays may go away)
-        c->boot_idx_words = words;
-        c->boot_layout_digest[0] = dg[0];
-        c->boot_layout_digest[1] = dg[1];
     }
+    K_states = c->boot_states;
+    const int64_t total = c->boot_total;
+    const bool has_order = c->boot_has_order;
+    if (total < n_global0 + c->N) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: the runs do not cover this shard");
     if (!c->lden_eff) {
         HIPCHK(c, cache_malloc((void**)&c->lden_eff, (size_t)c->ld * sizeof(double)));
         HIPCHK(c, hipMemsetAsync(c->lden_eff, 0, (size_t)c->ld * sizeof(double), c->stream));
@@ -1105,7 +1142,7 @@ int mbar_ctx_draw_bootstrap_weights(mbar_ctx* c, uint64_t seed, int64_t replicat
         HIPCHK(c, hipMemsetAsync(c->cwsq, 0, (size_t)c->ld * sizeof(double), c->stream));
     }
     HIPCHK(c, launch_fill(c->stream, c->cw, 0.0, c->N));
-    HIPCHK(c, launch_bootstrap_counts(c->stream, seed, replicate, c->boot_idx, K_states, total, order ? c->boot_idx + K_states + 1 : nullptr,
+    HIPCHK(c, launch_bootstrap_counts(c->stream, seed, replicate, c->boot_idx, K_states, total, has_order ? c->boot_idx + K_states + 1 : nullptr,
                                       n_global0, c->N, c->cw));
     HIPCHK(c, launch_sqrt_vec(c->stream, c->cwsq, c->cw, c->N));
     HIPCHK(c, hipStreamSynchronize(c->stream));

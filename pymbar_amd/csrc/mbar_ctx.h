@@ -288,6 +288,8 @@ struct mbar_ctx {
     int64_t* boot_idx = nullptr;    // bootstrap draws: cum[K + 1] | order[total] (mbar_ctx_draw_bootstrap_weights keeps the last layout)
     size_t boot_idx_words = 0;
     uint64_t boot_layout_digest[2] = {0, 0};
+    int64_t boot_states = 0, boot_total = 0;  // the layout on the device: number of runs, positions in total
+    bool boot_has_order = false;
     bool vec_holds_logshift = false;  // vec_tmp holds log(A - shift) of mbar_ctx_vec_logshift (and not some other call's vector)
     // captured SCI batch (launch-bound loop: 3 small kernels per iteration replayed from a hipGraph)
     hipGraphExec_t sci_graph = nullptr;

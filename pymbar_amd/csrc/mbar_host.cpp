@@ -157,6 +157,13 @@ void solve8_avx512(double* row0, size_t S, int nr, int j0, int jb, const double*
 // the factorisation of 511 unknowns itself).  run(T, fn): fn(0) on the caller's thread, fn(1 .. T-1) on workers; one job at a time.
 class HostTeam {
 public:
+    HostTeam() {
+        // fork(): the child has none of the parent's threads and inherits the mutexes in whatever state they were in.  The
+        // handlers take both locks around the fork (no job is running, nobody is half-way through the bookkeeping), release them
+        // on both sides, and the child starts over with no workers, no placement memory and fresh condition variables (the
+        // parent's may have waiters recorded that do not exist in the child).
+        pthread_atfork(&HostTeam::atfork_prepare, &HostTeam::atfork_parent, &HostTeam::atfork_child);
+    }
     void run(int T, const std::function<void(int)>& fn) {
         if (T <= 1) {
             fn(0);
@@ -165,10 +172,7 @@ public:
         std::lock_guard<std::mutex> one_job(run_mu_);
         {
             std::unique_lock<std::mutex> lk(mu_);
-            if (pid_ != getpid()) {  // (a forked child has none of the parent's threads: start over, leaking the parent's handles)
-                workers_ = new std::vector<std::thread>();
-                pid_ = getpid();
-            }
+            if (pid_ != getpid()) reset_after_fork();  // (a child forked before the handlers were registered, or the first use)
             while ((int)workers_->size() < T - 1) {
                 const int id = (int)workers_->size() + 1;
                 workers_->emplace_back([this, id] { worker(id); });
@@ -180,10 +184,16 @@ public:
             ++generation_;
         }
         cv_go_.notify_all();
+        // (the workers hold a pointer to `fn` until the last of them is done: wait for them on EVERY way out of fn(0))
+        struct WaitForWorkers {
+            HostTeam* t;
+            ~WaitForWorkers() {
+                std::unique_lock<std::mutex> lk(t->mu_);
+                t->cv_done_.wait(lk, [&] { return t->remaining_ == 0; });
+                t->job_ = nullptr;
+            }
+        } wait_for_workers{this};
         fn(0);
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_done_.wait(lk, [&] { return remaining_ == 0; });
-        job_ = nullptr;
     }
     // team size for a caller that would like T threads: no more than the caller's core + the free cores of its L3 domain
     int suggest(int T) {
@@ -295,6 +305,22 @@ private:
             if (--remaining_ == 0) cv_done_.notify_one();
         }
     }
+    // (call with mu_ held, or from the fork handler of the child) no workers, no placement memory, counters at rest
+    void reset_after_fork() {
+        workers_ = new std::vector<std::thread>();  // (the parent's handles are leaked: their threads do not exist here)
+        pid_ = getpid();
+        pin_key_ = -2;
+        near_key_ = -1;
+        pinned_workers_ = 0;
+        near_.clear();
+        near_domain_.clear();
+        generation_ = active_ = remaining_ = 0;
+        stop_ = false;
+        job_ = nullptr;
+    }
+    static void atfork_prepare();
+    static void atfork_parent();
+    static void atfork_child();
     std::mutex run_mu_, mu_;
     std::condition_variable cv_go_, cv_done_;
     std::vector<std::thread>* workers_ = nullptr;
@@ -304,6 +330,21 @@ private:
     pid_t pid_ = 0;
 };
 HostTeam g_team;
+void HostTeam::atfork_prepare() {
+    g_team.run_mu_.lock();
+    g_team.mu_.lock();
+}
+void HostTeam::atfork_parent() {
+    g_team.mu_.unlock();
+    g_team.run_mu_.unlock();
+}
+void HostTeam::atfork_child() {
+    if (g_team.workers_) g_team.reset_after_fork();
+    new (&g_team.cv_go_) std::condition_variable();
+    new (&g_team.cv_done_) std::condition_variable();
+    g_team.mu_.unlock();
+    g_team.run_mu_.unlock();
+}
 
 constexpr int CHOL_BLOCKED_MIN = 64;    // unknowns from which the blocked form is used (round 5: it wins from here on, 4.5x at 255) ...
 constexpr int CHOL_THREADED_MIN = 448;  // ... and from which it is worth a team (below: one thread, same code)

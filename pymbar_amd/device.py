@@ -201,16 +201,28 @@ class DeviceMatrix:
             raise ValueError(f"sample weights must have shape ({self.N_local},)")
         self._check(self._lib.mbar_ctx_set_sample_weights(self._ctx, _dptr(c_n)))
 
-    def draw_bootstrap_weights(self, seed, replicate, cumN, order=None, n_global0=0):
+    def draw_bootstrap_weights(self, seed, replicate, cumN, order=None, n_global0=0, layout_key=None):
         """Per-sample multiplicities = draw counts of bootstrap replicate ``replicate`` of the counter-based stream ``seed``, drawn
         ON THE DEVICE (``mbar_ctx_draw_bootstrap_weights``; :func:`pymbar_amd._lib.bootstrap_draws` gives the same draws on the
-        host).  ``cumN`` (K + 1): positions of the states' runs; ``order``: sample index of a position (``None``: the default layout)."""
-        cumN = np.ascontiguousarray(cumN, dtype=np.int64)
+        host).  ``cumN`` (K + 1): positions of the states' runs; ``order``: sample index of a position (``None``: the default layout).
+        ``layout_key``: any object that identifies (cumN, order) for the caller -- the layout is uploaded when the key changes
+        (``mbar_ctx_set_bootstrap_layout``) and replicates with the same key touch no host array of N integers; without a key the
+        arrays travel with every call and the library digests them to see whether its device copy still matches."""
         ip = C.POINTER(C.c_int64)
+        if layout_key is not None and layout_key is getattr(self, "_boot_layout_key", None):
+            self._check(self._lib.mbar_ctx_draw_bootstrap_weights(self._ctx, C.c_uint64(int(seed)), int(replicate), None, 0, None, int(n_global0)))
+            return
+        cumN = np.ascontiguousarray(cumN, dtype=np.int64)
         optr = None
         if order is not None:
             order = np.ascontiguousarray(order, dtype=np.int64)
             optr = order.ctypes.data_as(ip)
+        if layout_key is not None:
+            self._check(self._lib.mbar_ctx_set_bootstrap_layout(self._ctx, cumN.ctypes.data_as(ip), len(cumN) - 1, optr))
+            self._boot_layout_key = layout_key
+            self._check(self._lib.mbar_ctx_draw_bootstrap_weights(self._ctx, C.c_uint64(int(seed)), int(replicate), None, 0, None, int(n_global0)))
+            return
+        self._boot_layout_key = None
         self._check(self._lib.mbar_ctx_draw_bootstrap_weights(self._ctx, C.c_uint64(int(seed)), int(replicate), cumN.ctypes.data_as(ip),
                                                               len(cumN) - 1, optr, int(n_global0)))
 

@@ -112,6 +112,8 @@ class MBAR:
                  bootstrap_solver_protocol=None, rseed=None, device=None, copy=True, bootstrap_rng="reference"):
         from .device import DeviceMatrix
 
+        if bootstrap_rng not in ("reference", "device"):  # (before the upload and the main solve: a typo must not cost either)
+            raise ParameterError("bootstrap_rng must be 'reference' or 'device'")
         self.N_k = np.array(N_k, dtype=np.int64)
         self.N = int(np.sum(self.N_k))
         if len(np.shape(u_kn)) == 3:
@@ -238,9 +240,10 @@ class MBAR:
         self.f_k = mbar_solvers.solve_mbar_for_all_states(self._dm, self.N_k, self.f_k, self.states_with_samples,
                                                           solver_protocol)
 
-        if bootstrap_rng not in ("reference", "device"):
-            raise ParameterError("bootstrap_rng must be 'reference' or 'device'")
         self.n_bootstraps = 0
+        # which random stream the replicates were actually drawn from: "device" only when the device stream could be used
+        # (group sizes equal to N_k and a backend that has it); a request that could not be honoured is logged, not silent
+        self.bootstrap_rng_used = None if n_bootstraps <= 0 else "reference"
         self._bootstrap_stream = None   # (seed, cumN, order) of the device stream, or None: numpy's, rows stored
         self._bootstrap_rints = None
         if n_bootstraps > 0 and bootstrap_rng == "device" and hasattr(self._dm, "draw_bootstrap_weights"):
@@ -253,6 +256,7 @@ class MBAR:
                 order = None if default_layout else np.concatenate([np.asarray(g, dtype=np.int64) for g in groups])
                 seed = int(self.rng.integers(np.iinfo(np.int64).max))   # (deterministic under rseed)
                 self._bootstrap_stream = (seed, cumN, order)
+                self.bootstrap_rng_used = "device"
                 for b in range(n_bootstraps):
                     self._set_bootstrap_weights(self._dm, b)
                     f_k_init = self.f_k.copy()
@@ -264,6 +268,9 @@ class MBAR:
                     finally:
                         self._dm.set_sample_weights(None)
                 n_bootstraps = 0  # (done)
+        if n_bootstraps > 0 and bootstrap_rng == "device":
+            logger.warning("bootstrap_rng='device' is not available here (x_kindices group sizes differ from N_k, or the backend has no "
+                           "device stream): the replicates are drawn from numpy's stream (bootstrap_rng_used = 'reference')")
         if n_bootstraps > 0:
             self.n_bootstraps = n_bootstraps
             self.f_k_boots = np.zeros([n_bootstraps, K])
@@ -329,7 +336,8 @@ class MBAR:
         samples): drawn on the device from the counter-based stream, or the draw counts of the stored row."""
         if self._bootstrap_stream is not None and self._bootstrap_rints is None and hasattr(dm, "draw_bootstrap_weights"):
             seed, cumN, order = self._bootstrap_stream
-            dm.draw_bootstrap_weights(seed, b, cumN, order)
+            # (the layout is constant for this object's lifetime: it goes to a matrix's context once, keyed by the stream tuple)
+            dm.draw_bootstrap_weights(seed, b, cumN, order, layout_key=self._bootstrap_stream)
         else:
             dm.set_sample_weights(np.bincount(self._bootstrap_row(b), minlength=self.N))
 

@@ -345,11 +345,19 @@ def adaptive(u_kn, N_k, f_k, tol=1.0e-8, options=None):
         x, res = h.solve_adaptive(f_k, tol=tol, maxiter=maxiter, min_sc_iter=int(options["min_sc_iter"]),
                                   gamma=float(options["gamma"]), history_rows=maxiter if verbose else 0)
     if verbose:
+        # the reference's per-iteration lines (mbar_solvers.py:598-624), replayed from the rows the device loop recorded:
+        # {choice, |g_sci|, |g_nr|, max_delta} per iteration; its two wordings of a self-consistent choice depend on the running
+        # count AFTER the increment (:609-620)
+        min_sc_iter, sci_seen = int(options["min_sc_iter"]), 0
         for it, row in enumerate(res["history"]):
             logger.info("self consistent iteration gradient norm is %10.5g, Newton-Raphson gradient norm is %10.5g"
                         % (row[1], row[2]))
             if row[0] == 0:
-                logger.info(f"Choosing self-consistent iteration on iteration {it:d}")
+                sci_seen += 1
+                if sci_seen < min_sc_iter:
+                    logger.info(f"Choosing self-consistent iteration on iteration {it:d} because min_sci_iter={min_sc_iter:d}")
+                else:
+                    logger.info(f"Choosing self-consistent iteration for lower gradient on iteration {it:d}")
             else:
                 logger.info(f"Newton-Raphson used on iteration {it:}")
     if res["success"]:
@@ -366,8 +374,9 @@ def adaptive(u_kn, N_k, f_k, tol=1.0e-8, options=None):
         if maxiter <= 0:
             logger.warning(f"No iterations ran be cause maximum_iterations was <= 0 ({maxiter})!")
         else:
+            # (the reference prints the index of the last iteration, mbar_solvers.py:655-657: one less than the count)
             logger.warning(f"max_delta = {res['max_delta']:e}, tol = {tol:e}, maximum_iterations = {maxiter:d}, "
-                           f"iterations completed = {res['iterations']:d}")
+                           f"iterations completed = {max(0, res['iterations'] - 1):d}")
     results = dict(success=res["success"], message=message, x=x, nr_iter=res["nr_iter"], sci_iter=res["sci_iter"],
                    iterations=res["iterations"], wall_ms=res["wall_ms"])
     if res.get("psum") is not None and np.all(np.isfinite(res["psum"])):

@@ -103,7 +103,7 @@ class OracleMatrix:
             assert np.all(c == np.round(c)) and c.shape == (self.u_full.shape[1],)
             self.u = np.repeat(self.u_full, c.astype(int), axis=1)
 
-    def draw_bootstrap_weights(self, seed, replicate, cumN, order=None, n_global0=0):
+    def draw_bootstrap_weights(self, seed, replicate, cumN, order=None, n_global0=0, layout_key=None):
         """Model of mbar_ctx_draw_bootstrap_weights: the draw counts of the counter-based stream (the host function of the C
         library yields the draws; it needs no GPU)."""
         from pymbar_amd import _lib

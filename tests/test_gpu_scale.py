@@ -171,3 +171,61 @@ def test_config3_itself_matches_the_reference(golden):
         assert res0["light_sweeps"] == 0
         dm.set_option("pmode", 1)
     _logical_ranks(u_kn, N_k, 8, g)
+
+
+def test_config4_shape_on_one_device():
+    """BASELINE.json config 4 (K=128, N=1e8: 102.4 GB of u + 102.4 GB of resident probabilities) on ONE 288 GB device, in the
+    shape the metric runs it in: EIGHT logical ranks of 1.25e7 columns each (the real 12.8 GB-per-GPU shard; ``mbar_loopback`` =
+    ONE all-reduce per iteration on the compute streams, the code RCCL drives), generated in HBM by the shard-invariant
+    generator.  The reference cannot hold this matrix, but the per-iteration sums of pymbar/mbar_solvers.py:581-594 are
+    shard-additive, so the checks are: ranks bit-identical; the SAME matrix solved in one context (64-bit lane offsets: a
+    different kernel family) gives the same iteration count, the same choices and ``Delta_f`` to 1e-12; the solution is the
+    analytic one to sampling error; and the per-state sums / Gram matrix of one 1e5-column block agree with the CPU oracle."""
+    from oracle import mbar_oracle as oracle
+    from pymbar_amd.device import DeviceMatrix, LoopbackGroup, device_info
+
+    K, N, nranks = 128, 100_000_000, 8
+    if device_info()["total_mem_bytes"] < 230 * (1 << 30):
+        pytest.skip("config 4 on one device needs 205 GB + work space")
+    O_k, K_k, N_k = ts.config3_params(K=K, N=N)
+    assert int(N_k.sum()) == N
+    bounds = [shard_bounds(N, r, nranks) for r in range(nranks)]
+    assert all(b - a == 12_500_000 for a, b in bounds)
+    with LoopbackGroup(nranks) as grp:
+        def worker(r):
+            n0, n1 = bounds[r]
+            with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0, n_global0=n0, N_local=n1 - n0) as dm:
+                dm.set_loopback(grp, r)
+                dm.set_Nk(N_k)
+                out = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+                dm.comm_destroy()
+                return out
+
+        ranks = run_ranks(nranks, worker, timeout=900.0)
+    f8, r8 = ranks[0]
+    for f, res in ranks[1:]:
+        assert np.array_equal(f, f8) and res["iterations"] == r8["iterations"] and np.array_equal(res["history"], r8["history"])
+    assert r8["success"] and r8["iterations"] <= 8
+    assert r8["builds"] == 1 and r8["gram_sweeps"] == 0  # (default path on every rank: P mode, fused sweep)
+    assert np.max(np.abs(f8 - ts.harmonic_free_energies(K_k))) < 5e-3
+    with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0) as dm:
+        dm.set_Nk(N_k)
+        f1, r1 = dm.solve_adaptive(np.zeros(K), tol=1e-12, min_sc_iter=0, history_rows=64)
+        assert r1["success"] and r1["iterations"] == r8["iterations"]
+        n = r1["iterations"] - 1  # (the last choice compares two round-off-level norms)
+        assert np.array_equal(r1["history"][:n, 0], r8["history"][:n, 0])
+        np.testing.assert_allclose(_delta(f1), _delta(f8), rtol=0, atol=1e-12)
+        psum, sld, gram = dm.eval(f1, gram=True)
+        assert abs(psum[0].sum() - N) < 1e-6 * N ** 0.5
+        assert np.max(np.abs(psum[0] - N_k)) < 1e-5           # gradient vanishes (|g| relative to N_k = 781250: 1e-11)
+        assert np.array_equal(gram, gram.T)
+    # one block of 1e5 columns from the middle of rank 3's shard, same bits through the shard-invariant generator
+    n_blk0 = bounds[3][0] + 4_000_000
+    with DeviceMatrix.harmonic(O_k, K_k, N_k, seed=0, n_global0=n_blk0, N_local=100_000) as sub:
+        u_sub = sub.to_host()
+        sub.set_Nk(N_k)
+        ps, sl, gs = sub.eval(f8, gram=True)
+    part = oracle.shard_partials(u_sub, N_k, f8, want_gram=True)
+    np.testing.assert_allclose(ps[0], part["psum"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(gs, part["gram"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(sl[0], part["sumlogden"], rtol=1e-13)

@@ -469,6 +469,56 @@ def test_host_team_survives_a_fork():
     assert np.array_equal(_lib.host_newton_direction(H, g, threads=4), x_parent)  # (and the parent's team is still there)
 
 
+def test_host_team_survives_a_fork_while_another_thread_uses_it():
+    """fork() while another thread of the parent is INSIDE the team (its job mutex held, workers running): the fork handlers take
+    the team's locks around the fork, so the child never inherits a mutex locked by a thread it does not have; the child factors
+    several times (workers re-created and placed anew), the parent's thread keeps getting the same bits throughout."""
+    import os
+    import select
+    import threading
+
+    from pymbar_amd import _lib
+
+    rng = np.random.default_rng(5)
+    H = _mbar_like_hessian(700, rng)
+    g = rng.normal(size=700) * 1e-2
+    g -= g.mean()
+    x_ref = _lib.host_newton_direction(H, g, threads=4)
+    stop, bad = threading.Event(), []
+
+    def busy():
+        while not stop.is_set():
+            if not np.array_equal(_lib.host_newton_direction(H, g, threads=4), x_ref):
+                bad.append(1)
+
+    t = threading.Thread(target=busy, daemon=True)
+    t.start()
+    try:
+        for _ in range(6):
+            r, w = os.pipe()
+            pid = os.fork()
+            if pid == 0:  # child
+                code = 1
+                try:
+                    ok = all(np.array_equal(_lib.host_newton_direction(H, g, threads=4), x_ref) for _ in range(3))
+                    code = 0 if ok else 2
+                finally:
+                    os.write(w, bytes([code]))
+                    os._exit(code)
+            os.close(w)
+            ready, _, _ = select.select([r], [], [], 60.0)
+            if not ready:
+                os.kill(pid, 9)
+            os.waitpid(pid, 0)
+            assert ready, "the forked child hung in the host factorisation"
+            assert os.read(r, 1) == bytes([0])
+            os.close(r)
+    finally:
+        stop.set()
+        t.join(60.0)
+    assert not t.is_alive() and not bad
+
+
 def test_host_newton_direction_falls_back_to_the_pseudo_inverse():
     """Disconnected groups of states: the gauge-fixed block is singular, the Cholesky factorisations (both forms) report the
     breakdown and the minimum-norm solution of lstsq is returned instead."""
