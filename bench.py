@@ -582,6 +582,12 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
+    # The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a version banner from C stdio when a
+    # communicator is created, flushed at exit -- i.e. AFTER the line): file descriptor 1 is pointed at stderr for everything but
+    # the line itself, which goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -898,7 +904,8 @@ def main():
                     out["wallclock_to_converge_speedup_vs_reference_on_gpu_host"] = rg["wallclock_to_converge_s"] / t_conv
             if "reference_on_build_container" in cpu:
                 out["speedup_vs_reference_on_build_container"] = it_per_s / cpu["reference_on_build_container"]["value"]
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dm is not None:
         dm.close()
     if group is not None:

@@ -224,6 +224,7 @@ class MBAR:
             raise
         # the matrix goes to HBM once and stays there for the lifetime of the object
         self._device = device
+        self._bootstrap_protocol = bootstrap_solver_protocol
         import time as _time
 
         _t0 = _time.perf_counter()

@@ -229,3 +229,89 @@ def test_config4_shape_on_one_device():
     np.testing.assert_allclose(ps[0], part["psum"], rtol=1e-11, atol=1e-9)
     np.testing.assert_allclose(gs, part["gram"], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(sl[0], part["sumlogden"], rtol=1e-13)
+
+
+def test_600_states_150000_samples_against_the_oracle_loop():
+    """Above 256 states at a size where round-off could tell the sweeps on the resident probability matrix from the sweeps on u
+    (round 5 rebuilt this whole path: `k_gram_rect`, `host_pmode`, the host Cholesky team): the host-driven adaptive solve with
+    host_pmode 2 (both sweeps on P, Gram in 256-state panels + 128 x 256 rectangles), 1 (128-state panels) and 0 (both sweeps on
+    u) against the CPU oracle's loop (oracle.adaptive = mbar_solvers.py:575-640 restated; ~30 s) on the same 600 x 150 000
+    matrix: iteration count, per-iteration choices, gradient norms of every iteration, free energies."""
+    from oracle import mbar_oracle as oracle
+    from pymbar_amd.device import DeviceMatrix
+
+    K, N = 600, 150_000
+    O_k, K_k, N_k = ts.config3_params(K=K, N=N)
+    N_k[-1] += N - N_k.sum()
+    _, u_kn, N_k, _ = ts.harmonic_u_kn(O_k, K_k, N_k, seed=K)
+    hist = []
+    r_or = oracle.adaptive(np.ascontiguousarray(u_kn), N_k.astype(float), np.zeros(K), tol=1e-10, min_sc_iter=0, history=hist)
+    assert r_or["success"]
+    gn = np.array([[h["gnorm_sci"], h["gnorm_nr"]] for h in hist])
+    with DeviceMatrix.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        for mode in (2, 1, 0):
+            dm.set_option("host_pmode", mode)
+            fa, ra = dm.solve_adaptive(np.zeros(K), tol=1e-10, maxiter=100, min_sc_iter=0, history_rows=100)
+            assert ra["success"] and ra["iterations"] == r_or["iterations"], (mode, ra["iterations"], r_or["iterations"])
+            np.testing.assert_allclose(fa, r_or["x"], rtol=0, atol=1e-12 * np.max(np.abs(r_or["x"])), err_msg=f"host_pmode {mode}")
+            _assert_delta_f(fa, r_or["x"], f"host_pmode {mode}")
+            n = ra["iterations"]
+            # gradient norms of every iteration: relative, with the round-off floor of the sums (N_k ~ 250: ~1e-12 absolute)
+            np.testing.assert_allclose(ra["history"][:n, 1:3], gn[:n], rtol=1e-2, atol=1e-10, err_msg=f"host_pmode {mode}")
+            choices = np.array([1 if h["choice"] == "nr" else 0 for h in hist[:n - 1]])  # (the last one compares round-off)
+            assert np.array_equal(ra["history"][:n - 1, 0].astype(int), choices), mode
+
+
+def test_device_drawn_bootstrap_replicates_at_128_states_1e6_samples():
+    """``bootstrap_rng="device"`` at the headline state count: every replicate's multiplicities drawn ON THE DEVICE equal the draw
+    counts of the host face of the same counter-based stream (``mbar_bootstrap_draws``) -- the per-state sums of a sweep are then
+    bit-identical -- for the default layout and for a permuted ``x_kindices``-like order (layout uploaded once, keyed), and the
+    class solves exactly those replicates: ``f_k_boots`` of the device stream = the solve with the host-drawn counts as sample
+    weights (1e-10); bit-identical between two objects under the same ``rseed``."""
+    import pymbar_amd
+    from pymbar_amd import _lib
+    from pymbar_amd.device import DeviceMatrix
+
+    K, N = 128, 1_000_000
+    O_k, K_k, N_k = ts.config3_params(K, N)
+    x_n, u_kn, N_k, s_n = ts.harmonic_u_kn(O_k, K_k, N_k, seed=0)
+    N = u_kn.shape[1]
+    cum = np.concatenate(([0], np.cumsum(N_k))).astype(np.int64)
+    f = ts.harmonic_free_energies(K_k)
+    perm = np.random.default_rng(2).permutation(N)
+    with DeviceMatrix.from_host(u_kn) as dm:
+        dm.set_Nk(N_k)
+        for order, key in ((None, object()), (perm, object())):
+            for rep in (0, 5):
+                dm.draw_bootstrap_weights(777, rep, cum, order, layout_key=key)   # (second replicate: no array crosses the boundary)
+                ps, _, _ = dm.eval(f)
+                rints = _lib.bootstrap_draws(777, rep, cum, order)
+                counts = np.bincount(rints, minlength=N)
+                # every state keeps its sample count (resampling WITHIN states, mbar.py:425-433)
+                owner = np.searchsorted(cum, np.arange(N) if order is None else np.argsort(perm), side="right") - 1
+                assert np.array_equal(np.bincount(owner, weights=counts, minlength=K).astype(np.int64), N_k)
+                dm.set_sample_weights(counts)
+                ps_ref, _, _ = dm.eval(f)
+                assert np.array_equal(ps[0], ps_ref[0]), (rep, order is None)
+        dm.set_sample_weights(None)
+    a = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=3, rseed=5, bootstrap_rng="device", copy=False)
+    b = pymbar_amd.MBAR(u_kn, N_k, n_bootstraps=3, rseed=5, bootstrap_rng="device", copy=False)
+    try:
+        assert a.bootstrap_rng_used == "device" and a._bootstrap_rints is None
+        assert np.array_equal(a.f_k_boots, b.f_k_boots)
+        seed, cumN, order = a._bootstrap_stream
+        with DeviceMatrix.from_host(u_kn) as dm:
+            for i in range(3):
+                dm.set_sample_weights(np.bincount(_lib.bootstrap_draws(seed, i, cumN, order), minlength=N))
+                fr = ms.solve_mbar_for_all_states(dm, N_k, a.f_k.copy(), a.states_with_samples, a._bootstrap_protocol)
+                # (the object's matrix starts each replicate from the resident probability matrix of its main solve, this one
+                # builds its own: the same replicate solved from two anchors -- equal to the solver's tolerance, not bit for bit)
+                np.testing.assert_allclose(fr, a.f_k_boots[i], rtol=0, atol=1e-10, err_msg=f"replicate {i}")
+        # the spread of the replicates is the bootstrap error estimate: the right order of magnitude against the analytic covariance
+        r = a.compute_free_energy_differences(uncertainty_method="svd-ew")
+        sd = a.f_k_boots.std(0, ddof=1)
+        assert np.all(sd[1:] > 0) and np.median(sd[1:] / r["dDelta_f"][0, 1:]) < 5.0
+    finally:
+        a.close()
+        b.close()
