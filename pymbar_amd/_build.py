@@ -22,6 +22,8 @@ KERNEL_DEPS = ["mbar_device.h", "exp2_table.inc", "log_table.inc"]
 DEPS = SOURCES + COMMON_DEPS + KERNEL_DEPS + HOST_DEPS
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# (A/B builds of kernel variants kept behind macros: MBAR_EXTRA_HIPCC_FLAGS="-DMBAR_..." python -m pymbar_amd._build --force)
+FLAGS += os.environ.get("MBAR_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

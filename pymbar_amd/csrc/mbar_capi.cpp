@@ -390,6 +390,22 @@ void gram_operand_sums(const double* G, int64_t K, const double* w, double* out)
     }
 }
 
+void gram_row_sums(const double* blocks, int nb, int64_t K, double* psum) {
+    std::vector<double> acc((size_t)nb * 16, 0.0);
+    int b = 0;
+    for (int I = 0; I < nb; ++I)
+        for (int J = I; J < nb; ++J, ++b) {
+            const double* blk = blocks + (size_t)b * 256;
+            for (int r = 0; r < 16; ++r)
+                for (int q = (I == J ? r : 0); q < 16; ++q) {
+                    const double v = blk[r * 16 + q];
+                    acc[(size_t)16 * I + r] += v;
+                    if (I != J || q != r) acc[(size_t)16 * J + q] += v;
+                }
+        }
+    for (int64_t k = 0; k < K; ++k) psum[k] = acc[(size_t)k];
+}
+
 // Scatter reduced blocks (host copy) into a dense symmetric K x K matrix.
 void unpack_gram(const GramPlan& plan, const double* blocks, int64_t K, double* G) {
     for (const auto& it : plan.items) {
@@ -787,6 +803,7 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "pcache") c->opt_pcache = value;
     else if (k == "merge_select") c->opt_merge_select = value;
     else if (k == "light_last") c->opt_light_last = value;
+    else if (k == "debug_download_p") c->opt_debug_download_p = value;
     else if (k == "direct_results") c->opt_direct_results = value;
     else if (k == "sci_merged") c->opt_sci_merged = value;
     else if (k == "host_pmode") c->opt_host_pmode = value;
@@ -970,7 +987,12 @@ int mbar_ctx_fill_masked_rows(mbar_ctx* c, int64_t row0, int64_t nrows, const do
 int mbar_ctx_download_u(mbar_ctx* c, double* out, int64_t ld_out) {
     if (!c || !out || ld_out < c->N) return fail(c, MBAR_ERR_ARG, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(double), c->u, (size_t)c->ld * sizeof(double),
+    const double* src = c->u;
+    if (c->opt_debug_download_p) {  // (tests: the resident probability matrix of the last adaptive solve instead of u)
+        if (!c->P || !c->P_valid) return fail(c, MBAR_ERR_STATE, "no resident probability matrix on this context");
+        src = c->P;
+    }
+    HIPCHK(c, hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(double), src, (size_t)c->ld * sizeof(double),
                                (size_t)c->N * sizeof(double), (size_t)c->K, hipMemcpyDeviceToHost, c->stream));
     return sync_stream(c);
 }

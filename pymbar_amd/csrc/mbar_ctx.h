@@ -320,7 +320,7 @@ struct mbar_ctx {
     std::vector<double> P_a0;       // anchor of the resident probability matrix: aden at the build point (Kp entries)
     // options
     int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
-    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1, opt_direct_results = 1;
+    int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1, opt_direct_results = 1, opt_debug_download_p = 0;
     int64_t opt_small_balanced = 1, opt_sci_pingpong = 1, opt_host_pmode = 2, opt_rect_waves = 8;
 
     // comm
@@ -420,6 +420,9 @@ int quad_live_blocks(const mbar_ctx* c);
 int run_gram(mbar_ctx* c, const double* anum_dev, const double* logden, size_t red_off, const GramPlan& plan, const double* pmat = nullptr);
 void gram_operand_sums(const double* G, int64_t K, const double* w, double* out);
 void unpack_gram(const GramPlan& plan, const double* blocks, int64_t K, double* G);
+// psum[k] = sum_j G[k][j] from the reduced upper-triangular blocks of ONE diagonal panel of nb x 16 states (host copy; block (I, J >= I)
+// at ((I nb - I (I - 1) / 2) + (J - I)) * 256, element (r, q) at r * 16 + q): with the rows of p summing to one that is sum_n c_n p_kn.
+void gram_row_sums(const double* blocks, int nb, int64_t K, double* psum);
 void unpack_gram_to_hessian(const GramPlan& plan, const double* blocks, int64_t K, const double* factor, const int* pos, int m, double* H,
                             int threads);
 int ensure_red(mbar_ctx* c, size_t want);

@@ -212,6 +212,70 @@ __device__ __forceinline__ void exp2s_batch2(double (&x0)[N], double (&x1)[N]) {
         x1[i] = ldexp(T1[i] * x1[i], q1[i]);
     }
 }
+// 2^(-w/S) for w >= 0 (round 6; the build sweep's exponential, where the argument is "column maximum minus entry" and can
+// be formed non-negative EXACTLY): floor and fraction come straight from the argument -- n = -trunc(w) (one conversion with a
+// negated source), z = fract(w) in [0, 1) (one instruction) -- instead of rint / subtract / convert, and no clamp is needed below:
+//   2^(-w/S) = 2^(n/S) 2^(-z/S) = ldexp(T[n & (S-1)] * Q(z), n >> EXP2_BITS),  Q = degree-3 polynomial of 2^(-z/S) on [0, 1]
+// (error 8.8e-18, tools/gen_exp2_poly.py).  Eight fp64 + three integer instructions (exp2s_batch: nine + three, + the clamp).  Huge
+// finite w is safe (v_cvt_i32_f64 saturates, ldexp(.., -2^20) = 0); CLAMP = true also takes w = +inf (matrices with +inf entries).
+constexpr double EXP2N_POLY[4] = {1.0, -0x1.62e42fefa3028p-12, 0x1.ebfbdf9648000p-25, -0x1.c69cea0000000p-38};
+template <int N, bool CLAMP>
+__device__ __forceinline__ void exp2s_neg_batch(double (&w)[N]) {
+    double T[N];
+    int q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double t = CLAMP ? fmin(w[i], 2.0e9) : w[i];
+        const int ni = (int)(-t);
+        w[i] = __builtin_amdgcn_fract(t);
+        q[i] = ni >> EXP2_BITS;
+        T[i] = exp2_table_at(ni);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double p = EXP2N_POLY[3];
+        p = fma(p, w[i], EXP2N_POLY[2]);
+        p = fma(p, w[i], EXP2N_POLY[1]);
+        w[i] = fma(p, w[i], EXP2N_POLY[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = ldexp(T[i] * w[i], q[i]);
+}
+template <int N, bool CLAMP>
+__device__ __forceinline__ void exp2s_neg_batch2(double (&w0)[N], double (&w1)[N]) {  // two argument sets, one pipeline
+    double T0[N], T1[N];
+    int q0[N], q1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double t0 = CLAMP ? fmin(w0[i], 2.0e9) : w0[i], t1 = CLAMP ? fmin(w1[i], 2.0e9) : w1[i];
+        const int n0 = (int)(-t0), n1 = (int)(-t1);
+        w0[i] = __builtin_amdgcn_fract(t0);
+        w1[i] = __builtin_amdgcn_fract(t1);
+        q0[i] = n0 >> EXP2_BITS;
+        q1[i] = n1 >> EXP2_BITS;
+        T0[i] = exp2_table_at(n0);
+        T1[i] = exp2_table_at(n1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double p0 = EXP2N_POLY[3], p1 = EXP2N_POLY[3];
+        p0 = fma(p0, w0[i], EXP2N_POLY[2]);
+        p1 = fma(p1, w1[i], EXP2N_POLY[2]);
+        p0 = fma(p0, w0[i], EXP2N_POLY[1]);
+        p1 = fma(p1, w1[i], EXP2N_POLY[1]);
+        w0[i] = fma(p0, w0[i], EXP2N_POLY[0]);
+        w1[i] = fma(p1, w1[i], EXP2N_POLY[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        w0[i] = ldexp(T0[i] * w0[i], q0[i]);
+        w1[i] = ldexp(T1[i] * w1[i], q1[i]);
+    }
+}
 // 1 / s for s > 0: hardware estimate + two Newton steps (the divide expansion costs twice as many instructions)
 __device__ __forceinline__ double recip_fast(double s) {
     double r = __builtin_amdgcn_rcp(s);

@@ -278,11 +278,13 @@ hipError_t launch_fused(hipStream_t s, int nb, const LaunchGeom& g, const double
 LaunchGeom build_sweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
 hipError_t launch_build_sweep(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                               const double* aden, const double* cw, double* P, double* rinv_slot, double* psum_part);
-// ... and the Gram matrix at the anchor point as well (gram partial records in the fused sweep's layout and count)
+// ... and the Gram matrix at the anchor point as well (gram partial records in the fused sweep's per-wave layout and count).  It
+// leaves NO per-state sums: they are the row sums of that Gram matrix (host::gram_row_sums on the reduced blocks).  general: the samples
+// carry multiplicities (wsq = their square roots; otherwise any vector of ld doubles) or the matrix holds +inf entries.
 LaunchGeom build_gram_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);
 hipError_t launch_build_gram(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
-                             const double* aden, const double* cw, const double* wsq, double* P, double* rinv_slot,
-                             double* psum_part, double* gram_part);
+                             const double* aden, const double* wsq, bool general, double* P, double* rinv_slot, double* gram_part);
+
 // 129 .. 256 states: P = exp(aden_k - u_kn - logden_n) (rows = padded state count; padding and sub-normal entries: 0)
 hipError_t launch_make_p(hipStream_t s, int num_cu, const double* u, int64_t ld, int64_t N, int64_t rows, const double* aden,
                          const double* logden, double* P);

@@ -333,7 +333,13 @@ k_fused(const double* __restrict__ P, int64_t ld, int64_t N, int64_t ntiles, con
 #pragma unroll
             for (int J = I; J < NB; ++J, ++b) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = G[b][r];
+                for (int r = 0; r < 4; ++r) {
+#if defined(MBAR_GRAM_STORE_NT)  // (A/B build, profiles/r6_ab_fused_record_stores_nt.txt)
+                    __builtin_nontemporal_store(G[b][r], &gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane]);
+#else
+                    gram_part[((gw * NBLK + b) * 4 + r) * 64 + lane] = G[b][r];
+#endif
+                }
             }
     }
 }

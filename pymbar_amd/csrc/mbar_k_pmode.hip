@@ -193,16 +193,24 @@ k_build_sweep(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntile
 // cores: the normalised probabilities it writes to P are exactly the MFMA operands, so the separate first Gram sweep of
 // the fused loop (one more pass over HBM) is not needed.  One group of 4 samples at a time (the 36 accumulator blocks
 // of a 128-state panel leave no room for two groups of exponential temporaries).  wsq: sqrt of the sample multiplicities.
-template <int NB, bool WIDE>
+// The kernel is bound by matrix + vector ISSUE on the pipe they share (9.2 k matrix cycles + the vector instructions of 512
+// exponentials per tile and wave), so round 6 took vector instructions out of it -- per element 18 -> 14:
+//   * the per-state sums are not accumulated: the rows of p sum to one, so sum_n c_n p_kn = sum_j G_kj of the Gram matrix this very
+//     sweep accumulates (the host adds the rows of the reduced blocks: gram_row_sums);
+//   * GENERAL = false (no sample multiplicities, no +inf entries in the matrix -- the first solve on a matrix): the operand IS the
+//     probability (no multiplication by the root of the multiplicity; a sample beyond N gets the reciprocal 0 instead, which also
+//     leaves an all-zero column in P's padding -- what the sweeps on P expect there), and the exponential needs no clamp;
+//   * the exponential takes a non-negative argument "column maximum minus entry" (exp2s_neg_batch: fract + one conversion instead
+//     of rint + subtract + convert).
+template <int NB, bool WIDE, bool GENERAL>
 __global__ void __launch_bounds__(256, 1)
 k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ aden,
-             const double* __restrict__ cw, const double* __restrict__ wsq, double* __restrict__ P,
-             double* __restrict__ rinv_slot, double* __restrict__ psum_part, double* __restrict__ gram_part) {
+             const double* __restrict__ wsq, double* __restrict__ P, double* __restrict__ rinv_slot, double* __restrict__ gram_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = NB * 16;
     constexpr int NDMA = ROWS / 8;
     constexpr int U_BYTES = ROWS * TS * 8;
-    constexpr int TILE_BYTES = U_BYTES + 2 * TS * 8;  // + the tile's 16 sample weights and their square roots
+    constexpr int TILE_BYTES = U_BYTES + TS * 8;  // + the square roots of the tile's 16 sample multiplicities
     constexpr int NBLK = NB * (NB + 1) / 2;
     constexpr bool PINNED = NBLK > GRAM_AGPR_BLOCKS;
     const int lane = threadIdx.x & 63;
@@ -217,15 +225,17 @@ k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles
     RowIdentity rows{0};
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
 
-    double a[NB], acc[NB];
+    double aL[NB];  // a_k log2(e) S; states without samples / padding rows: a finite sentinel far below everything (their e is 0)
+    {
+        double a[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) {
-        a[I] = aden[16 * I + ks];
-        acc[I] = 0.0;
+        for (int I = 0; I < NB; ++I) a[I] = aden[16 * I + ks];
+        if constexpr (NB <= 2) rows.live = live_piece_mask<NB>(a, -INFINITY);  // (narrow panels only: see k_gram)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) aL[I] = a[I] > -INFINITY ? a[I] * LOG2E_S : -1.0e9;
     }
 #pragma unroll
-    for (int I = 0; I < NB; ++I) settle(a[I]);
-    if constexpr (NB <= 2) rows.live = live_piece_mask<NB>(a, -INFINITY);  // (narrow panels only: see k_gram)
+    for (int I = 0; I < NB; ++I) settle(aL[I]);
     v4d G[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) G[b] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -236,8 +246,7 @@ k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles
 
     auto stage = [&](int64_t tile, char* dst) {
         stage_tile<ROWS, true, 0, 1>(u, ld, tile * TS, dst, lane, so, rows);
-        stage_vec16<true>(cw, tile * TS, dst + U_BYTES, lane);
-        stage_vec16<true>(wsq, tile * TS, dst + U_BYTES + TS * 8, lane);
+        stage_vec16<true>(wsq, tile * TS, dst + U_BYTES, lane);
     };
     int64_t t = gw;
     int cur = 0;
@@ -247,58 +256,96 @@ k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles
         const int64_t tn = t + W;
         if (tn < ntiles) {
             stage(tn, buf + (cur ^ 1) * TILE_BYTES);
-            // vmcnt counts stores too, in issue order: [tile t: NDMA + 2][stores of tile t - W: NDMA + 1][tile tn: NDMA + 2]
+            // vmcnt counts stores too, in issue order: [tile t: NDMA + 1][stores of tile t - W: NDMA + 1][tile tn: NDMA + 1]
             if (t != gw)
-                wait_vm<(NDMA + 1) + (NDMA + 2)>();
+                wait_vm<2 * (NDMA + 1)>();
             else
-                wait_vm<NDMA + 2>();
+                wait_vm<NDMA + 1>();
         } else {
             wait_vm<0>();
         }
+        const int nvalid = (int)(N - t * TS < TS ? N - t * TS : TS);  // (wave-uniform: samples of this tile that exist)
+        auto mfma = [&](int b, double xx, double yy) {
+            if constexpr (PINNED) {
+                if (b < GRAM_AGPR_BLOCKS)
+                    asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(G[b]) : "v"(xx), "v"(yy));
+                else
+                    asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(G[b]) : "v"(xx), "v"(yy));
+            } else {
+                G[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xx, yy, G[b], 0, 0, 0);
+            }
+        };
+        // Two groups of four samples side by side (round 6): a group's way from its LDS reads to its operands is a CHAIN -- tile
+        // read, 16-lane maximum (DPP), table look-up, 16-lane sum (DPP), reciprocal -- whose latencies a lone wave cannot hide behind
+        // anything but independent work of its own; the second group's chain is that work.  (Round 5 had no registers for it: 200
+        // vector registers beside the 248 accumulator registers; the leaner exponential and the dropped per-state sums left 121.)
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g) {
-            const double w = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
-            const double sw = *reinterpret_cast<const double*>(cbuf + U_BYTES + TS * 8 + (4 * g + ns) * 8);
-            double x[NB];
-#pragma unroll
-            for (int I = 0; I < NB; ++I) x[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int I = 0; I < NB; ++I) x[I] = a[I] - x[I];
-            const double m2 = row16_max(tree_max<NB>(x)) * LOG2E_S;
-#pragma unroll
-            for (int I = 0; I < NB; ++I) x[I] = fma(x[I], LOG2E_S, -m2);
-            exp2s_batch<NB>(x);
-            const double ri = recip_fast(row16_sum(tree_sum<NB>(x)));
-            const bool valid = (t * TS + 4 * g + ns) < N;
-            const double opw = valid ? sw : 0.0;
-            double p[NB];
+        for (int g = 0; g < GROUPS; g += 2) {
+            double x0[NB], x1[NB];
 #pragma unroll
             for (int I = 0; I < NB; ++I) {
-                x[I] *= ri;                                   // P_kn
-                acc[I] = fma(x[I], w, acc[I]);                // per-state sums (gradient at the anchor)
-                *reinterpret_cast<double*>(cbuf + I * (16 * TS * 8) + pos[g]) = x[I];
-                p[I] = x[I] * opw;                            // MFMA operand (sqrt of the multiplicity; 0 on the padding)
+                x0[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g]);
+                x1[I] = *reinterpret_cast<const double*>(cbuf + I * (16 * TS * 8) + pos[g + 1]);
             }
-            auto mfma = [&](int b, double xx, double yy) {
-                if constexpr (PINNED) {
-                    if (b < GRAM_AGPR_BLOCKS)
-                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(G[b]) : "v"(xx), "v"(yy));
-                    else
-                        asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(G[b]) : "v"(xx), "v"(yy));
-                } else {
-                    G[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xx, yy, G[b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+                x0[I] = fma(x0[I], -LOG2E_S, aL[I]);   // (a_k - u_kn) log2(e) S
+                x1[I] = fma(x1[I], -LOG2E_S, aL[I]);
+            }
+            double m0 = tree_max<NB>(x0), m1 = tree_max<NB>(x1);
+            row16_max2(m0, m1);
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+                x0[I] = m0 - x0[I];                      // >= 0, exactly 0 for the column's largest term
+                x1[I] = m1 - x1[I];
+            }
+            exp2s_neg_batch2<NB, GENERAL>(x0, x1);
+            double s0 = tree_sum<NB>(x0), s1 = tree_sum<NB>(x1);
+            row16_sum2(s0, s1);
+            double ri0 = recip_fast(s0), ri1 = recip_fast(s1);
+            if (4 * g + ns >= nvalid) ri0 = 0.0;       // beyond N: an all-zero column of P, operand 0
+            if (4 * g + 4 + ns >= nvalid) ri1 = 0.0;
+            double p0[NB], p1[NB];
+            if constexpr (GENERAL) {
+                const double sw0 = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + ns) * 8);
+                const double sw1 = *reinterpret_cast<const double*>(cbuf + U_BYTES + (4 * g + 4 + ns) * 8);
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    x0[I] *= ri0;                          // P_kn
+                    x1[I] *= ri1;
+                    *reinterpret_cast<double*>(cbuf + I * (16 * TS * 8) + pos[g]) = x0[I];
+                    *reinterpret_cast<double*>(cbuf + I * (16 * TS * 8) + pos[g + 1]) = x1[I];
+                    p0[I] = x0[I] * sw0;                   // MFMA operand: the root of the multiplicity rides on both sides
+                    p1[I] = x1[I] * sw1;
                 }
-            };
+            } else {
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    p0[I] = x0[I] * ri0;                   // P_kn = the MFMA operand
+                    p1[I] = x1[I] * ri1;
+                    *reinterpret_cast<double*>(cbuf + I * (16 * TS * 8) + pos[g]) = p0[I];
+                    *reinterpret_cast<double*>(cbuf + I * (16 * TS * 8) + pos[g + 1]) = p1[I];
+                }
+            }
             if constexpr (PINNED) {
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 7");
             }
-            int b = 0;
+            {
+                int b = 0;
 #pragma unroll
-            for (int I = 0; I < NB; ++I)
+                for (int I = 0; I < NB; ++I)
 #pragma unroll
-                for (int J = I; J < NB; ++J) mfma(b++, p[I], p[J]);
+                    for (int J = I; J < NB; ++J) mfma(b++, p0[I], p0[J]);
+            }
+            {
+                int b = 0;
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+#pragma unroll
+                    for (int J = I; J < NB; ++J) mfma(b++, p1[I], p1[J]);
+            }
             if constexpr (PINNED) __builtin_amdgcn_sched_barrier(0);
         }
         // the tile now holds P: out with it, 16 bytes per lane, 8 lanes per row (the LDS-DMA pattern backwards)
@@ -317,13 +364,6 @@ k_build_gram(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles
         cur ^= 1;
     }
     if constexpr (PINNED) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-    for (int I = 0; I < NB; ++I) {
-        double v = acc[I];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16) psum_part[gw * ROWS + 16 * I + lane] = v;
-    }
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
 #pragma unroll
@@ -569,13 +609,12 @@ LaunchGeom build_gram_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_
     // (same grid as the fused sweep, so that the partial-record counts agree; the kernel strides over tiles, so it does
     // not matter if the look-up tables leave room for one workgroup per CU less)
     LaunchGeom g = fused_geometry(nb, num_cu, ntiles, grid_override);
-    g.lds_bytes = (size_t)4 * 2 * ((size_t)nb * 16 * TS * 8 + 2 * TS * 8) + EXP_TABLE_BYTES;  // (its own tile layout + the tables)
+    g.lds_bytes = (size_t)4 * 2 * ((size_t)nb * 16 * TS * 8 + TS * 8) + EXP_TABLE_BYTES;  // (its own tile layout + the tables)
     return g;
 }
 template <int NB>
 static hipError_t launch_build_gram_nb(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
-                                       const double* aden, const double* cw, const double* wsq, double* P, double* rinv_slot,
-                                       double* pp, double* gp) {
+                                       const double* aden, const double* wsq, bool general, double* P, double* rinv_slot, double* gp) {
     auto go = [&](auto kern) -> hipError_t {
         if (g.lds_bytes > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -583,17 +622,17 @@ static hipError_t launch_build_gram_nb(hipStream_t s, const LaunchGeom& g, const
             if (e != hipSuccess) return e;
         }
         const int64_t ntiles = (N + TS - 1) / TS;
-        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, u, ld, N, ntiles, aden, cw, wsq, P, rinv_slot, pp, gp);
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, u, ld, N, ntiles, aden, wsq, P, rinv_slot, gp);
         return hipGetLastError();
     };
-    return stage_offsets_wide(ld) ? go(k_build_gram<NB, true>) : go(k_build_gram<NB, false>);
+    if (general) return stage_offsets_wide(ld) ? go(k_build_gram<NB, true, true>) : go(k_build_gram<NB, false, true>);
+    return stage_offsets_wide(ld) ? go(k_build_gram<NB, true, false>) : go(k_build_gram<NB, false, false>);
 }
 hipError_t launch_build_gram(hipStream_t s, int nb, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
-                             const double* aden, const double* cw, const double* wsq, double* P, double* rinv_slot,
-                             double* psum_part, double* gram_part) {
+                             const double* aden, const double* wsq, bool general, double* P, double* rinv_slot, double* gram_part) {
     switch (nb) {
 #define MBAR_CASE(NB_) \
-    case NB_: return launch_build_gram_nb<NB_>(s, g, u, ld, N, aden, cw, wsq, P, rinv_slot, psum_part, gram_part);
+    case NB_: return launch_build_gram_nb<NB_>(s, g, u, ld, N, aden, wsq, general, P, rinv_slot, gram_part);
         MBAR_CASE(1) MBAR_CASE(2) MBAR_CASE(3) MBAR_CASE(4) MBAR_CASE(5) MBAR_CASE(6) MBAR_CASE(7) MBAR_CASE(8)
 #undef MBAR_CASE
         default: return hipErrorInvalidValue;

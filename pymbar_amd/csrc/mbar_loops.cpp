@@ -538,24 +538,30 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         {
             ScopedTimer t(c, MBAR_TIMER_OTHER);
             if (fused)
-                HIPCHK(c, launch_build_gram(c->stream, nb, gb, c->u, c->ld, c->N, d_aden(c), c->cw, c->weighted ? c->cwsq : c->cw,
-                                            c->P, c->logden[0], c->part, c->part_g));
+                HIPCHK(c, launch_build_gram(c->stream, nb, gb, c->u, c->ld, c->N, d_aden(c), c->weighted ? c->cwsq : c->cw,
+                                            c->weighted || !lc_slot.unclamped, c->P, c->logden[0], c->part_g));
             else
                 HIPCHK(c, launch_build_sweep(c->stream, nb, gb, c->u, c->ld, c->N, d_aden(c), c->cw, c->P, c->logden[0], c->part));
         }
-        if (fused) {  // per-state sums and the Gram matrix at the anchor: one pair of reduction launches, ONE all-reduce
-            HIPCHK(c, launch_reduce2(c->stream, c->part, Kp, c->part_g, (int64_t)rec_g, gb.nwaves, c->scratch, c->red,
-                                     c->red + off_gram));
-            rc = allreduce_dev(c, c->red, (int64_t)(off_gram + rec_g), 0);
+        if (fused) {
+            // the Gram matrix at the anchor: one reduction, ONE all-reduce; the per-state sums are its row sums (the rows of p sum to
+            // one: sum_n c_n p_kn = sum_j G_kj), taken on the host from the reduced blocks -- the build sweep accumulates none
+            HIPCHK(c, launch_reduce(c->stream, c->part_g, gb.nwaves, (int64_t)rec_g, c->scratch, c->red + off_gram));
+            rc = allreduce_dev(c, c->red + off_gram, (int64_t)rec_g, 0);
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->hred + off_gram, c->red + off_gram, rec_g * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            rc = sync_stream(c);
+            if (rc) return rc;
+            gram_row_sums(c->hred + off_gram, (int)nb, K, psum.data());
         } else {
             HIPCHK(c, launch_reduce(c->stream, c->part, gb.nwaves, Kp, c->scratch, c->red));
             rc = allreduce_dev(c, c->red, Kp, 0);
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->hred, c->red, (size_t)Kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            rc = sync_stream(c);
+            if (rc) return rc;
+            for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k];
         }
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->hred, c->red, (size_t)Kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        rc = sync_stream(c);
-        if (rc) return rc;
-        for (int64_t k = 0; k < K; ++k) psum[k] = c->hred[k];
         c->P_a0 = an0;
         c->P_valid = true;
         res.builds += 1;
