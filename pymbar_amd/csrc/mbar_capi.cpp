@@ -808,6 +808,10 @@ int mbar_ctx_set_option(mbar_ctx* c, const char* key, int64_t value) {
     else if (k == "sci_merged") c->opt_sci_merged = value;
     else if (k == "host_pmode") c->opt_host_pmode = value;
     else if (k == "rect_waves") c->opt_rect_waves = value == 8 ? 8 : 4;
+    else if (k == "newton_ldlt") {
+        c->opt_newton_ldlt = value ? 1 : 0;
+        (void)drop_graphs(c);
+    }
     else if (k == "sci_pingpong") {
         c->opt_sci_pingpong = value;
         (void)drop_graphs(c);

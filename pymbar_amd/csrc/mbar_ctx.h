@@ -321,7 +321,7 @@ struct mbar_ctx {
     // options
     int64_t opt_grid = 0, opt_force_generic = 0, opt_check_finite = 1, opt_sci_batch = 16, opt_timing = 0, opt_graph = 1, opt_small = 1, opt_wide = 1;
     int64_t opt_device_loop = 1, opt_adapt_batch = 8, opt_pmode = 1, opt_fused = 1, opt_quad = 1, opt_device_loop_wide = 1, opt_pcache = 1, opt_merge_select = 1, opt_sci_merged = 1, opt_wide_pmode = 1, opt_quad_trim = 1, opt_light_last = 1, opt_direct_results = 1, opt_debug_download_p = 0;
-    int64_t opt_small_balanced = 1, opt_sci_pingpong = 1, opt_host_pmode = 2, opt_rect_waves = 8;
+    int64_t opt_small_balanced = 1, opt_sci_pingpong = 1, opt_host_pmode = 2, opt_rect_waves = 8, opt_newton_ldlt = 1;
 
     // comm
     ncclComm_t comm = nullptr;

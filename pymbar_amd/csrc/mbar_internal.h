@@ -261,6 +261,8 @@ struct AdaptArgs {
     int light_ok;
     // MBAR_DEBUG_STAMPS=1: shader-clock stamps of the phases of k_select_newton (thread 0; [8] per launch slot, 64 slots)
     long long* stamps;
+    // K x K Newton solve up to 128 states: 1 = blocked LDL^T on the matrix cores (newton_body_ldlt), 0 = register Gauss-Jordan
+    int newton_ldlt;
 };
 // ---- P mode: resident probability matrix P = exp(a0 - u - logden(a0)) (see k_psweep) ----------------------------------
 LaunchGeom psweep_geometry(int nb, int num_cu, int64_t ntiles, int64_t grid_override);

@@ -1050,6 +1050,267 @@ k_select(AdaptArgs q, int gram_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
     select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
 }
+// ---------------------------------------------------------------------------------------------
+// The K x K Newton solve as a BLOCKED LDL^T factorisation on the fp64 matrix cores (round 6; up to 128 states, the default).
+// The register Gauss-Jordan solve above (newton_body) does K^3 / 2 multiply-adds in 64 two-pivot steps with a barrier each and
+// is bound by the vector issue rate of one compute unit (114 k clocks at 127 unknowns); here the work is K^3 / 6, almost all of
+// it rank-16 updates of 16 x 16 blocks (four v_mfma_f64_16x16x4_f64 each), with TWO barriers per block column of 16 pivots
+// instead of one per two pivots.  tools/newton_ldlt_model.py is the lane-level numpy statement of the same algorithm.
+//   * Rows / columns are the states 0 .. Kp-1 in their natural order, so the 16 x 16 blocks are the blocks of the reduced Gram
+//     record.  live = sampled and not the gauge state; every other row is an identity row (pivot 1, no coupling, x = 0).  Row 0
+//     is never live (state 0 is the gauge state or unsampled): it carries the right-hand side g and RIDES ALONG -- pivots run
+//     from the LAST row upwards (H = U D U^T), so row 0 is eliminated by every pivot and never is one.
+//   * Block (i, j), i <= j, is held TRANSPOSED in the accumulator layout of the matrix instruction: lane (g, r), register t <->
+//     row 16 i + r, column 16 j + 4 t + g.  In that layout the pivot row of the diagonal block and column p of a panel block
+//     are operands AS THEY STAND (the 16 lanes of group g = p & 3 of register t = p >> 2; the other lane groups of the operand
+//     are zero), a pivot is one rank-1 matrix instruction per block of the block column, and register t of a finished panel
+//     block is the K-chunk {pivots 4 t + g} of the rank-16 update -- no transposition anywhere.
+//   * Every wave eliminates the diagonal block for itself (bit-identical copies) and carries its share of the panel blocks
+//     (block (i, j) lives in wave (i + j) & 3, slot i >> 2; diagonal masters in wave j & 3), so there is no exchange inside a
+//     block column.  Per block column: frozen panel -> LDS (plain V, and W = -V / d), barrier, every wave updates its blocks of
+//     the trailing matrix B_ij += V_j W_i^T, the master of the next diagonal block goes to LDS, barrier.
+//   * x by forward substitution on the unit triangle W with x_0 = -1 (the ride-along row makes the right-hand side one more
+//     column of the triangle): one thread per unknown, 16 sequential steps per diagonal block through v_readlane.
+// Pivots are recorded and tested against the same threshold as before (a live pivot <= eps * M * max psum, or a non-finite one,
+// hands the solve to the host loop); they are the pivots of the REVERSED elimination order, not of the ascending one.
+// LDS: 44 blocks of 2 KB (7 plain panels, 28 scaled panels, 8 scaled diagonal blocks, 1 exchange) in the dynamic allocation,
+// which the selection's staged Gram blocks (dead once the set-up has them in registers) share.
+// ---------------------------------------------------------------------------------------------
+constexpr int LDLT_BLK = 4 * 64;             // doubles of a 16 x 16 block in register order [t][lane]
+constexpr int LDLT_V_OFF = 0;                // [7]  plain panel blocks (i, kb) of the current block column
+constexpr int LDLT_W_OFF = 7 * LDLT_BLK;     // [28] scaled panel blocks, index kb (kb - 1) / 2 + i
+constexpr int LDLT_DW_OFF = 35 * LDLT_BLK;   // [8]  scaled frozen diagonal blocks
+constexpr int LDLT_DN_OFF = 43 * LDLT_BLK;   // [1]  the next diagonal block, from its master to every wave
+constexpr int LDLT_LDS_DOUBLES = 44 * LDLT_BLK;
+static_assert(LDLT_LDS_DOUBLES >= SELECT_GRAM_LDS_DOUBLES, "the staged Gram blocks share the allocation");
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ v4d ldlt_read_block(const double* p, int lane) {
+    v4d r;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r[t] = p[t * 64 + lane];
+    return r;
+}
+__device__ __forceinline__ void ldlt_write_block(double* p, int lane, const v4d& v) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p[t * 64 + lane] = v[t];
+}
+__device__ __forceinline__ void ldlt_rank16(v4d& acc, const v4d& a, const v4d& b) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
+}
+
+template <int NB>  // block rows the instantiation has registers for: 4 (up to 64 states) or 8 (up to 128)
+__device__ __forceinline__ void newton_body_ldlt(const AdaptArgs& q, double* ws, const double* gram_lds, long long* st = nullptr) {  // 256 threads
+    __shared__ double s_f[128], s_ps[128], s_nk[128], s_ln[128], s_cc[128], s_a0[128], s_b[128], s_dg[128], s_x[128], s_pv[128];
+    __shared__ int s_live[128], s_first[1], s_pos[128];
+    __shared__ double s_pmax[4];
+    if (q.ctl[CTL_DONE] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = lane >> 4, R = lane & 15;
+    const int nb = q.Kp / 16, M = q.m - 1;
+    const int first = q.sampled[0];
+    double pm = 0.0;
+    if (tid < 128) {
+        const int k = tid;
+        const bool in = k < q.Kp;
+        const double nk = in ? q.Nk[k] : 0.0, ps = in ? q.psum[k] : 0.0;
+        const bool sampled = k < q.K && nk > 0.0;
+        const bool live = sampled && k != first;
+        s_f[k] = k < q.K ? q.f[k] : 0.0;
+        s_ps[k] = ps;
+        s_nk[k] = nk;
+        s_ln[k] = in ? q.lnNk[k] : 0.0;
+        s_cc[k] = (in && q.pmode) ? (q.fused ? q.cgram[k] : q.ccur[k]) : 1.0;  // the multipliers the Gram sweep left out
+        s_a0[k] = (in && q.pmode) ? q.a0[k] : 0.0;
+        s_live[k] = live ? 1 : 0;
+        s_b[k] = live ? ps - nk : 0.0;   // g (:284-292), the ride-along row
+        s_dg[k] = live ? ps : 1.0;       // diagonal of H (:395-411) / of an identity row
+        s_pos[k] = k;                    // (newton_tail indexes the direction through the sampled list: here by state)
+        s_pv[k] = 1.0;
+        if (sampled) pm = ps;
+    }
+    if (tid == 0) s_first[0] = first;
+    pm = wave_max(pm);
+    if (lane == 0) s_pmax[wave] = pm;
+    __syncthreads();
+    // pivots below eps * M * (largest per-state sum, which bounds the diagonal of H) count as zero like the singular values
+    // numpy.linalg.lstsq drops (:582): the host path then takes the pseudo-inverse
+    const double piv_thr = fmax(fmax(s_pmax[0], s_pmax[1]), fmax(s_pmax[2], s_pmax[3])) * 2.220446049250313e-16 * (double)(M > 0 ? M : 1);
+
+    // ---- set-up: H = diag(psum) - c c^T G on the live states, identity elsewhere, g in row / column 0
+    auto load_block = [&](int i, int j) -> v4d {  // (i <= j < nb, wave-uniform)
+        const int b = i * nb - (i * (i - 1)) / 2 + (j - i);
+        const int kr = 16 * i + R;
+        const bool lr = s_live[kr] != 0;
+        const double ncr = -s_cc[kr];
+        v4d a;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = 4 * t + G, kc = 16 * j + c;
+            const double gv = gram_lds ? gram_lds[b * (16 * SELECT_GRAM_PITCH) + R * SELECT_GRAM_PITCH + c] : q.gram_red[b * 256 + R * 16 + c];
+            const bool lc = s_live[kc] != 0;
+            double v = (lr && lc) ? ncr * s_cc[kc] * gv : 0.0;
+            if (i == j && R == c) v += s_dg[kr];
+            if (i == 0 && R == 0 && kc != 0) v = s_b[kc];  // row 0
+            if (j == 0 && c == 0 && kr != 0) v = s_b[kr];  // column 0 (block (0, 0) only)
+            a[t] = v;
+        }
+        return a;
+    };
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    v4d Pn[NB - 1][2], Dm[2];
+#pragma unroll
+    for (int j = 1; j < NB; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int i = 4 * s + ((wave - j) & 3);
+            Pn[j - 1][s] = (j < nb && i < j) ? load_block(i, j) : zero4;
+        }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int j = wave + 4 * s;
+        Dm[s] = j < nb ? load_block(j, j) : zero4;
+    }
+    __syncthreads();  // (the staged Gram blocks are dead from here: ws may be written)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        if (wave + 4 * s == nb - 1) ldlt_write_block(ws + LDLT_DN_OFF, lane, Dm[s]);
+    __syncthreads();
+    if (st && tid == 0) st[2] = clock64();
+
+    // ---- elimination, block column by block column from the last
+#pragma unroll
+    for (int kb = NB - 1; kb >= 0; --kb) {
+        if (kb < nb) {
+            v4d D = ldlt_read_block(ws + LDLT_DN_OFF, lane);
+            const int i0 = (wave - kb) & 3, i1 = 4 + i0;  // this wave's panel blocks of the block column
+            const bool ok0 = i0 < kb, ok1 = i1 < kb;
+            v4d RV = zero4;
+#pragma unroll
+            for (int p = 15; p >= (kb == 0 ? 1 : 0); --p) {
+                const int t = p >> 2, g = p & 3;
+                const double d = readlane_f64(D[t], 16 * g + p);
+                if (tid == 0) s_pv[16 * kb + p] = d;
+                const double nr = -recip_fast(d);
+                const bool gs = G == g;
+                const double X = (gs && R < p) ? D[t] : 0.0;  // the pivot row, left of the pivot
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(X, X * nr, D, 0, 0, 0);
+                if (kb > 0) {
+                    if (ok0) {
+                        const double Y = gs ? Pn[kb > 0 ? kb - 1 : 0][0][t] * nr : 0.0;  // column p of the panel block over the pivot
+                        Pn[kb > 0 ? kb - 1 : 0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(X, Y, Pn[kb > 0 ? kb - 1 : 0][0], 0, 0, 0);
+                    }
+                    if (ok1) {
+                        const double Y = gs ? Pn[kb > 0 ? kb - 1 : 0][1][t] * nr : 0.0;
+                        Pn[kb > 0 ? kb - 1 : 0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(X, Y, Pn[kb > 0 ? kb - 1 : 0][1], 0, 0, 0);
+                    }
+                }
+                RV[t] = gs ? nr : RV[t];
+            }
+            // the frozen block column: V (this block column's updates only) and W = -V / d (kept for the substitution)
+            if (kb > 0) {
+                if (ok0) {
+                    ldlt_write_block(ws + LDLT_V_OFF + i0 * LDLT_BLK, lane, Pn[kb > 0 ? kb - 1 : 0][0]);
+                    ldlt_write_block(ws + LDLT_W_OFF + (kb * (kb - 1) / 2 + i0) * LDLT_BLK, lane, Pn[kb > 0 ? kb - 1 : 0][0] * RV);
+                }
+                if (ok1) {
+                    ldlt_write_block(ws + LDLT_V_OFF + i1 * LDLT_BLK, lane, Pn[kb > 0 ? kb - 1 : 0][1]);
+                    ldlt_write_block(ws + LDLT_W_OFF + (kb * (kb - 1) / 2 + i1) * LDLT_BLK, lane, Pn[kb > 0 ? kb - 1 : 0][1] * RV);
+                }
+            }
+            if (wave == (kb & 3)) {
+                v4d dw = D * RV;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dw[t] = R < 4 * t + G ? dw[t] : 0.0;  // entry [c][r], r < c: the pivot row of pivot c
+                ldlt_write_block(ws + LDLT_DW_OFF + kb * LDLT_BLK, lane, dw);
+            }
+            if (kb > 0) {
+                __syncthreads();
+                // trailing matrix: B_ij += V_j W_i^T for this wave's blocks, the next diagonal block first
+#pragma unroll
+                for (int j = kb - 1; j >= 0; --j) {
+                    const int a0 = (wave - j) & 3, a1 = 4 + a0;
+                    const bool own_d = (j & 3) == wave, t0 = j > 0 && a0 < j, t1 = j > 0 && a1 < j;
+                    if (own_d || t0 || t1) {
+                        const v4d Vj = ldlt_read_block(ws + LDLT_V_OFF + j * LDLT_BLK, lane);
+                        if (own_d) {
+                            const v4d Wj = ldlt_read_block(ws + LDLT_W_OFF + (kb * (kb - 1) / 2 + j) * LDLT_BLK, lane);
+                            ldlt_rank16(Dm[j >> 2], Vj, Wj);
+                            if (j == kb - 1) ldlt_write_block(ws + LDLT_DN_OFF, lane, Dm[j >> 2]);
+                        }
+                        if (t0) {
+                            const v4d Wi = ldlt_read_block(ws + LDLT_W_OFF + (kb * (kb - 1) / 2 + a0) * LDLT_BLK, lane);
+                            ldlt_rank16(Pn[j > 0 ? j - 1 : 0][0], Vj, Wi);
+                        }
+                        if (t1) {
+                            const v4d Wi = ldlt_read_block(ws + LDLT_W_OFF + (kb * (kb - 1) / 2 + a1) * LDLT_BLK, lane);
+                            ldlt_rank16(Pn[j > 0 ? j - 1 : 0][1], Vj, Wi);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (st && tid == 0) st[3] = clock64();
+
+    // ---- x_P = sum_{r < P} W[r][P] x_r with x_0 = -1: thread P; a diagonal block is 16 sequential steps of its 16 lanes
+    {
+        __syncthreads();  // (the last diagonal block of W)
+        const int P = tid & 127, kbP = P >> 4, p = P & 15;
+        double wd[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wd[r] = ws[LDLT_DW_OFF + kbP * LDLT_BLK + (p >> 2) * 64 + 16 * (p & 3) + r];  // zero for r >= p
+        double accx = 0.0;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            if (kb < nb) {
+                if (wave == (kb >> 2)) {
+                    if (G == (kb & 3)) {
+                        double xv = (kb == 0 && R == 0) ? -1.0 : accx;
+#pragma unroll
+                        for (int r = 0; r < 15; ++r) xv = fma(wd[r], readlane_f64(xv, 16 * (kb & 3) + r), xv);
+                        s_x[16 * kb + R] = xv;
+                    }
+                }
+                __syncthreads();
+                if (tid < 128 && kbP > kb && kbP < nb) {
+                    const double* wp = ws + LDLT_W_OFF + (kbP * (kbP - 1) / 2 + kb) * LDLT_BLK + (p >> 2) * 64 + 16 * (p & 3);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accx = fma(wp[r], s_x[16 * kb + r], accx);
+                }
+            }
+        }
+        __syncthreads();
+        // the gauge component (and the ride-along -1 of row 0) are zero in the direction
+        if (tid == 0) {
+            s_x[0] = 0.0;
+            s_x[first] = 0.0;
+        }
+        __syncthreads();
+    }
+    bool bad = false;
+    if (tid < 128 && tid < q.Kp && s_live[tid]) {
+        const double pvv = s_pv[tid];
+        bad = !(pvv > piv_thr) || !isfinite(pvv);
+    }
+    if (st && tid == 0) st[4] = clock64();
+    newton_tail<256>(q, s_x, bad, s_f, s_ps, s_nk, s_ln, s_a0, s_first, s_pos, tid);
+}
+// (amdgpu_waves_per_eu(2): at most 256 registers, for which the compiler takes the matrix instructions' VGPR form -- with the whole
+// 512 it keeps the accumulators in AGPRs and copies every block to VGPRs and back around each pivot's vector instructions)
+template <int NB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_newton_ldlt(AdaptArgs q) {
+    extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
+    newton_body_ldlt<NB>(q, select_dyn_lds, nullptr);
+}
+
 // Fused loop: the selection of iteration i and the Newton solve of iteration i + 1 in ONE launch (a kernel boundary costs ~5 us;
 // at the sizes pymbar is mostly used at that is a tenth of an iteration).  A stop or pause flag raised by the selection makes the
 // solve return at once.
@@ -1063,6 +1324,18 @@ k_select_newton(AdaptArgs q, int gram_in_lds) {
     __syncthreads();
     if (st && threadIdx.x == 0) st[1] = clock64();
     newton_body<16, R>(q, st);
+    if (st && threadIdx.x == 0) st[5] = clock64();
+}
+template <int NB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_select_newton_ldlt(AdaptArgs q, int gram_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
+    long long* st = q.stamps ? q.stamps + 8 * (q.ctl[CTL_ITER] & 63) : nullptr;  // (debug: one slot per iteration)
+    if (st && threadIdx.x == 0) st[0] = clock64();
+    select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
+    __syncthreads();
+    if (st && threadIdx.x == 0) st[1] = clock64();
+    newton_body_ldlt<NB>(q, select_dyn_lds, gram_in_lds ? select_dyn_lds : nullptr, st);
     if (st && threadIdx.x == 0) st[5] = clock64();
 }
 
@@ -1312,6 +1585,16 @@ hipError_t launch_reduce2(hipStream_t s, const double* partA, int64_t countA, co
 hipError_t launch_newton(hipStream_t s, const AdaptArgs& a) {
     const int M = a.m - 1;
     if (M > 127 || a.Kp > 128) return hipErrorInvalidValue;
+    if (a.newton_ldlt) {
+        const size_t lds = (size_t)LDLT_LDS_DOUBLES * sizeof(double);
+        auto go = [&](auto kern) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, s, a);
+            return hipGetLastError();
+        };
+        return a.Kp <= 64 ? go(k_newton_ldlt<4>) : go(k_newton_ldlt<8>);
+    }
     if (M <= 31)
         hipLaunchKernelGGL((k_newton<8, 4>), dim3(1), dim3(64), 0, s, a);
     else if (M <= 63)
@@ -1355,7 +1638,7 @@ hipError_t launch_select_newton(hipStream_t s, const AdaptArgs& a) {
     if (M > 127 || a.Kp > 128) return hipErrorInvalidValue;
     // full panel in the fused loop: the selection takes the second candidate's per-state sums from the reduced Gram blocks, staged in LDS
     const int stage = (a.fused && a.Kp == 128) ? 1 : 0;
-    const size_t lds = stage ? (size_t)SELECT_GRAM_LDS_DOUBLES * sizeof(double) : 0;
+    const size_t lds = a.newton_ldlt ? (size_t)LDLT_LDS_DOUBLES * sizeof(double) : stage ? (size_t)SELECT_GRAM_LDS_DOUBLES * sizeof(double) : 0;
     auto go = [&](auto kern) -> hipError_t {
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1364,6 +1647,7 @@ hipError_t launch_select_newton(hipStream_t s, const AdaptArgs& a) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, s, a, stage);
         return hipGetLastError();
     };
+    if (a.newton_ldlt) return a.Kp <= 64 ? go(k_select_newton_ldlt<4>) : go(k_select_newton_ldlt<8>);
     if (M <= 63) return go(k_select_newton<4>);
     return go(k_select_newton<8>);
 }

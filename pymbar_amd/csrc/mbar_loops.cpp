@@ -633,6 +633,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     q.fused = fused ? 1 : 0;
     q.cgram = fused ? c->pm_vec + 2 * Kp : nullptr;
     q.light_ok = light ? 1 : 0;
+    q.newton_ldlt = c->opt_newton_ldlt ? 1 : 0;
+    if (const char* e = std::getenv("MBAR_NEWTON_LDLT")) q.newton_ldlt = std::atoi(e) != 0 ? 1 : 0;
     q.stamps = nullptr;
     if (std::getenv("MBAR_DEBUG_STAMPS")) {
         if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 65 * 8 * sizeof(long long)));
