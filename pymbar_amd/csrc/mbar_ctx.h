@@ -312,7 +312,7 @@ struct mbar_ctx {
     size_t part_g_doubles = 0;
     double* cwsq = nullptr;         // sqrt of the per-sample multiplicities (only when weighted; else cw itself serves)
     double* chol = nullptr;         // workspace of the blocked Cholesky Newton solve (129 .. 256 states)
-    long long* stamps = nullptr;    // MBAR_DEBUG_STAMPS: phase stamps of k_select_newton (64 launches x 8)
+    long long* stamps = nullptr;    // MBAR_DEBUG_STAMPS: phase stamps of k_select_newton (64 launches x 16)
     // P outlives the solve that built it: a later solve on the same matrix whose start lies within the window of the anchor
     // (bootstrap replicates, protocol stages, continuation) starts with ONE fused sweep instead of the build sweep
     std::vector<double> last_psum;  // per-state sums at the f the last adaptive solve returned (empty: none)

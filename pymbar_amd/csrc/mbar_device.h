@@ -62,6 +62,28 @@ __device__ __forceinline__ double row16_sum(double x) {
     x += dpp_move<0x140>(x);
     return x;
 }
+// The value of lane (l ^ M): across the 16-lane rows through the LDS crossbar (ds_bpermute), inside a row by DPP -- row_ror:8,
+// two bank-masked row shifts by 4, the quad permutes -- whose latency is an instruction's, not a round trip's.  A butterfly
+// built from it adds the same pairs in the same order as one built from __shfl_xor.
+template <int M>
+__device__ __forceinline__ double lane_xor(double x) {
+    if constexpr (M >= 16) {
+        return __shfl_xor(x, M);
+    } else if constexpr (M == 8) {
+        return dpp_move<0x128>(x);
+    } else if constexpr (M == 4) {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        int tl = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xF, 0x5, false);  // quads 0, 2: lane l + 4 (row_shl:4)
+        tl = __builtin_amdgcn_update_dpp(tl, lo, 0x114, 0xF, 0xA, false);      // quads 1, 3: lane l - 4 (row_shr:4)
+        int th = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xF, 0x5, false);
+        th = __builtin_amdgcn_update_dpp(th, hi, 0x114, 0xF, 0xA, false);
+        return __hiloint2double(th, tl);
+    } else if constexpr (M == 2) {
+        return dpp_move<0x4E>(x);
+    } else {
+        return dpp_move<0xB1>(x);
+    }
+}
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);

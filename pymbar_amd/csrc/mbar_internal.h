@@ -259,7 +259,7 @@ struct AdaptArgs {
     // fused loop: the last iteration may run without its Gram matrix (CTL_LIGHT); 0 = never (small problems: an idle launch
     // per iteration would cost more than the one lighter sweep saves)
     int light_ok;
-    // MBAR_DEBUG_STAMPS=1: shader-clock stamps of the phases of k_select_newton (thread 0; [8] per launch slot, 64 slots)
+    // MBAR_DEBUG_STAMPS=1: shader-clock stamps of the phases of k_select_newton (thread 0; [16] per launch slot, 64 slots)
     long long* stamps;
     // K x K Newton solve up to 128 states: 1 = blocked LDL^T on the matrix cores (newton_body_ldlt), 0 = register Gauss-Jordan
     int newton_ldlt;

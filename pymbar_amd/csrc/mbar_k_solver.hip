@@ -927,27 +927,44 @@ k_chol_finish(AdaptArgs q, const double* __restrict__ Aw) {
 // loads -- all 36 in flight -- before the matrix-vector product below reads them.
 constexpr int SELECT_GRAM_PITCH = 17;  // a 16 x 16 block's rows are stored 17 doubles apart: the column walk of a row is conflict-free
 constexpr int SELECT_GRAM_LDS_DOUBLES = 36 * 16 * SELECT_GRAM_PITCH;
-__device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds = nullptr) {  // (256 threads; the pointers of q may be LDS or global)
-    __shared__ double red[4];
+__device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds = nullptr, long long* st = nullptr) {  // (256 threads; the pointers of q may be LDS or global)
     int* ctl = q.ctl;
-    if (ctl[CTL_DONE] != 0) return;
     const int tid = threadIdx.x, Kp = q.Kp;
-    const double tol = q.prm[1];
-    const int min_sc = (int)q.prm[2];
-    const bool check = q.prm[3] != 0.0;
-    const int first = q.sampled[0];
+    // Every input is loaded up front and unconditionally (both halves of aden / lse_red, the choice between them made afterwards):
+    // ONE round of memory latency instead of a chain of three, with the 36 loads of the staged Gram blocks queued behind them.
     const bool in = tid < Kp;
+    const int done = ctl[CTL_DONE], spec_w = ctl[CTL_SPEC], light_w = ctl[CTL_LIGHT], sci_w = ctl[CTL_SCI];
+    const double tol = q.prm[1], prm2 = q.prm[2], prm3 = q.prm[3];
+    const int first = q.sampled[0];
     const double nk = in ? q.Nk[tid] : 0.0;
+    const double ad0 = (in && q.pmode) ? q.aden[tid] : 1.0, ad1 = (in && q.pmode) ? q.aden[Kp + tid] : 1.0;
+    const double rat = (in && !q.pmode) ? q.ratio[tid] : 0.0;
+    const double ls0 = in ? q.lse_red[tid] : 0.0, ls1 = in ? q.lse_red[Kp + tid] : 0.0;
+    const double fo = in ? q.f[tid] : 0.0, fs = in ? q.cand[tid] : 0.0, fn = in ? q.cand[Kp + tid] : 0.0;
+    const double lnk = in ? q.lnNk[tid] : 0.0;
+    constexpr int NBLK_STAGE = 36;
+    double gstage[NBLK_STAGE];
+    if (gram_lds) {
+#pragma unroll
+        for (int b = 0; b < NBLK_STAGE; ++b) gstage[b] = q.gram_red[b * 256 + tid];
+    }
+    if (done != 0) return;
+    const int min_sc = (int)prm2;
+    const bool check = prm3 != 0.0;
     const bool sampled = in && tid < q.K && nk > 0.0;
     // the sweeps accumulate UNSCALED per-state sums: times the candidate's per-state constant = its psum
     // (classic: ratio c_k of the second candidate only; P mode: exp(a - a0) of both, kept in aden).  Index 0 = the
     // self-consistent candidate, 1 = Newton-Raphson; the fused sweep may have been handed them in swapped order (CTL_SPEC).
-    const bool swap = q.fused && ctl[CTL_SPEC] == 0;
-    const bool light = q.fused && q.light_ok && ctl[CTL_LIGHT] != 0;  // this iteration's sweep was the plain one: no Gram matrix
-    const int o_sci = swap ? Kp : 0, o_nr = swap ? 0 : Kp;
-    const double m0 = (in && q.pmode) ? q.aden[o_sci + tid] : 1.0;
-    const double m1 = in ? (q.pmode ? q.aden[o_nr + tid] : q.ratio[tid]) : 0.0;
-    double raw0 = in ? q.lse_red[o_sci + tid] : 0.0, raw1 = in ? q.lse_red[o_nr + tid] : 0.0;
+    const bool swap = q.fused && spec_w == 0;
+    const bool light = q.fused && q.light_ok && light_w != 0;  // this iteration's sweep was the plain one: no Gram matrix
+    const double m0 = swap ? ad1 : ad0;
+    const double m1 = in ? (q.pmode ? (swap ? ad0 : ad1) : rat) : 0.0;
+    double raw0 = swap ? ls1 : ls0, raw1 = swap ? ls0 : ls1;
+    if (st && tid == 0) st[8] = st[9] = st[10] = clock64();
+    if (gram_lds) {
+#pragma unroll
+        for (int b = 0; b < NBLK_STAGE; ++b) gram_lds[b * (16 * SELECT_GRAM_PITCH) + (tid >> 4) * SELECT_GRAM_PITCH + (tid & 15)] = gstage[b];
+    }
     if (q.fused && !light && Kp == 128 && FUSED_PSUM1_FROM_GRAM_NB <= 8) {  // (k_fused<8> only: narrower panels and k_fused_quad accumulate both rows)
         // the fused sweep of a full panel left the unscaled sums of its SECOND multiplier row c to be taken from the Gram matrix
         // it accumulated for that candidate: sum_n w_n P_kn / s_n = sum_j c_j G'_kj (rows of p sum to one)
@@ -959,22 +976,19 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds
         const int k = tid & 127, h = tid >> 7, nb = Kp / 16;
         double acc = 0.0;
         if (gram_lds) {
-            constexpr int NBLK = 36;
-            double v[NBLK];
+            if (st && tid == 0) st[9] = clock64();
+            // (block by block: the block index and whether it is read transposed are the same for the 16 columns of a block, the
+            // inner loop is 16 multiply-adds on a fixed stride; the terms are added in the same order as before -- j ascending)
+            const int I = k >> 4, ki = k & 15;
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) v[b] = q.gram_red[b * 256 + tid];
+            for (int Jq = 0; Jq < 4; ++Jq) {
+                const int J = 4 * h + Jq;
+                const int lo = I < J ? I : J, hi = I < J ? J : I;
+                const int b = lo * nb - (lo * (lo - 1)) / 2 + (hi - lo);
+                const double* gp = gram_lds + b * (16 * SELECT_GRAM_PITCH) + (I <= J ? ki * SELECT_GRAM_PITCH : ki);
+                const int stride = I <= J ? 1 : SELECT_GRAM_PITCH;
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) gram_lds[b * (16 * SELECT_GRAM_PITCH) + (tid >> 4) * SELECT_GRAM_PITCH + (tid & 15)] = v[b];
-            __syncthreads();
-            for (int j = h * 64; j < h * 64 + 64; ++j) {
-                int ki = k, kj = j;
-                if (ki > kj) {
-                    ki = j;
-                    kj = k;
-                }
-                const int I = ki >> 4, J = kj >> 4;
-                const int b = I * nb - (I * (I - 1)) / 2 + (J - I);
-                acc = fma(s_c[j], gram_lds[b * (16 * SELECT_GRAM_PITCH) + (ki & 15) * SELECT_GRAM_PITCH + (kj & 15)], acc);
+                for (int kj = 0; kj < 16; ++kj) acc = fma(s_c[16 * J + kj], gp[kj * stride], acc);
             }
         } else {
 #pragma unroll 8
@@ -984,16 +998,55 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds
         __syncthreads();
         if (h == 0) acc += s_half[k];
         if (swap) raw0 = acc; else raw1 = acc;
+        if (st && tid == 0) st[10] = clock64();
     }
     const double ps0 = raw0 * m0;
     const double ps1 = raw1 * m1;
-    const double fo = in ? q.f[tid] : 0.0, fs = in ? q.cand[tid] : 0.0, fn = in ? q.cand[Kp + tid] : 0.0;
-    const double lnk = in ? q.lnNk[tid] : 0.0;
     const double ga = sampled ? ps0 - nk : 0.0, gb = sampled ? ps1 - nk : 0.0;
-    const double gs = block256_sum(ga * ga, red);
-    const double gn = block256_sum(gb * gb, red);
+    // convergence measures over the sampled states except the gauge state (:627-633); NaN: see the host loop.  They depend on the
+    // choice through f_new, so both variants go through the ONE exchange that also carries the two gradient norms (five block
+    // reductions one after the other were ~6 k clocks of butterflies and barriers): sums in the order of block256_sum, maxima.
+    const bool counts = sampled && tid != first;
+    const double small = tol < 1e-8 ? tol : 1e-8;
+    double rv[8];
+    rv[0] = ga * ga;
+    rv[1] = gb * gb;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+        const double fc = c2 == 0 ? fs : fn;
+        const double div = fabs(fc) < small ? 1.0 : fabs(fc);
+        const double d1 = counts ? fabs(fc - fo) / div : 0.0;
+        const double d2 = counts ? fabs(fs - fn) / div : 0.0;
+        rv[2 + 3 * c2] = (d1 != d1) ? 1.0 : 0.0;
+        rv[3 + 3 * c2] = d1 != d1 ? 0.0 : d1;
+        rv[4 + 3 * c2] = d2 != d2 ? 0.0 : d2;
+    }
+    auto butterfly = [&](auto mtag) {
+        constexpr int m = decltype(mtag)::value;
+        double o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = lane_xor<m>(rv[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rv[i] = i < 2 ? rv[i] + o[i] : fmax(rv[i], o[i]);
+    };
+    butterfly(std::integral_constant<int, 32>());
+    butterfly(std::integral_constant<int, 16>());
+    butterfly(std::integral_constant<int, 8>());
+    butterfly(std::integral_constant<int, 4>());
+    butterfly(std::integral_constant<int, 2>());
+    butterfly(std::integral_constant<int, 1>());
+    __shared__ double red8[4][8];
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red8[tid >> 6][i] = rv[i];
+    }
+    __syncthreads();
+    const double gs = (red8[0][0] + red8[1][0]) + (red8[2][0] + red8[3][0]);
+    const double gn = (red8[0][1] + red8[1][1]) + (red8[2][1] + red8[3][1]);
+    if (st && tid == 0) st[11] = clock64();
     // :607 (every thread holds the same sums); a NaN Newton gradient loses against a finite self-consistent one (host loop)
-    const int ch = (gs < gn || (gn != gn && gs == gs) || ctl[CTL_SCI] < min_sc) ? 0 : 1;
+    const int ch = (gs < gn || (gn != gn && gs == gs) || sci_w < min_sc) ? 0 : 1;
     const double fnew = ch == 0 ? fs : fn;
     if (in) {
         q.f[tid] = fnew;
@@ -1001,16 +1054,12 @@ __device__ __forceinline__ void select_body(const AdaptArgs& q, double* gram_lds
         q.anum[tid] = sampled ? fnew + lnk : -INFINITY;
         if (q.pmode) q.ccur[tid] = ch == 0 ? m0 : m1;
     }
-    // convergence measures over the sampled states except the gauge state (:627-633); NaN: see the host loop
-    const bool counts = sampled && tid != first;
-    const double small = tol < 1e-8 ? tol : 1e-8;
-    const double div = fabs(fnew) < small ? 1.0 : fabs(fnew);
-    const double d1 = counts ? fabs(fnew - fo) / div : 0.0;
-    const double d2 = counts ? fabs(fs - fn) / div : 0.0;
-    const double nan_seen = block256_max((d1 != d1) ? 1.0 : 0.0, red);
-    double max_delta = block256_max(d1 != d1 ? 0.0 : d1, red);
-    const double max_diff = block256_max(d2 != d2 ? 0.0 : d2, red);
+    const int ro = 2 + 3 * ch;
+    const double nan_seen = fmax(fmax(red8[0][ro], red8[1][ro]), fmax(red8[2][ro], red8[3][ro]));
+    double max_delta = fmax(fmax(red8[0][ro + 1], red8[1][ro + 1]), fmax(red8[2][ro + 1], red8[3][ro + 1]));
+    const double max_diff = fmax(fmax(red8[0][ro + 2], red8[1][ro + 2]), fmax(red8[2][ro + 2], red8[3][ro + 2]));
     if (nan_seen > 0.0) max_delta = NAN;
+    if (st && tid == 0) st[12] = clock64();
     // Fused sweep: the Gram matrix of the Newton-Raphson candidate is already there.  It serves the next iteration when
     // that candidate was accepted -- or when the two candidates coincide to 1e-10 (at the fixed point the choice is
     // round-off noise; the Hessian of one is the Hessian of the other far below any tolerance it is used at).
@@ -1105,7 +1154,7 @@ __device__ __forceinline__ void ldlt_rank16(v4d& acc, const v4d& a, const v4d& b
 
 template <int NB>  // block rows the instantiation has registers for: 4 (up to 64 states) or 8 (up to 128)
 __device__ __forceinline__ void newton_body_ldlt(const AdaptArgs& q, double* ws, const double* gram_lds, long long* st = nullptr) {  // 256 threads
-    __shared__ double s_f[128], s_ps[128], s_nk[128], s_ln[128], s_cc[128], s_a0[128], s_b[128], s_dg[128], s_x[128], s_pv[128];
+    __shared__ double s_f[128], s_ps[128], s_nk[128], s_ln[128], s_cl[128], s_a0[128], s_b[128], s_dg[128], s_x[128], s_pv[128];
     __shared__ int s_live[128], s_first[1], s_pos[128];
     __shared__ double s_pmax[4];
     if (q.ctl[CTL_DONE] != 0) return;
@@ -1125,7 +1174,8 @@ __device__ __forceinline__ void newton_body_ldlt(const AdaptArgs& q, double* ws,
         s_ps[k] = ps;
         s_nk[k] = nk;
         s_ln[k] = in ? q.lnNk[k] : 0.0;
-        s_cc[k] = (in && q.pmode) ? (q.fused ? q.cgram[k] : q.ccur[k]) : 1.0;  // the multipliers the Gram sweep left out
+        const double cc = (in && q.pmode) ? (q.fused ? q.cgram[k] : q.ccur[k]) : 1.0;  // the multipliers the Gram sweep left out
+        s_cl[k] = live ? cc : 0.0;
         s_a0[k] = (in && q.pmode) ? q.a0[k] : 0.0;
         s_live[k] = live ? 1 : 0;
         s_b[k] = live ? ps - nk : 0.0;   // g (:284-292), the ride-along row
@@ -1146,19 +1196,26 @@ __device__ __forceinline__ void newton_body_ldlt(const AdaptArgs& q, double* ws,
     auto load_block = [&](int i, int j) -> v4d {  // (i <= j < nb, wave-uniform)
         const int b = i * nb - (i * (i - 1)) / 2 + (j - i);
         const int kr = 16 * i + R;
-        const bool lr = s_live[kr] != 0;
-        const double ncr = -s_cc[kr];
+        const double ncr = -s_cl[kr];  // (zero for a row that is not live: the product below then is the zero of an identity row)
         v4d a;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int c = 4 * t + G, kc = 16 * j + c;
             const double gv = gram_lds ? gram_lds[b * (16 * SELECT_GRAM_PITCH) + R * SELECT_GRAM_PITCH + c] : q.gram_red[b * 256 + R * 16 + c];
-            const bool lc = s_live[kc] != 0;
-            double v = (lr && lc) ? ncr * s_cc[kc] * gv : 0.0;
-            if (i == j && R == c) v += s_dg[kr];
-            if (i == 0 && R == 0 && kc != 0) v = s_b[kc];  // row 0
-            if (j == 0 && c == 0 && kr != 0) v = s_b[kr];  // column 0 (block (0, 0) only)
-            a[t] = v;
+            a[t] = (ncr * s_cl[kc]) * gv;
+        }
+        if (i == j) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (R == 4 * t + G) a[t] += s_dg[kr];
+        }
+        if (i == 0) {  // row 0 (and column 0 of block (0, 0)): the right-hand side
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = 4 * t + G, kc = 16 * j + c;
+                if (R == 0 && kc != 0) a[t] = s_b[kc];
+                if (j == 0 && c == 0 && R != 0) a[t] = s_b[kr];
+            }
         }
         return a;
     };
@@ -1187,6 +1244,8 @@ __device__ __forceinline__ void newton_body_ldlt(const AdaptArgs& q, double* ws,
 #pragma unroll
     for (int kb = NB - 1; kb >= 0; --kb) {
         if (kb < nb) {
+            long long tk0 = 0;
+            if (st && tid == 0) tk0 = clock64();
             v4d D = ldlt_read_block(ws + LDLT_DN_OFF, lane);
             const int i0 = (wave - kb) & 3, i1 = 4 + i0;  // this wave's panel blocks of the block column
             const bool ok0 = i0 < kb, ok1 = i1 < kb;
@@ -1195,22 +1254,27 @@ __device__ __forceinline__ void newton_body_ldlt(const AdaptArgs& q, double* ws,
             for (int p = 15; p >= (kb == 0 ? 1 : 0); --p) {
                 const int t = p >> 2, g = p & 3;
                 const double d = readlane_f64(D[t], 16 * g + p);
-                if (tid == 0) s_pv[16 * kb + p] = d;
                 const double nr = -recip_fast(d);
                 const bool gs = G == g;
-                const double X = (gs && R < p) ? D[t] : 0.0;  // the pivot row, left of the pivot
-                D = __builtin_amdgcn_mfma_f64_16x16x4f64(X, X * nr, D, 0, 0, 0);
-                if (kb > 0) {
-                    if (ok0) {
-                        const double Y = gs ? Pn[kb > 0 ? kb - 1 : 0][0][t] * nr : 0.0;  // column p of the panel block over the pivot
-                        Pn[kb > 0 ? kb - 1 : 0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(X, Y, Pn[kb > 0 ? kb - 1 : 0][0], 0, 0, 0);
-                    }
-                    if (ok1) {
-                        const double Y = gs ? Pn[kb > 0 ? kb - 1 : 0][1][t] * nr : 0.0;
-                        Pn[kb > 0 ? kb - 1 : 0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(X, Y, Pn[kb > 0 ? kb - 1 : 0][1], 0, 0, 0);
-                    }
+                const double X = (gs && R < p) ? D[t] : 0.0;  // the pivot row, left of the pivot; zero in the other lane groups,
+                const double Xn = X * nr;                     // which is what confines the rank-1 products to K index g
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(X, Xn, D, 0, 0, 0);
+                if (kb > 0) {  // (register t of a panel block over the pivot: its lane group g is column p)
+                    if (ok0) Pn[kb > 0 ? kb - 1 : 0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xn, Pn[kb > 0 ? kb - 1 : 0][0][t], Pn[kb > 0 ? kb - 1 : 0][0], 0, 0, 0);
+                    if (ok1) Pn[kb > 0 ? kb - 1 : 0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xn, Pn[kb > 0 ? kb - 1 : 0][1][t], Pn[kb > 0 ? kb - 1 : 0][1], 0, 0, 0);
                 }
                 RV[t] = gs ? nr : RV[t];
+            }
+            if (st && tid == 0) {
+                const long long tk1 = clock64();
+                st[6] += tk1 - tk0;
+                tk0 = tk1;
+            }
+            // the pivots: the diagonal of the block (entry [p][p] is final once pivot p + 1 is done)
+            if (wave == (kb & 3)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (R == 4 * t + G) s_pv[16 * kb + R] = D[t];
             }
             // the frozen block column: V (this block column's updates only) and W = -V / d (kept for the substitution)
             if (kb > 0) {
@@ -1255,45 +1319,54 @@ __device__ __forceinline__ void newton_body_ldlt(const AdaptArgs& q, double* ws,
                 }
                 __syncthreads();
             }
+            if (st && tid == 0) st[7] += clock64() - tk0;
         }
     }
     if (st && tid == 0) st[3] = clock64();
 
-    // ---- x_P = sum_{r < P} W[r][P] x_r with x_0 = -1: thread P; a diagonal block is 16 sequential steps of its 16 lanes
-    {
-        __syncthreads();  // (the last diagonal block of W)
-        const int P = tid & 127, kbP = P >> 4, p = P & 15;
-        double wd[16];
+    // ---- x_P = sum_{r < P} W[r][P] x_r with x_0 = -1.  Wave w holds the unknowns of block rows 4 w .. 4 w + 3, one per lane;
+    // a source block b is 16 sequential steps in which x_r leaves lane (b, r) through v_readlane and EVERY lane of the wave adds its
+    // own weight times it -- the triangle of the block itself for the lanes of group b (zero from the diagonal on), the panel block
+    // over (b, G) for the groups after it, zero before it -- so the four blocks of a wave need no barrier among themselves.
+    __syncthreads();  // (the last diagonal block of W)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wd[r] = ws[LDLT_DW_OFF + kbP * LDLT_BLK + (p >> 2) * 64 + 16 * (p & 3) + r];  // zero for r >= p
-        double accx = 0.0;
+    for (int w2 = 0; w2 < (NB + 3) / 4; ++w2) {
+        if (wave == w2 && 4 * w2 < nb) {
+            const int kbP = 4 * w2 + G;
+            const int off = (R >> 2) * 64 + 16 * (R & 3);  // the 16 weights of unknown p = R within a block: register R >> 2, lane group R & 3
+            double wt[4][16];
 #pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-            if (kb < nb) {
-                if (wave == (kb >> 2)) {
-                    if (G == (kb & 3)) {
-                        double xv = (kb == 0 && R == 0) ? -1.0 : accx;
+            for (int b = 0; b < 4; ++b) {
+                const int kb = 4 * w2 + b;
+                const double* wp = G == b ? ws + LDLT_DW_OFF + kb * LDLT_BLK + off : ws + LDLT_W_OFF + (kbP * (kbP - 1) / 2 + kb) * LDLT_BLK + off;
 #pragma unroll
-                        for (int r = 0; r < 15; ++r) xv = fma(wd[r], readlane_f64(xv, 16 * (kb & 3) + r), xv);
-                        s_x[16 * kb + R] = xv;
-                    }
-                }
-                __syncthreads();
-                if (tid < 128 && kbP > kb && kbP < nb) {
-                    const double* wp = ws + LDLT_W_OFF + (kbP * (kbP - 1) / 2 + kb) * LDLT_BLK + (p >> 2) * 64 + 16 * (p & 3);
+                for (int r = 0; r < 16; ++r) wt[b][r] = (G >= b && kbP < nb) ? wp[r] : 0.0;  // (block rows from nb on: LDS nobody wrote)
+            }
+            double xv = (w2 == 0 && lane == 0) ? -1.0 : 0.0;
+            if (kbP < nb) {
+                for (int kb = 0; kb < 4 * w2; ++kb) {  // the block rows of the waves before this one
+                    const double* wp = ws + LDLT_W_OFF + (kbP * (kbP - 1) / 2 + kb) * LDLT_BLK + off;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) accx = fma(wp[r], s_x[16 * kb + r], accx);
+                    for (int r = 0; r < 16; ++r) xv = fma(wp[r], s_x[16 * kb + r], xv);
                 }
             }
-        }
-        __syncthreads();
-        // the gauge component (and the ride-along -1 of row 0) are zero in the direction
-        if (tid == 0) {
-            s_x[0] = 0.0;
-            s_x[first] = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (4 * w2 + b < nb) {  // (a source block past the last one would feed whatever its lanes hold into 0 * x)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xv = fma(wt[b][r], readlane_f64(xv, 16 * b + r), xv);
+                }
+            }
+            s_x[64 * w2 + lane] = xv;
         }
         __syncthreads();
     }
+    // the gauge component (and the ride-along -1 of row 0) are zero in the direction
+    if (tid == 0) {
+        s_x[0] = 0.0;
+        s_x[first] = 0.0;
+    }
+    __syncthreads();
     bool bad = false;
     if (tid < 128 && tid < q.Kp && s_live[tid]) {
         const double pvv = s_pv[tid];
@@ -1318,7 +1391,7 @@ template <int R>
 __global__ void __launch_bounds__(256)
 k_select_newton(AdaptArgs q, int gram_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
-    long long* st = q.stamps ? q.stamps + 8 * (q.ctl[CTL_ITER] & 63) : nullptr;  // (debug: one slot per iteration)
+    long long* st = q.stamps ? q.stamps + 16 * (q.ctl[CTL_ITER] & 63) : nullptr;  // (debug: one slot per iteration)
     if (st && threadIdx.x == 0) st[0] = clock64();
     select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
     __syncthreads();
@@ -1330,9 +1403,9 @@ template <int NB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_select_newton_ldlt(AdaptArgs q, int gram_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double select_dyn_lds[];
-    long long* st = q.stamps ? q.stamps + 8 * (q.ctl[CTL_ITER] & 63) : nullptr;  // (debug: one slot per iteration)
+    long long* st = q.stamps ? q.stamps + 16 * (q.ctl[CTL_ITER] & 63) : nullptr;  // (debug: one slot per iteration)
     if (st && threadIdx.x == 0) st[0] = clock64();
-    select_body(q, gram_in_lds ? select_dyn_lds : nullptr);
+    select_body(q, gram_in_lds ? select_dyn_lds : nullptr, st);
     __syncthreads();
     if (st && threadIdx.x == 0) st[1] = clock64();
     newton_body_ldlt<NB>(q, select_dyn_lds, gram_in_lds ? select_dyn_lds : nullptr, st);

@@ -637,8 +637,8 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     if (const char* e = std::getenv("MBAR_NEWTON_LDLT")) q.newton_ldlt = std::atoi(e) != 0 ? 1 : 0;
     q.stamps = nullptr;
     if (std::getenv("MBAR_DEBUG_STAMPS")) {
-        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 65 * 8 * sizeof(long long)));
-        HIPCHK(c, hipMemsetAsync(c->stamps, 0, 65 * 8 * sizeof(long long), c->stream));
+        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 65 * 16 * sizeof(long long)));
+        HIPCHK(c, hipMemsetAsync(c->stamps, 0, 65 * 16 * sizeof(long long), c->stream));
         q.stamps = c->stamps;
     }
 
@@ -885,13 +885,14 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
         if (it > res.iterations) max_delta = h[ad_off_state(c)];
     }
     if (q.stamps) {
-        std::vector<long long> st(65 * 8);
+        std::vector<long long> st(65 * 16);
         HIPCHK(c, hipMemcpy(st.data(), c->stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) {
-            const long long* p = st.data() + 8 * i;
+            const long long* p = st.data() + 16 * i;
             if (!p[0] || !p[5]) continue;
-            std::fprintf(stderr, "[mbar] k_select_newton launch %d (shader clocks): select %lld, set-up %lld, elimination %lld, solution %lld, candidates %lld, total %lld\n",
-                         i, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[5] - p[0]);
+            std::fprintf(stderr, "[mbar] k_select_newton launch %d (shader clocks): select %lld, set-up %lld, elimination %lld, solution %lld, candidates %lld, total %lld; of the elimination: pivot loops %lld, exchange + trailing update %lld; of the selection: inputs %lld, Gram staged %lld, matrix-vector product %lld, sums %lld, maxima %lld\n",
+                         i, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[5] - p[0], p[6], p[7], p[8] - p[0], p[9] - p[8], p[10] - p[9],
+                         p[11] - p[10], p[12] - p[11]);
         }
     }
     res.iterations = it;
@@ -1066,7 +1067,7 @@ int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, in
     int64_t it = 0;  // iterations accepted so far
     long long* sci_stamps = nullptr;
     if (merged && std::getenv("MBAR_DEBUG_STAMPS")) {
-        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 65 * 8 * sizeof(long long)));
+        if (!c->stamps) HIPCHK(c, hipMalloc((void**)&c->stamps, 65 * 16 * sizeof(long long)));
         HIPCHK(c, hipMemsetAsync(c->stamps, 0, 64 * 8 * sizeof(long long), c->stream));
         sci_stamps = c->stamps;
     }
