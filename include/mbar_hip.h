@@ -281,6 +281,30 @@ int mbar_w(mbar_ctx* ctx, const double* f, double* out_kn, int64_t ld_out);
  * mbar.py:1816,1849 and compute_overlap mbar.py:606); fp64 MFMA. */
 int mbar_gram_w(mbar_ctx* ctx, const double* f, double* gramW, double* wsum);
 
+/* ---- extension contexts: rows appended to a resident matrix without a copy of it ------------
+ * The general path of the expectation family (pymbar/mbar.py:886-903 builds an N x (K + NL + S) host array of log weights;
+ * rounds 3-5 of this library copied the resident matrix device to device into a (K + NL + S)-row one per call).  An extension
+ * context holds ONLY the new rows (new states, observables as unsampled states) -- same device, samples and row pitch as `base`,
+ * its storage a whole number of row pitches away from base's -- and the sweeps below read [rows of base | rows of ext]:
+ *   mbar_ctx_create_ext      base of at most 128 states on one rank, 129 .. 256 rows in total (else MBAR_ERR_ARG: the caller
+ *                            falls back to an augmented copy); rows are written with mbar_ctx_upload_rows / mbar_ctx_copy_rows /
+ *                            mbar_ctx_rows_logshift / mbar_ctx_vec_logshift on the extension and the three calls below;
+ *   mbar_ctx_rows_sub_from   dst rows = src rows - v  (src = dst or its base; v as in mbar_ctx_rows_sub);
+ *   mbar_ctx_rows_rsub_from  dst rows = src rows - dst rows;
+ *   mbar_ctx_rows_obs_from   dst rows = base rows[state_row0 ..) - log(base rows[obs_row0 ..) - shift_r), shift_r as in
+ *                            mbar_ctx_rows_logshift, handed back (observables that ARE resident rows: entropy / enthalpy);
+ *   mbar_lognum_ext          log normalisers of the extension's rows at f_base (the base's log-denominators / multiplicities);
+ *   mbar_gram_w_ext          W^T W of [base | ext] at (f_base, f_ext), (K_base + K_ext)^2 row-major, ONE one-read sweep of both
+ *                            matrices (k_gram_quad_split); wsum as in mbar_gram_w (N_k = 0 for the extension's rows).
+ * Evaluations and solves on an extension context fail with MBAR_ERR_STATE; destroy it before its base. */
+int mbar_ctx_create_ext(mbar_ctx** out, mbar_ctx* base, int64_t K_rows);
+int mbar_ctx_rows_sub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows, const double* v_host);
+int mbar_ctx_rows_rsub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows);
+int mbar_ctx_rows_obs_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* base, int64_t state_row0, int64_t obs_row0, int64_t nrows,
+                           double* shift_out);
+int mbar_lognum_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, double* lognum_ext);
+int mbar_gram_w_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, const double* f_ext, double* gramW, double* wsum);
+
 /* ---- solver loops (replace adaptive(), mbar_solvers.py:510-667) ---------------------------- */
 typedef struct mbar_solve_result {
     int64_t iterations; /* iterations executed                                   */

@@ -491,6 +491,7 @@ int64_t lse_rows(const mbar_ctx* c) { return c->Kp; }
 // Core of mbar_eval: f points to nf*K doubles on the host.  Leaves logden in ld0/ld1.
 int eval_core(mbar_ctx* c, const double* f, int nf, unsigned flags, double* ld0, double* ld1, double* psum,
               double* sumlogden, double* gram) {
+    if (c && c->ext_base) return fail(c, MBAR_ERR_STATE, "evaluation: an extension context holds rows only (mbar_lognum_ext / mbar_gram_w_ext sweep them)");
     if (!c->have_Nk) return fail(c, MBAR_ERR_STATE, "mbar_ctx_set_Nk has not been called");
     if (nf < 1 || nf > 2) return fail(c, MBAR_ERR_ARG, "nf must be 1 or 2");
     const bool want_gram = (flags & MBAR_EVAL_GRAM) != 0;
@@ -732,7 +733,8 @@ void mbar_ctx_destroy(mbar_ctx* c) {
     flush_timers(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->u) (void)cache_free(c->u);
+    if (c->u_alloc) (void)cache_free(c->u_alloc);
+    else if (c->u) (void)cache_free(c->u);
     if (c->logden[0]) (void)cache_free(c->logden[0]);
     if (c->ad) (void)cache_free(c->ad);
     if (c->P) (void)cache_free(c->P);
@@ -1054,6 +1056,7 @@ int mbar_ctx_set_Nk(mbar_ctx* c, const double* N_k) {
 }
 
 int mbar_ctx_set_sample_weights(mbar_ctx* c, const double* c_n) {
+    if (c && c->ext_base) return fail(c, MBAR_ERR_STATE, "mbar_ctx_set_sample_weights: an extension context holds rows only (mbar_lognum_ext / mbar_gram_w_ext sweep them)");
     if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
     bool weighted = false;
@@ -1131,6 +1134,7 @@ int mbar_ctx_set_bootstrap_layout(mbar_ctx* c, const int64_t* cumN, int64_t K_st
 
 int mbar_ctx_draw_bootstrap_weights(mbar_ctx* c, uint64_t seed, int64_t replicate, const int64_t* cumN, int64_t K_states,
                                     const int64_t* order, int64_t n_global0) {
+    if (c && c->ext_base) return fail(c, MBAR_ERR_STATE, "mbar_ctx_draw_bootstrap_weights: an extension context holds rows only (mbar_lognum_ext / mbar_gram_w_ext sweep them)");
     if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
     if (replicate < 0 || n_global0 < 0) return fail(c, MBAR_ERR_ARG, "mbar_ctx_draw_bootstrap_weights: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1178,6 +1182,7 @@ int mbar_ctx_draw_bootstrap_weights(mbar_ctx* c, uint64_t seed, int64_t replicat
 }
 
 int mbar_ctx_weights_from_vec(mbar_ctx* c, double power) {
+    if (c && c->ext_base) return fail(c, MBAR_ERR_STATE, "mbar_ctx_weights_from_vec: an extension context holds rows only (mbar_lognum_ext / mbar_gram_w_ext sweep them)");
     if (!c) return fail(c, MBAR_ERR_ARG, "NULL argument");
     if (!c->vec_tmp || !c->vec_holds_logshift)
         return fail(c, MBAR_ERR_STATE, "mbar_ctx_weights_from_vec: no observable in the staging vector (mbar_ctx_vec_logshift first; "
@@ -1365,6 +1370,259 @@ int mbar_gram_w(mbar_ctx* c, const double* f, double* gramW, double* wsum) {
     std::fill(G, G + (size_t)c->K * c->K, 0.0);
     unpack_gram(plan, c->hred, c->K, G);
     if (wsum) gram_operand_sums(G, c->K, c->Nk.data(), wsum);  // sum_n W_nj = sum_k N_k (W^T W)_kj
+    return MBAR_OK;
+}
+
+// ---- extension contexts: rows appended to a resident matrix WITHOUT a copy of it (the general path of the expectation family,
+// pymbar/mbar.py:886-903 builds an N x (K + NL + S) host array there) -------------------------------------------------------------
+// The extension holds only the new rows -- same device, N_local and row pitch as `base` -- and its storage starts a whole number
+// of row pitches away from base's, so that a one-read sweep addresses [rows of base | rows of ext] as ONE 192- / 256-row panel
+// (k_gram_quad_split).  K_rows real rows; the allocated rows make 16 ceil(base K / 16) + rows = 192 or 256.
+int mbar_ctx_create_ext(mbar_ctx** out, mbar_ctx* base, int64_t K_rows) {
+    if (!out) return fail(nullptr, MBAR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!base || K_rows < 1) return fail(base, MBAR_ERR_ARG, "mbar_ctx_create_ext: base context and K_rows >= 1");
+    if (base->ext_base) return fail(base, MBAR_ERR_ARG, "mbar_ctx_create_ext: the base is an extension itself");
+    const int64_t need = base->Kp + (K_rows + 15) / 16 * 16;
+    if (base->Kp > 128 || need <= 128 || need > 256 || base->nranks > 1 || wide_pitch(base) || !use_fast(base) || !base->opt_quad)
+        return fail(base, MBAR_ERR_ARG, "mbar_ctx_create_ext: needs a base of at most 128 states on one rank and 129 .. 256 rows in total");
+    const int64_t Kp_ext = (need <= 192 ? 192 : 256) - base->Kp;
+    mbar_ctx* c = new mbar_ctx();
+    g_live_contexts.fetch_add(1);
+    c->device = base->device;
+    c->K = K_rows;
+    c->Kp = Kp_ext;
+    c->N = base->N;
+    c->ld = base->ld;
+    c->num_cu = base->num_cu;
+    c->ext_base = base;
+#define CRT(expr)                                                                                   \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            int rc_ = fail(nullptr, MBAR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+            mbar_ctx_destroy(c);                                                                    \
+            return rc_;                                                                             \
+        }                                                                                           \
+    } while (0)
+    CRT(hipSetDevice(c->device));
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        auto& pool = g_stream_pool[c->device];
+        if (!pool.empty()) {
+            c->stream = pool.back();
+            pool.pop_back();
+        }
+    }
+    if (!c->stream) CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t pitch = (size_t)c->ld * sizeof(double);
+    const size_t ubytes = (size_t)c->Kp * pitch;
+    CRT(cache_malloc((void**)&c->u_alloc, ubytes + pitch));
+    {   // first address of the allocation that is congruent to base->u modulo the row pitch
+        const uintptr_t a = reinterpret_cast<uintptr_t>(c->u_alloc), b = reinterpret_cast<uintptr_t>(base->u);
+        const uintptr_t r = a >= b ? (a - b) % pitch : (pitch - (b - a) % pitch) % pitch;
+        c->u = reinterpret_cast<double*>(a + (r == 0 ? 0 : pitch - r));
+    }
+    // (only what no row operation writes is zeroed -- the padding rows and the padding columns behind N_local: the K_rows real rows
+    // are whole-row uploads, copies or kernel outputs of the caller before the first sweep; zeroing 128 rows x 4e6 samples was
+    // 0.8 ms of a 20 ms call)
+    if (c->Kp > c->K) CRT(launch_zero(c->stream, c->u + (size_t)c->K * c->ld, (size_t)(c->Kp - c->K) * pitch));
+    if (c->ld > c->N)
+        CRT(hipMemset2DAsync(c->u + c->N, pitch, 0, (size_t)(c->ld - c->N) * sizeof(double), (size_t)c->K, c->stream));
+    CRT(cache_malloc((void**)&c->logden[0], (size_t)3 * 16 * sizeof(double)));  // (never swept on its own: the log-denominators are the base's)
+    c->logden[1] = c->logden[2] = c->logden[0];
+    CRT(cache_malloc((void**)&c->small, small_doubles(256) * sizeof(double)));
+    CRT(cache_host_malloc((void**)&c->hstage, (size_t)4 * 256 * sizeof(double)));
+    CRT(hipMemsetAsync(c->small, 0, small_doubles(256) * sizeof(double), c->stream));
+    CRT(hipStreamSynchronize(c->stream));
+#undef CRT
+    c->Nk.assign(K_rows, 0.0);
+    c->lnNk.assign(K_rows, 0.0);
+    *out = c;
+    return MBAR_OK;
+}
+
+static int ext_pair_ok(mbar_ctx* ext, mbar_ctx* base, const char* who) {
+    if (!ext || !base) return fail(ext, MBAR_ERR_ARG, std::string(who) + ": NULL context");
+    if (ext->ext_base != base) return fail(ext, MBAR_ERR_ARG, std::string(who) + ": the first context is not an extension of the second");
+    return MBAR_OK;
+}
+static void ext_touched(mbar_ctx* c) {
+    c->u_checked = false;
+    c->P_valid = false;
+    c->last_psum.clear();
+}
+
+// dst rows = src rows - v (v_host, or NULL: the vector staged in dst by the previous call / mbar_ctx_vec_logshift); src is dst or its base
+int mbar_ctx_rows_sub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows, const double* v_host) {
+    if (!dst || !src) return fail(dst, MBAR_ERR_ARG, "NULL argument");
+    if (src != dst && dst->ext_base != src) return fail(dst, MBAR_ERR_ARG, "mbar_ctx_rows_sub_from: src must be dst or its base");
+    if (nrows < 0 || dst_row0 < 0 || src_row0 < 0 || dst_row0 + nrows > dst->K || src_row0 + nrows > src->K)
+        return fail(dst, MBAR_ERR_ARG, "row range out of bounds");
+    if (src == dst && dst_row0 != src_row0 && dst_row0 < src_row0 + nrows && src_row0 < dst_row0 + nrows)
+        return fail(dst, MBAR_ERR_ARG, "mbar_ctx_rows_sub_from: the row ranges overlap");
+    if (!v_host && !dst->vec_tmp) return fail(dst, MBAR_ERR_STATE, "mbar_ctx_rows_sub_from: no vector has been uploaded yet");
+    if (nrows == 0) return MBAR_OK;
+    HIPCHK(dst, hipSetDevice(dst->device));
+    if (src != dst) HIPCHK(dst, hipStreamSynchronize(src->stream));
+    if (!dst->vec_tmp) HIPCHK(dst, cache_malloc((void**)&dst->vec_tmp, (size_t)dst->ld * sizeof(double)));
+    if (v_host) {
+        dst->vec_holds_logshift = false;
+        HIPCHK(dst, hipMemcpyAsync(dst->vec_tmp, v_host, (size_t)dst->N * sizeof(double), hipMemcpyHostToDevice, dst->stream));
+    }
+    HIPCHK(dst, launch_rows_sub(dst->stream, dst->u + dst_row0 * dst->ld, src->u + src_row0 * src->ld, dst->ld, nrows, dst->vec_tmp, dst->N));
+    ext_touched(dst);
+    return sync_stream(dst);
+}
+
+// dst rows = src rows - dst rows
+int mbar_ctx_rows_rsub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows) {
+    if (!dst || !src) return fail(dst, MBAR_ERR_ARG, "NULL argument");
+    if (src != dst && dst->ext_base != src) return fail(dst, MBAR_ERR_ARG, "mbar_ctx_rows_rsub_from: src must be dst or its base");
+    if (nrows < 0 || dst_row0 < 0 || src_row0 < 0 || dst_row0 + nrows > dst->K || src_row0 + nrows > src->K)
+        return fail(dst, MBAR_ERR_ARG, "row range out of bounds");
+    if (src == dst && dst_row0 < src_row0 + nrows && src_row0 < dst_row0 + nrows)
+        return fail(dst, MBAR_ERR_ARG, "mbar_ctx_rows_rsub_from: the row ranges overlap");
+    if (nrows == 0) return MBAR_OK;
+    HIPCHK(dst, hipSetDevice(dst->device));
+    if (src != dst) HIPCHK(dst, hipStreamSynchronize(src->stream));
+    HIPCHK(dst, launch_rows_rsub(dst->stream, dst->u + dst_row0 * dst->ld, src->u + src_row0 * src->ld, dst->ld, nrows, dst->N));
+    ext_touched(dst);
+    return sync_stream(dst);
+}
+
+// dst rows = base rows [state_row0 ..) - log(base rows [obs_row0 ..) - shift_r), shift_r = min_r - |4 eps min_r| (mbar.py:827-832)
+// handed back: observables that ARE rows of the resident matrix (entropy / enthalpy: the reduced potentials), each at its own
+// state, in one read of the rows concerned -- no copy of them, no pass in place
+int mbar_ctx_rows_obs_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* base, int64_t state_row0, int64_t obs_row0, int64_t nrows,
+                           double* shift_out) {
+    int rc = ext_pair_ok(dst, base, "mbar_ctx_rows_obs_from");
+    if (rc) return rc;
+    if (!shift_out) return fail(dst, MBAR_ERR_ARG, "NULL argument");
+    if (nrows < 0 || dst_row0 < 0 || state_row0 < 0 || obs_row0 < 0 || dst_row0 + nrows > dst->K || state_row0 + nrows > base->K ||
+        obs_row0 + nrows > base->K)
+        return fail(dst, MBAR_ERR_ARG, "row range out of bounds");
+    if (nrows == 0) return MBAR_OK;
+    HIPCHK(dst, hipSetDevice(dst->device));
+    HIPCHK(dst, hipStreamSynchronize(base->stream));
+    rc = ensure(dst, &dst->scratch, &dst->scratch_doubles, (size_t)nrows * 257);
+    if (rc) return rc;
+    double* shift_dev = dst->scratch + (size_t)nrows * 256;
+    HIPCHK(dst, launch_rows_obs(dst->stream, dst->u + dst_row0 * dst->ld, base->u + obs_row0 * base->ld, base->u + state_row0 * base->ld,
+                                dst->ld, nrows, dst->N, dst->scratch, shift_dev));
+    HIPCHK(dst, hipMemcpyAsync(shift_out, shift_dev, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, dst->stream));
+    ext_touched(dst);
+    return sync_stream(dst);
+}
+
+// Log normalisers of the extension's rows as unsampled states of the base's mixture at f_base (K_base entries):
+// lognum_ext[r] = log sum_n c_n exp(-row_rn - logden_n(f_base)) with the base's log-denominators and sample multiplicities.
+int mbar_lognum_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, double* lognum_ext) {
+    int rc = ext_pair_ok(ext, base, "mbar_lognum_ext");
+    if (rc) return rc;
+    if (!f_base || !lognum_ext) return fail(ext, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(ext, hipSetDevice(ext->device));
+    rc = eval_core(base, f_base, 1, 0, base->logden[0], nullptr, nullptr, nullptr, nullptr);
+    if (rc) return fail(ext, rc, std::string("mbar_lognum_ext: ") + mbar_last_error(base));
+    rc = refresh_poison(ext);
+    if (rc) return rc;
+    if (base->u_poison || ext->u_poison || !f_is_finite(base, f_base, 1)) {
+        std::fill(lognum_ext, lognum_ext + ext->K, std::numeric_limits<double>::quiet_NaN());
+        return MBAR_OK;
+    }
+    const int64_t nch = lognum_chunks(ext->N, ext->K);
+    rc = ensure(ext, &ext->lognum_part, &ext->lognum_part_doubles, (size_t)2 * ext->K * nch + 2 * ext->K);
+    if (rc) return rc;
+    double* pmax = ext->lognum_part;
+    double* psum = pmax + (size_t)ext->K * nch;
+    double* omax = psum + (size_t)ext->K * nch;
+    double* osum = omax + ext->K;
+    HIPCHK(ext, hipMemsetAsync(d_anum(ext), 0, (size_t)ext->Kp * sizeof(double), ext->stream));  // anum = 0
+    const double* lden = base->logden[0];
+    if (base->weighted) {  // log sum_n c_n exp(...) = log sum_n exp(... + ln c_n)
+        HIPCHK(ext, launch_shift_logden(ext->stream, base->logden[0], base->cw, 1.0, base->N, base->lden_eff));
+        lden = base->lden_eff;
+    }
+    {
+        ScopedTimer t(ext, MBAR_TIMER_OTHER);
+        HIPCHK(ext, launch_lognum(ext->stream, ext->u, ext->ld, ext->N, ext->K, d_anum(ext), lden, pmax, psum, nch));
+        HIPCHK(ext, launch_lognum_merge(ext->stream, pmax, psum, ext->K, nch, omax, osum));
+    }
+    std::vector<double> hm(ext->K), hs(ext->K);
+    HIPCHK(ext, hipMemcpyAsync(hm.data(), omax, ext->K * sizeof(double), hipMemcpyDeviceToHost, ext->stream));
+    HIPCHK(ext, hipMemcpyAsync(hs.data(), osum, ext->K * sizeof(double), hipMemcpyDeviceToHost, ext->stream));
+    rc = sync_stream(ext);
+    if (rc) return rc;
+    for (int64_t k = 0; k < ext->K; ++k) lognum_ext[k] = hm[k] + std::log(hs[k]);
+    return MBAR_OK;
+}
+
+// W^T W of the weight columns of [base rows | extension rows] at (f_base, f_ext): ONE one-read sweep over the two matrices
+// (gramW: (K_base + K_ext)^2 row-major; wsum as in mbar_gram_w, with N_k = 0 for the extension's rows).
+int mbar_gram_w_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, const double* f_ext, double* gramW, double* wsum) {
+    int rc = ext_pair_ok(ext, base, "mbar_gram_w_ext");
+    if (rc) return rc;
+    if (!f_base || !f_ext || !gramW) return fail(ext, MBAR_ERR_ARG, "NULL argument");
+    HIPCHK(ext, hipSetDevice(ext->device));
+    rc = eval_core(base, f_base, 1, 0, base->logden[0], nullptr, nullptr, nullptr, nullptr);
+    if (rc) return fail(ext, rc, std::string("mbar_gram_w_ext: ") + mbar_last_error(base));
+    rc = refresh_poison(ext);
+    if (rc) return rc;
+    const int64_t Kb = base->K, Ke = ext->K, Kt = Kb + Ke, rows = base->Kp + ext->Kp;
+    bool finite = f_is_finite(base, f_base, 1);
+    for (int64_t k = 0; k < Ke; ++k) finite = finite && std::isfinite(f_ext[k]);
+    if (base->u_poison || ext->u_poison || !finite) {
+        std::fill(gramW, gramW + (size_t)Kt * Kt, std::numeric_limits<double>::quiet_NaN());
+        if (wsum) std::fill(wsum, wsum + Kt, std::numeric_limits<double>::quiet_NaN());
+        return MBAR_OK;
+    }
+    const int nbt = (int)(rows / 16);
+    GramPlan plan = gram_plan(rows, true);
+    const size_t total = plan.total_blocks * 256;
+    rc = ensure_red(ext, total);
+    if (rc) return rc;
+    // operand constants of the joint panel: f_base, padding, f_ext, padding (-inf: a zero operand)
+    std::vector<double> an((size_t)rows, -std::numeric_limits<double>::infinity());
+    for (int64_t k = 0; k < Kb; ++k) an[k] = f_base[k];
+    for (int64_t k = 0; k < Ke; ++k) an[(size_t)base->Kp + k] = f_ext[k];
+    double* an_dev = ext->small;  // (small_doubles(256) of them)
+    HIPCHK(ext, hipMemcpyAsync(an_dev, an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, ext->stream));
+    const double* logden = base->logden[0];
+    if (base->weighted) {  // sum_n c_n p p^T: each operand carries sqrt(c_n), folded into the exponent
+        HIPCHK(ext, launch_shift_logden(ext->stream, logden, base->cw, 0.5, base->N, base->lden_eff));
+        logden = base->lden_eff;
+    }
+    const int64_t ntiles = (ext->N + TS - 1) / TS;
+    LaunchGeom g = gram_quad_geometry(nbt, ext->num_cu, ntiles, ext->opt_grid);
+    // (padding blocks at the END of the joint panel are left out of the sweep like quad_trim does for one matrix)
+    g.live_blocks = ext->opt_quad_trim ? (int)((base->Kp + Ke + 15) / 16) : 0;
+    const size_t rec = (size_t)plan.items[0].nblk * 256;
+    rc = ensure(ext, &ext->part, &ext->part_doubles, (size_t)g.nwaves * rec);
+    if (rc) return rc;
+    rc = ensure(ext, &ext->scratch, &ext->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * rec);
+    if (rc) return rc;
+    const int64_t row_j0 = (reinterpret_cast<intptr_t>(ext->u) - reinterpret_cast<intptr_t>(base->u)) / (intptr_t)((size_t)base->ld * sizeof(double));
+    {
+        ScopedTimer t(ext, MBAR_TIMER_GRAM);
+        HIPCHK(ext, launch_gram_quad_split(ext->stream, nbt, g, base->u, base->ld, base->N, an_dev, logden, ext->part, base->Kp, row_j0));
+    }
+    {
+        ScopedTimer t(ext, MBAR_TIMER_REDUCE);
+        HIPCHK(ext, launch_reduce(ext->stream, ext->part, g.nwaves, (int64_t)rec, ext->scratch, ext->red));
+    }
+    HIPCHK(ext, hipMemcpyAsync(ext->hred, ext->red, total * sizeof(double), hipMemcpyDeviceToHost, ext->stream));
+    rc = sync_stream(ext);
+    if (rc) return rc;
+    std::vector<double> Gp((size_t)rows * rows, 0.0);
+    unpack_gram(plan, ext->hred, rows, Gp.data());
+    auto src = [&](int64_t k) { return k < Kb ? k : base->Kp + (k - Kb); };
+    for (int64_t i = 0; i < Kt; ++i)
+        for (int64_t j = 0; j < Kt; ++j) gramW[(size_t)i * Kt + j] = Gp[(size_t)src(i) * rows + src(j)];
+    if (wsum) {
+        std::vector<double> Nk((size_t)Kt, 0.0);
+        for (int64_t k = 0; k < Kb; ++k) Nk[k] = base->Nk[k];
+        gram_operand_sums(gramW, Kt, Nk.data(), wsum);
+    }
     return MBAR_OK;
 }
 

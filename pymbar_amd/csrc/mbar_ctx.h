@@ -267,6 +267,8 @@ struct mbar_ctx {
     std::vector<int> sampled;       // indices with N_k > 0
     // device
     double* u = nullptr;
+    double* u_alloc = nullptr;  // extension contexts (mbar_ctx_create_ext): the allocation `u` points into
+    mbar_ctx* ext_base = nullptr;  // ... and the context whose rows theirs are appended to
     double* logden[3] = {nullptr, nullptr, nullptr};
     double* dn = nullptr;           // objective offsets (or null)
     double* cw = nullptr;           // per-sample multiplicities (ld doubles; 1 on data, 0 on padding by default)

@@ -116,6 +116,8 @@ hipError_t launch_lse(hipStream_t s, int nb, int nf, const LaunchGeom& g,
 LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, int64_t grid_override);
 hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n);  // row[i] -= v[i]
 hipError_t launch_rows_sub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, const double* v, int64_t n);
+hipError_t launch_rows_obs(hipStream_t s, double* dst, const double* obs, const double* state, int64_t ld, int64_t nrows, int64_t n,
+                           double* part, double* shift_out);
 hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n);
 // rows r < nrows of base (pitch ld, n valid entries): row <- log(row - shift_r), shift_r = min_r - |4 eps min_r| -> shift_out[r]
 // (device); part: scratch of 256 * nrows doubles
@@ -143,6 +145,8 @@ hipError_t launch_gram_rect(hipStream_t s, int nbi, const LaunchGeom& g, const d
 hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N,
                             const double* anum, const double* logden, double* gram_part, const LoopCtl& lc = LoopCtl(),
                             double* Pout = nullptr);
+hipError_t launch_gram_quad_split(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* anum,
+                                  const double* logden, double* gram_part, int64_t split_rows, int64_t row_j0);
 
 // ---- layout-agnostic fallbacks (any K) ---------------------------------------------------------
 // 257 .. 512 states in one read: nf = 2 evaluates a second candidate through the ratio row aden[rows + k] = exp(a'_k - a_k)

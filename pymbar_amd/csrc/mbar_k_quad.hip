@@ -61,10 +61,14 @@ __device__ __forceinline__ void quad_store_blocks(double* __restrict__ rec, cons
 // NBM <= NBT: blocks of 16 states that hold real states (a 160-state problem in the 192-row panel: 10 of 12).  The rows
 // beyond are padding: they are neither staged nor turned into operands, and their blocks are left out (55 matrix instructions
 // per k-step instead of 78) -- the record keeps the panel's layout, with zeros there.
-template <int NBT, int WV, bool WIDE, bool PMODE, bool STOREP = false, int NBM = NBT>
+// SPLIT: the panel's rows come from TWO matrices of one row pitch -- rows [0, split_rows) from `u`, the rest from row_j0 on, counted
+// in rows of `u` (an extension context's storage starts a whole number of row pitches away from its base matrix's:
+// mbar_ctx_create_ext) -- so that rows appended to a resident matrix are swept with it without a copy of it.
+template <int NBT, int WV, bool WIDE, bool PMODE, bool STOREP = false, int NBM = NBT, bool SPLIT = false>
 __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
                                                const double* __restrict__ anum, const double* __restrict__ logden,
-                                               double* __restrict__ gram_part, char* smem, int lane, double* __restrict__ Pout = nullptr) {
+                                               double* __restrict__ gram_part, char* smem, int lane, double* __restrict__ Pout = nullptr,
+                                               int64_t split_rows = 0, int64_t row_j0 = 0) {
     constexpr int ROWS = NBT * 16, NQ = NBT / 4, QDMA = ROWS / 4 / 8;
     constexpr int U_BYTES = ROWS * TS * 8;
     constexpr int TILE_BYTES = U_BYTES + 4 * 1024;  // + one copy of the tile's 16 logden values per wave (a 1 KB LDS-DMA piece each)
@@ -75,7 +79,7 @@ __device__ __forceinline__ void gram_quad_body(const double* __restrict__ u, int
     constexpr bool PINNED = true;
     const int ks = lane & 15, ns = lane >> 4;
     char* buf = smem + EXP_TABLE_BYTES;  // two tile buffers shared by the four waves
-    RowIdentity rows{0};
+    auto rows = [&](int tr) -> int64_t { return (SPLIT && tr >= split_rows) ? row_j0 + (tr - split_rows) : (int64_t)tr; };
     const StageOffsetsT<WIDE> so = make_stage_offsets<WIDE>(ld, lane);
     const int64_t G = gridDim.x;
 
@@ -268,6 +272,23 @@ k_gram_quad(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles,
         case 1: gram_quad_body<NBT, 1, WIDE, PMODE, STOREP, NBM>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
         case 2: gram_quad_body<NBT, 2, WIDE, PMODE, STOREP, NBM>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
         default: gram_quad_body<NBT, 3, WIDE, PMODE, STOREP, NBM>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, Pout); break;
+    }
+}
+
+template <int NBT, bool WIDE, int NBM = NBT>
+__global__ void __launch_bounds__(256, 1)
+k_gram_quad_split(const double* __restrict__ u, int64_t ld, int64_t N, int64_t ntiles, const double* __restrict__ anum,
+                  const double* __restrict__ logden, double* __restrict__ gram_part, int64_t split_rows, int64_t row_j0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    exp_table_init(smem);
+    __syncthreads();
+    switch (wave) {
+        case 0: gram_quad_body<NBT, 0, WIDE, false, false, NBM, true>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, nullptr, split_rows, row_j0); break;
+        case 1: gram_quad_body<NBT, 1, WIDE, false, false, NBM, true>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, nullptr, split_rows, row_j0); break;
+        case 2: gram_quad_body<NBT, 2, WIDE, false, false, NBM, true>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, nullptr, split_rows, row_j0); break;
+        default: gram_quad_body<NBT, 3, WIDE, false, false, NBM, true>(u, ld, N, ntiles, anum, logden, gram_part, smem, lane, nullptr, split_rows, row_j0); break;
     }
 }
 
@@ -817,6 +838,32 @@ hipError_t launch_gram_quad(hipStream_t s, int nbt, const LaunchGeom& g, const d
     if (nbt == 16)
         return lc.pmode ? launch_gram_quad_t<16, true>(s, g, u, ld, N, anum, logden, gram_part, lc)
                         : launch_gram_quad_t<16, false>(s, g, u, ld, N, anum, logden, gram_part, lc);
+    return hipErrorInvalidValue;
+}
+// One-read Gram sweep of a 192- / 256-row panel whose rows [split_rows, 16 nbt) live in another matrix of the same row pitch
+// (row_j0: their first row, counted in rows of `u`; classic operands only).  live_blocks as in launch_gram_quad.
+hipError_t launch_gram_quad_split(hipStream_t s, int nbt, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* anum,
+                                  const double* logden, double* gp, int64_t split_rows, int64_t row_j0) {
+    auto launch = [&](auto kern) -> hipError_t {
+        if (g.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        const int64_t ntiles = (N + TS - 1) / TS;
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(256), g.lds_bytes, s, u, ld, N, ntiles, anum, logden, gp, split_rows, row_j0);
+        return hipGetLastError();
+    };
+    if (split_rows < 8 || split_rows % 8 != 0 || split_rows >= 16 * nbt) return hipErrorInvalidValue;
+    const bool wide = stage_offsets_wide(ld);
+    const bool trim = g.live_blocks > 0 && g.live_blocks <= nbt - 2;
+    if (nbt == 12) {
+        if (trim) return wide ? launch(k_gram_quad_split<12, true, 10>) : launch(k_gram_quad_split<12, false, 10>);
+        return wide ? launch(k_gram_quad_split<12, true>) : launch(k_gram_quad_split<12, false>);
+    }
+    if (nbt == 16) {
+        if (trim) return wide ? launch(k_gram_quad_split<16, true, 14>) : launch(k_gram_quad_split<16, false, 14>);
+        return wide ? launch(k_gram_quad_split<16, true>) : launch(k_gram_quad_split<16, false>);
+    }
     return hipErrorInvalidValue;
 }
 // (the geometry is gram_quad_geometry(nbi + 16, ...): the same shared double buffer, one record per workgroup)

@@ -1599,6 +1599,32 @@ hipError_t launch_rows_logshift(hipStream_t s, double* base, int64_t ld, int64_t
     hipLaunchKernelGGL(k_rows_logshift, dim3(gx, gy), dim3(256), 0, s, base, ld, nrows, n, part, (int)gx, shift_out);
     return hipGetLastError();
 }
+// dst_r = state_r - log(obs_r - shift_r) with shift_r as in k_rows_logshift, from the same partial minima: observables that are rows of
+// a resident matrix, each at its own state, written straight into the rows of an extension context (mbar_ctx_rows_obs_from)
+__global__ void __launch_bounds__(256) k_rows_obs(double* __restrict__ dst, const double* __restrict__ obs, const double* __restrict__ state,
+                                                  int64_t ld, int64_t nrows, int64_t n, const double* __restrict__ part, int nparts,
+                                                  double* __restrict__ shift_out) {
+    __shared__ double red[4];
+    for (int64_t r = blockIdx.y; r < nrows; r += gridDim.y) {
+        double m = INFINITY;
+        for (int i = threadIdx.x; i < nparts; i += blockDim.x) m = fmin(m, part[r * nparts + i]);
+        m = -block256_max(-m, red);
+        const double shift = m - fabs(8.881784197001252e-16 * m);  // 4 eps (mbar.py:827-832)
+        if (blockIdx.x == 0 && threadIdx.x == 0) shift_out[r] = shift;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            dst[r * ld + i] = state[r * ld + i] - log(obs[r * ld + i] - shift);
+        __syncthreads();
+    }
+}
+hipError_t launch_rows_obs(hipStream_t s, double* dst, const double* obs, const double* state, int64_t ld, int64_t nrows, int64_t n,
+                           double* part, double* shift_out) {
+    const int64_t want = (n + 2047) / 2048;
+    const unsigned gx = (unsigned)(want < 256 ? (want < 1 ? 1 : want) : 256);
+    const unsigned gy = (unsigned)(nrows < 1024 ? (nrows < 1 ? 1 : nrows) : 1024);
+    hipLaunchKernelGGL(k_rows_min_partial, dim3(gx, gy), dim3(256), 0, s, obs, ld, nrows, n, part);
+    hipLaunchKernelGGL(k_rows_obs, dim3(gx, gy), dim3(256), 0, s, dst, obs, state, ld, nrows, n, (const double*)part, (int)gx, shift_out);
+    return hipGetLastError();
+}
 hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n) {
     const int64_t want = (n + 255) / 256;
     const unsigned gx = (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);

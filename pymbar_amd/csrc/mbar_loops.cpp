@@ -918,6 +918,7 @@ extern "C" {
 
 int mbar_solve_adaptive(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, int64_t min_sc_iter, double gamma,
                         int check_convergence, double* history, int64_t history_rows, mbar_solve_result* result) {
+    if (c && c->ext_base) return fail(c, MBAR_ERR_STATE, "mbar_solve_adaptive: an extension context holds rows only (mbar_lognum_ext / mbar_gram_w_ext sweep them)");
     if (!c || !f_inout) return fail(c, MBAR_ERR_ARG, "NULL argument");
     if (!c->have_Nk) return fail(c, MBAR_ERR_STATE, "mbar_ctx_set_Nk has not been called");
     HIPCHK(c, hipSetDevice(c->device));
@@ -994,6 +995,7 @@ int mbar_ctx_last_solve_psum(mbar_ctx* c, double* psum_out) {
 
 int mbar_solve_sci(mbar_ctx* c, double* f_inout, double tol, int64_t maxiter, int check_convergence,
                    mbar_solve_result* result) {
+    if (c && c->ext_base) return fail(c, MBAR_ERR_STATE, "mbar_solve_sci: an extension context holds rows only (mbar_lognum_ext / mbar_gram_w_ext sweep them)");
     if (!c || !f_inout) return fail(c, MBAR_ERR_ARG, "NULL argument");
     if (!c->have_Nk) return fail(c, MBAR_ERR_STATE, "mbar_ctx_set_Nk has not been called");
     HIPCHK(c, hipSetDevice(c->device));

@@ -35,6 +35,8 @@ class DeviceMatrix:
         if rc != _lib.MBAR_OK:
             raise _lib.MbarHipError(rc, _lib.last_error(None))
         self._Nk = None
+        self._version = 0  # bumped by everything that changes the matrix, N_k, the sample multiplicities or the transport
+        self._lognum_cache = None
         self._cb = None  # keeps the host all-reduce callback alive
         self.nranks = 1
         self.rank = 0
@@ -104,6 +106,7 @@ class DeviceMatrix:
     # ---- row-level assembly of an augmented matrix on the device (expectation family) ----------------------
     def upload_rows(self, row0, rows):
         """Whole rows ``[row0, row0 + len(rows))`` from a host array ``rows`` (R, N_local)."""
+        self._version += 1
         rows = np.ascontiguousarray(np.atleast_2d(rows), dtype=np.float64)
         if rows.shape[1] != self.N_local:
             raise ValueError("rows must have N_local columns")
@@ -111,12 +114,14 @@ class DeviceMatrix:
 
     def copy_rows_from(self, src, dst_row0=0, src_row0=0, nrows=None):
         """Device-to-device copy of rows of another resident matrix (same device, same N_local)."""
+        self._version += 1
         nrows = src.K - src_row0 if nrows is None else nrows
         self._check(self._lib.mbar_ctx_copy_rows(self._ctx, int(dst_row0), src._ctx, int(src_row0), int(nrows)))
 
     def row_sub(self, row, v_n=None):
         """``u[row, :] -= v_n`` on the device (v = log A_n turns a state row into an observable row).
         ``v_n=None`` subtracts the vector of the previous call again (no upload)."""
+        self._version += 1
         if v_n is None:
             self._check(self._lib.mbar_ctx_row_sub(self._ctx, int(row), None))
             return
@@ -128,6 +133,7 @@ class DeviceMatrix:
     def rows_sub(self, dst_row0, src_row0, nrows, v_n=None):
         """``u[dst_row0 + r, :] = u[src_row0 + r, :] - v_n`` for ``r < nrows`` in one launch (``v_n=None``: the vector of the
         previous call): an observable evaluated at a run of states, the state rows copied and shifted in the same pass."""
+        self._version += 1
         if v_n is None:
             self._check(self._lib.mbar_ctx_rows_sub(self._ctx, int(dst_row0), int(src_row0), int(nrows), None))
             return
@@ -139,11 +145,13 @@ class DeviceMatrix:
     def rows_rsub(self, dst_row0, src_row0, nrows):
         """``u[dst_row0 + r, :] = u[src_row0 + r, :] - u[dst_row0 + r, :]`` for ``r < nrows`` in one launch: rows uploaded as
         ``log A`` become observable rows ``u - log A``."""
+        self._version += 1
         self._check(self._lib.mbar_ctx_rows_rsub(self._ctx, int(dst_row0), int(src_row0), int(nrows)))
 
     def rows_logshift(self, row0, nrows):
         """Rows ``[row0, row0 + nrows)`` hold raw observable values and become ``log(A - shift)`` in place, ``shift = min A -
         |4 eps min A|`` per row (returned): the reference's shift-to-positive + log (mbar.py:858-867, :886-903) on the device."""
+        self._version += 1
         shift = np.empty(int(nrows), dtype=np.float64)
         self._check(self._lib.mbar_ctx_rows_logshift(self._ctx, int(row0), int(nrows), _dptr(shift)))
         return shift
@@ -161,6 +169,7 @@ class DeviceMatrix:
     def fill_masked_rows(self, row0, nrows, v_n, label_n):
         """Rows ``row0 + i`` (``i < nrows``) become ``v_n`` on the samples with ``label_n == i`` and ``+inf`` (weight zero)
         elsewhere: one extra "state" per histogram bin of a free energy surface, built on the device."""
+        self._version += 1
         v_n = np.ascontiguousarray(v_n, dtype=np.float64)
         label_n = np.ascontiguousarray(label_n, dtype=np.int32)
         if v_n.shape != (self.N_local,) or label_n.shape != (self.N_local,):
@@ -183,6 +192,7 @@ class DeviceMatrix:
 
     def set_Nk(self, N_k):
         """GLOBAL sample counts (any numeric dtype; zeros allowed)."""
+        self._version += 1
         Nk = np.ascontiguousarray(N_k, dtype=np.float64)
         if Nk.shape != (self.K,):
             raise ValueError(f"N_k must have shape ({self.K},)")
@@ -193,6 +203,7 @@ class DeviceMatrix:
     def set_sample_weights(self, c_n):
         """Per-sample multiplicities (``None`` restores 1): every sum over samples becomes ``sum_n c_n (...)``.
         A bootstrap replicate is ``np.bincount(resampled_indices, minlength=N)``."""
+        self._version += 1
         if c_n is None:
             self._check(self._lib.mbar_ctx_set_sample_weights(self._ctx, None))
             return
@@ -208,6 +219,7 @@ class DeviceMatrix:
         ``layout_key``: any object that identifies (cumN, order) for the caller -- the layout is uploaded when the key changes
         (``mbar_ctx_set_bootstrap_layout``) and replicates with the same key touch no host array of N integers; without a key the
         arrays travel with every call and the library digests them to see whether its device copy still matches."""
+        self._version += 1
         ip = C.POINTER(C.c_int64)
         if layout_key is not None and layout_key is getattr(self, "_boot_layout_key", None):
             self._check(self._lib.mbar_ctx_draw_bootstrap_weights(self._ctx, C.c_uint64(int(seed)), int(replicate), None, 0, None, int(n_global0)))
@@ -229,16 +241,19 @@ class DeviceMatrix:
     def weights_from_vec(self, power):
         """Per-sample weights ``(A_n - shift)**power`` from the observable ``vec_logshift`` left on the device (no upload, no host
         pass): the weighted sums of a single observable at the resident states.  ``set_sample_weights(None)`` restores 1."""
+        self._version += 1
         self._check(self._lib.mbar_ctx_weights_from_vec(self._ctx, float(power)))
 
     # ---- multi-GPU --------------------------------------------------------------------------------
     def comm_init_rccl(self, unique_id, rank, nranks):
+        self._version += 1
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self._lib.mbar_ctx_comm_init(self._ctx, buf, rank, nranks))
         self.rank, self.nranks, self.allreduce_kind = rank, nranks, "rccl"
 
     def set_host_allreduce(self, fn, rank, nranks):
         """``fn(array, op)`` must all-reduce the float64 numpy ``array`` in place (op 'sum'|'max')."""
+        self._version += 1
 
         def _cb(ptr, count, op, _user):
             try:
@@ -255,12 +270,14 @@ class DeviceMatrix:
     def set_loopback(self, group, rank):
         """Join the in-process transport ``group`` (:class:`LoopbackGroup`) as ``rank``: collectives run on the compute stream
         like RCCL's, between contexts of this process on one device (one caller thread per context)."""
+        self._version += 1
         self._check(self._lib.mbar_ctx_set_loopback(self._ctx, group._h, int(rank)))
         self._loop = group  # (keeps the group alive)
         self.rank, self.nranks, self.allreduce_kind = int(rank), group.nranks, "loopback"
 
     def comm_destroy(self):
         """Detach the cross-rank transport (destroys an RCCL communicator); the matrix is single-rank again."""
+        self._version += 1
         self._check(self._lib.mbar_ctx_comm_destroy(self._ctx))
         self._cb = None
         self.rank, self.nranks, self.allreduce_kind = 0, 1, "none"
@@ -300,6 +317,27 @@ class DeviceMatrix:
         out = np.empty(self.K, dtype=np.float64)
         self._check(self._lib.mbar_lognum(self._ctx, _dptr(f), _dptr(out)))
         return out
+
+    def lognum_cached(self, f):
+        """``lognum(f)``, kept while neither the matrix, N_k, the multiplicities nor ``f`` change (consecutive methods of the
+        class at the same ``f_k``: one sweep of the resident rows instead of one per call)."""
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        key = (self._version, f.tobytes())
+        if self._lognum_cache is None or self._lognum_cache[0] != key:
+            self._lognum_cache = (key, self.lognum(f))
+        return self._lognum_cache[1].copy()
+
+    def extend(self, nrows):
+        """An :class:`ExtendedMatrix` of ``K + nrows`` rows whose first K rows ARE this matrix (no copy) -- or ``None`` when the
+        library cannot sweep the two as one panel (more than 128 states here, fewer than 129 or more than 256 rows in total,
+        several ranks): the caller then assembles an augmented copy."""
+        if self.nranks != 1:
+            return None
+        ctx = C.c_void_p()
+        rc = self._lib.mbar_ctx_create_ext(C.byref(ctx), self._ctx, int(nrows))
+        if rc != _lib.MBAR_OK:
+            return None
+        return ExtendedMatrix(self, ctx, int(nrows))
 
     def logden(self, f):
         f = np.ascontiguousarray(f, dtype=np.float64)
@@ -381,6 +419,127 @@ class DeviceMatrix:
         t = C.c_double(0.0)
         self._check(self._lib.mbar_mfma_f64_peak(self._ctx, C.byref(t)))
         return t.value
+
+
+class ExtendedMatrix:
+    """``[rows of a resident DeviceMatrix | rows appended to it]`` without a copy of the resident rows: the appended rows live in
+    an extension context of the library (``mbar_ctx_create_ext``) and the sweeps read both matrices (``mbar_lognum_ext``,
+    ``mbar_gram_w_ext``).  Row indices are those of the augmented matrix of pymbar/mbar.py:886-903 -- ``[0, K)`` the resident
+    states, ``[K, K + R)`` the appended ones (N_k = 0) -- and the methods are the subset of :class:`DeviceMatrix` that the
+    expectation family drives; rows below K are read-only."""
+
+    def __init__(self, base, ctx, nrows):
+        self.base = base
+        self._lib = base._lib
+        self._ctx = ctx
+        self.Kb = base.K
+        self.K = base.K + nrows
+        self.N_local = base.N_local
+        self.nranks = 1
+
+    def _check(self, rc):
+        if rc != _lib.MBAR_OK:
+            raise _lib.MbarHipError(rc, _lib.last_error(self._ctx))
+
+    def close(self):
+        if self._ctx:
+            self._lib.mbar_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ext_row(self, row, n=1):
+        if row < self.Kb or row + n > self.K:
+            raise ValueError("only the appended rows can be written")
+        return int(row - self.Kb)
+
+    def _src(self, row0, n):
+        """(context, row) of a source run: the resident matrix below K, the extension from K on (a run does not straddle)."""
+        if row0 + n <= self.Kb:
+            return self.base._ctx, int(row0)
+        if row0 >= self.Kb:
+            return self._ctx, int(row0 - self.Kb)
+        raise ValueError("a source run straddles the resident and the appended rows")
+
+    def upload_rows(self, row0, rows):
+        rows = np.ascontiguousarray(np.atleast_2d(rows), dtype=np.float64)
+        if rows.shape[1] != self.N_local:
+            raise ValueError("rows must have N_local columns")
+        self._check(self._lib.mbar_ctx_upload_rows(self._ctx, self._ext_row(row0, rows.shape[0]), rows.shape[0], _dptr(rows), rows.shape[1]))
+
+    def copy_rows_from(self, src, dst_row0=0, src_row0=0, nrows=None):
+        nrows = src.K - src_row0 if nrows is None else nrows
+        if src is self.base and dst_row0 == 0 and src_row0 == 0 and nrows == self.Kb:
+            return  # (the resident rows ARE the first K rows)
+        self._check(self._lib.mbar_ctx_copy_rows(self._ctx, self._ext_row(dst_row0, nrows), src._ctx, int(src_row0), int(nrows)))
+
+    def rows_sub(self, dst_row0, src_row0, nrows, v_n=None):
+        sctx, srow = self._src(src_row0, nrows)
+        vp = None
+        if v_n is not None:
+            v_n = np.ascontiguousarray(v_n, dtype=np.float64)
+            if v_n.shape != (self.N_local,):
+                raise ValueError("v_n must have N_local entries")
+            vp = _dptr(v_n)
+        self._check(self._lib.mbar_ctx_rows_sub_from(self._ctx, self._ext_row(dst_row0, nrows), sctx, srow, int(nrows), vp))
+
+    def rows_rsub(self, dst_row0, src_row0, nrows):
+        sctx, srow = self._src(src_row0, nrows)
+        self._check(self._lib.mbar_ctx_rows_rsub_from(self._ctx, self._ext_row(dst_row0, nrows), sctx, srow, int(nrows)))
+
+    def rows_obs_from_base(self, dst_row0, state_row0, obs_row0, nrows):
+        """Appended rows ``dst`` = resident rows ``state`` - log(resident rows ``obs`` - shift); ``shift`` per row is returned."""
+        shift = np.empty(int(nrows), dtype=np.float64)
+        self._check(self._lib.mbar_ctx_rows_obs_from(self._ctx, self._ext_row(dst_row0, nrows), self.base._ctx, int(state_row0),
+                                                     int(obs_row0), int(nrows), _dptr(shift)))
+        return shift
+
+    def rows_logshift(self, row0, nrows):
+        shift = np.empty(int(nrows), dtype=np.float64)
+        self._check(self._lib.mbar_ctx_rows_logshift(self._ctx, self._ext_row(row0, nrows), int(nrows), _dptr(shift)))
+        return shift
+
+    def vec_logshift(self, A_n):
+        A_n = np.ascontiguousarray(A_n, dtype=np.float64)
+        if A_n.shape != (self.N_local,):
+            raise ValueError("A_n must have N_local entries")
+        shift = np.empty(1, dtype=np.float64)
+        self._check(self._lib.mbar_ctx_vec_logshift(self._ctx, _dptr(A_n), _dptr(shift)))
+        return float(shift[0])
+
+    def set_Nk(self, N_k):
+        N_k = np.asarray(N_k, dtype=np.float64)
+        if (N_k.shape != (self.K,) or np.any(N_k[self.Kb:] != 0) or self.base._Nk is None
+                or not np.array_equal(N_k[:self.Kb], self.base._Nk)):
+            raise ValueError("the appended rows are unsampled states of the resident matrix's mixture")
+
+    def lognum(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        fb = np.ascontiguousarray(f[:self.Kb])
+        out = np.empty(self.K, dtype=np.float64)
+        out[:self.Kb] = self.base.lognum_cached(fb)
+        ext = np.empty(self.K - self.Kb, dtype=np.float64)
+        self._check(self._lib.mbar_lognum_ext(self._ctx, self.base._ctx, _dptr(fb), _dptr(ext)))
+        out[self.Kb:] = ext
+        return out
+
+    def gram_w(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        fb, fe = np.ascontiguousarray(f[:self.Kb]), np.ascontiguousarray(f[self.Kb:])
+        G = np.empty((self.K, self.K), dtype=np.float64)
+        ws = np.empty(self.K, dtype=np.float64)
+        self._check(self._lib.mbar_gram_w_ext(self._ctx, self.base._ctx, _dptr(fb), _dptr(fe), _dptr(G), _dptr(ws)))
+        return G, ws
 
 
 class LoopbackGroup:

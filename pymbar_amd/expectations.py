@@ -31,7 +31,7 @@ logger = logging.getLogger(__name__)
 
 
 
-def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device, dedup=False):
+def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device, dedup=False, extend=False):
     """Assemble ``[u_kn; u_ln[L_list]; u_ln[state_rows[s]] - log(A[obs_rows[s]] - shift)]`` ON THE DEVICE, the extra rows as
     unsampled states (N_k = 0: they do not enter the denominator).  The resident ``u_kn`` is copied device to device; a
     new-state row that IS a resident row (``u_ln is mbar.u_kn``, the default of compute_expectations) likewise, and so are
@@ -43,7 +43,12 @@ def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device, ded
 
     ``dedup`` (only when the new states ARE resident rows): the copies are not made at all -- state ``l`` is row ``l`` -- and the
     matrix has K + S rows instead of K + NL + S (compute_expectations and the entropy / enthalpy decomposition at 128 states:
-    256 rows instead of 384, which keeps the sweeps on the one-read kernels); the caller expands the Gram matrix."""
+    256 rows instead of 384, which keeps the sweeps on the one-read kernels); the caller expands the Gram matrix.
+
+    ``extend`` (round 6): the resident rows are not copied either -- the extra rows go into an extension of the resident matrix
+    (``DeviceMatrix.extend``: the library sweeps ``[resident rows | appended rows]`` as one panel) when it can hold them (up to
+    128 resident states, 129 .. 256 rows in total, one rank); observables that are resident rows at resident states (entropy /
+    enthalpy) are then written in one pass, ``u_l - log(u_i - shift)`` straight from the resident rows."""
     from .device import DeviceMatrix
 
     K, N = mbar.K, mbar.N
@@ -52,8 +57,12 @@ def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device, ded
     dedup = dedup and resident
     if dedup:
         NL = 0
-    dm = DeviceMatrix.empty(K + NL + S, N, device=device)
-    dm.copy_rows_from(mbar._dm, 0, 0, K)
+    dm = None
+    if extend and hasattr(mbar._dm, "extend") and NL + S > 0:
+        dm = mbar._dm.extend(NL + S)
+    if dm is None:
+        dm = DeviceMatrix.empty(K + NL + S, N, device=device)
+        dm.copy_rows_from(mbar._dm, 0, 0, K)
     shift = np.zeros(len(A_n) if S > 0 else 0, dtype=np.float64)
 
     def runs(pairs):
@@ -81,15 +90,27 @@ def _augmented_matrix(mbar, u_ln, L_list, state_rows, A_n, obs_rows, device, ded
         # mostly DIFFERENT observables (entropy / enthalpy: the K reduced potentials, each at its own state): the raw rows go
         # into the observable rows (device to device when they are rows of the resident matrix, one transfer per run of
         # consecutive observables otherwise), become log(A - shift) there and then u - log(A - shift), one launch per run
-        for d0, o0, n in runs([(K + NL + s, int(obs_rows[s])) for s in range(S)]):
-            if A_n is mbar.u_kn:
-                dm.copy_rows_from(mbar._dm, d0, o0, n)
-            else:
-                dm.upload_rows(d0, A_n[o0:o0 + n])
-        shift_rows = dm.rows_logshift(K + NL, S)
-        shift[np.asarray(obs_rows, dtype=int)] = shift_rows
-        for d0, s0, n in runs([(K + NL + s, col[int(state_rows[s])]) for s in range(S)]):
-            dm.rows_rsub(d0, s0, n)
+        if A_n is mbar.u_kn and hasattr(dm, "rows_obs_from_base") and all(col[int(l)] < K for l in state_rows):
+            # (resident observables at resident states into appended rows: one pass per run, no copy of the observable rows)
+            trip = []
+            for s in range(S):
+                d, o_, st = K + NL + s, int(obs_rows[s]), col[int(state_rows[s])]
+                if trip and trip[-1][0] + trip[-1][3] == d and trip[-1][1] + trip[-1][3] == o_ and trip[-1][2] + trip[-1][3] == st:
+                    trip[-1][3] += 1
+                else:
+                    trip.append([d, o_, st, 1])
+            for d0, o0, s0, n in trip:
+                shift[o0:o0 + n] = dm.rows_obs_from_base(d0, s0, o0, n)
+        else:
+            for d0, o0, n in runs([(K + NL + s, int(obs_rows[s])) for s in range(S)]):
+                if A_n is mbar.u_kn:
+                    dm.copy_rows_from(mbar._dm, d0, o0, n)
+                else:
+                    dm.upload_rows(d0, A_n[o0:o0 + n])
+            shift_rows = dm.rows_logshift(K + NL, S)
+            shift[np.asarray(obs_rows, dtype=int)] = shift_rows
+            for d0, s0, n in runs([(K + NL + s, col[int(state_rows[s])]) for s in range(S)]):
+                dm.rows_rsub(d0, s0, n)
         uniq = []
     for i in uniq:  # one upload of A_i; its log, shifted, is subtracted at every state it is evaluated at
         shift[int(i)] = dm.vec_logshift(A_n[int(i)])
@@ -160,8 +181,11 @@ def compute_expectations_inner(mbar, A_n, u_ln, state_map, uncertainty_method=No
     # u_kn[:, bootstrap_rints[n]]) is the same matrix with per-sample multiplicities = draw counts.
     # (observables are made strictly positive so that they can live in log space, mbar.py:858-867: shift[i] is the reference's
     # A_min[i] - logfactors[i], found on the device)
+    # (an extension of the resident matrix instead of an augmented copy where the library can sweep the two as one panel; bootstrap
+    # replicates put multiplicities on the augmented matrix and "svd" downloads its weights: those keep the copy)
     dm, N_dm, shift, row_of_state = _augmented_matrix(mbar, u_ln, L_list, state_list[:S] if S > 0 else [], A_n, obs_list,
-                                                      getattr(mbar, "_device", None), dedup=dedup)
+                                                      getattr(mbar, "_device", None), dedup=dedup,
+                                                      extend=not bootstrap and uncertainty_method != "svd")
     R_dm = len(N_dm) - K      # extra rows on the device: S when the state rows are not duplicated, NL + S otherwise
     obs_row0 = len(N_dm) - S  # first observable row
     try:

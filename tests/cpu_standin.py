@@ -259,3 +259,95 @@ class OracleMatrix:
                 res["success"] = True
                 break
         return f, res
+
+
+class OracleExtended:
+    """Model of ``pymbar_amd.device.ExtendedMatrix`` (rows appended to a resident matrix without a copy of it): the resident rows
+    are read through ``base``, the appended ones are a numpy block; ``lognum`` / ``gram_w`` stack the two for the oracle."""
+
+    def __init__(self, base, nrows):
+        self.base, self.Kb, self.K, self.N_local, self.nranks = base, base.K, base.K + nrows, base.N_local, 1
+        self.ext = np.zeros((nrows, base.N_local))
+        self._last_v = None
+
+    def close(self):
+        pass
+
+    def _rows(self, row0, n):
+        if row0 + n <= self.Kb:
+            return self.base.u[row0:row0 + n]
+        assert row0 >= self.Kb
+        return self.ext[row0 - self.Kb:row0 - self.Kb + n]
+
+    def upload_rows(self, row0, rows):
+        rows = np.atleast_2d(np.asarray(rows, dtype=np.float64))
+        assert row0 >= self.Kb
+        self.ext[row0 - self.Kb:row0 - self.Kb + rows.shape[0]] = rows
+
+    def copy_rows_from(self, src, dst_row0=0, src_row0=0, nrows=None):
+        nrows = src.K - src_row0 if nrows is None else nrows
+        if src is self.base and dst_row0 == 0 and src_row0 == 0 and nrows == self.Kb:
+            return
+        assert dst_row0 >= self.Kb
+        self.ext[dst_row0 - self.Kb:dst_row0 - self.Kb + nrows] = src.u[src_row0:src_row0 + nrows]
+
+    def rows_sub(self, dst_row0, src_row0, nrows, v_n=None):
+        if v_n is not None:
+            self._last_v = np.asarray(v_n, dtype=np.float64).copy()
+        self.ext[dst_row0 - self.Kb:dst_row0 - self.Kb + nrows] = self._rows(src_row0, nrows) - self._last_v
+
+    def rows_rsub(self, dst_row0, src_row0, nrows):
+        d = self.ext[dst_row0 - self.Kb:dst_row0 - self.Kb + nrows]
+        d[...] = self._rows(src_row0, nrows) - d
+
+    def rows_obs_from_base(self, dst_row0, state_row0, obs_row0, nrows):
+        obs = self.base.u[obs_row0:obs_row0 + nrows]
+        amin = obs.min(axis=1)
+        shift = amin - np.abs(4.0 * np.finfo(np.float64).eps * amin)
+        with np.errstate(divide="ignore"):
+            self.ext[dst_row0 - self.Kb:dst_row0 - self.Kb + nrows] = self.base.u[state_row0:state_row0 + nrows] - np.log(obs - shift[:, None])
+        return shift
+
+    def rows_logshift(self, row0, nrows):
+        rows = self.ext[row0 - self.Kb:row0 - self.Kb + nrows]
+        amin = rows.min(axis=1)
+        shift = amin - np.abs(4.0 * np.finfo(np.float64).eps * amin)
+        with np.errstate(divide="ignore"):
+            rows[...] = np.log(rows - shift[:, None])
+        return shift
+
+    def vec_logshift(self, A_n):
+        A_n = np.asarray(A_n, dtype=np.float64)
+        amin = A_n.min()
+        shift = amin - np.abs(4.0 * np.finfo(np.float64).eps * amin)
+        with np.errstate(divide="ignore"):
+            self._last_v = np.log(A_n - shift)
+        return float(shift)
+
+    def set_Nk(self, N_k):
+        N_k = np.asarray(N_k, dtype=np.float64)
+        assert np.all(N_k[self.Kb:] == 0) and np.array_equal(N_k[:self.Kb], self.base.Nk)
+
+    def _stacked(self):
+        full = OracleMatrix(np.vstack([self.base.u, self.ext]))
+        full.set_Nk(np.concatenate([self.base.Nk, np.zeros(self.K - self.Kb)]))
+        return full
+
+    def lognum(self, f):
+        return self._stacked().lognum(f)
+
+    def gram_w(self, f):
+        return self._stacked().gram_w(f)
+
+
+def _oracle_extend(self, nrows):
+    """(as the library: up to 128 resident states, 129 .. 256 rows in total; the tests lower the bounds through EXTEND_ROWS)"""
+    lo, hi = OracleMatrix.EXTEND_ROWS
+    Kp = (self.K + 15) // 16 * 16
+    if self.allreduce is not None or not (lo < Kp + (nrows + 15) // 16 * 16 <= hi) or Kp > 128:
+        return None
+    return OracleExtended(self, nrows)
+
+
+OracleMatrix.EXTEND_ROWS = (128, 256)
+OracleMatrix.extend = _oracle_extend

@@ -36,4 +36,13 @@ for name, fn in calls.items():
         fn()
         t.append(1e3 * (time.perf_counter() - t0))
     print(f"{name}: {np.median(t):.2f} ms per call (median of {reps}; min {min(t):.2f})", flush=True)
+    if os.environ.get("MBAR_PROFILE_PY"):
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        fn()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
 m.close()
