@@ -35,8 +35,10 @@ class DeviceMatrix:
         if rc != _lib.MBAR_OK:
             raise _lib.MbarHipError(rc, _lib.last_error(None))
         self._Nk = None
-        self._version = 0  # bumped by everything that changes the matrix, N_k, the sample multiplicities or the transport
+        self._version = 0  # bumped by everything that changes the matrix, N_k or the transport
+        self._wtag = None  # None = unit sample multiplicities; otherwise a token of the weights last installed
         self._lognum_cache = None
+        self._gram_w_cache = None
         self._cb = None  # keeps the host all-reduce callback alive
         self.nranks = 1
         self.rank = 0
@@ -192,18 +194,18 @@ class DeviceMatrix:
 
     def set_Nk(self, N_k):
         """GLOBAL sample counts (any numeric dtype; zeros allowed)."""
-        self._version += 1
         Nk = np.ascontiguousarray(N_k, dtype=np.float64)
         if Nk.shape != (self.K,):
             raise ValueError(f"N_k must have shape ({self.K},)")
         if self._Nk is None or not np.array_equal(Nk, self._Nk):
+            self._version += 1
             self._check(self._lib.mbar_ctx_set_Nk(self._ctx, _dptr(Nk)))
             self._Nk = Nk.copy()
 
     def set_sample_weights(self, c_n):
         """Per-sample multiplicities (``None`` restores 1): every sum over samples becomes ``sum_n c_n (...)``.
         A bootstrap replicate is ``np.bincount(resampled_indices, minlength=N)``."""
-        self._version += 1
+        self._wtag = None if c_n is None else object()
         if c_n is None:
             self._check(self._lib.mbar_ctx_set_sample_weights(self._ctx, None))
             return
@@ -219,7 +221,7 @@ class DeviceMatrix:
         ``layout_key``: any object that identifies (cumN, order) for the caller -- the layout is uploaded when the key changes
         (``mbar_ctx_set_bootstrap_layout``) and replicates with the same key touch no host array of N integers; without a key the
         arrays travel with every call and the library digests them to see whether its device copy still matches."""
-        self._version += 1
+        self._wtag = object()
         ip = C.POINTER(C.c_int64)
         if layout_key is not None and layout_key is getattr(self, "_boot_layout_key", None):
             self._check(self._lib.mbar_ctx_draw_bootstrap_weights(self._ctx, C.c_uint64(int(seed)), int(replicate), None, 0, None, int(n_global0)))
@@ -241,7 +243,7 @@ class DeviceMatrix:
     def weights_from_vec(self, power):
         """Per-sample weights ``(A_n - shift)**power`` from the observable ``vec_logshift`` left on the device (no upload, no host
         pass): the weighted sums of a single observable at the resident states.  ``set_sample_weights(None)`` restores 1."""
-        self._version += 1
+        self._wtag = object()
         self._check(self._lib.mbar_ctx_weights_from_vec(self._ctx, float(power)))
 
     # ---- multi-GPU --------------------------------------------------------------------------------
@@ -322,10 +324,24 @@ class DeviceMatrix:
         """``lognum(f)``, kept while neither the matrix, N_k, the multiplicities nor ``f`` change (consecutive methods of the
         class at the same ``f_k``: one sweep of the resident rows instead of one per call)."""
         f = np.ascontiguousarray(f, dtype=np.float64)
+        if self._wtag is not None:
+            return self.lognum(f)
         key = (self._version, f.tobytes())
         if self._lognum_cache is None or self._lognum_cache[0] != key:
             self._lognum_cache = (key, self.lognum(f))
         return self._lognum_cache[1].copy()
+
+    def gram_w_cached(self, f):
+        """``gram_w(f)`` with unit multiplicities, kept like ``lognum_cached`` (the covariance of the free energies, overlap and
+        every expectation at the same ``f_k`` start from the same ``W^T W`` of the resident states)."""
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        if self._wtag is not None:
+            return self.gram_w(f)
+        key = (self._version, f.tobytes())
+        if self._gram_w_cache is None or self._gram_w_cache[0] != key:
+            self._gram_w_cache = (key, self.gram_w(f))
+        G, ws = self._gram_w_cache[1]
+        return G.copy(), ws.copy()
 
     def extend(self, nrows):
         """An :class:`ExtendedMatrix` of ``K + nrows`` rows whose first K rows ARE this matrix (no copy) -- or ``None`` when the

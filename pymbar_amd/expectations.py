@@ -279,7 +279,8 @@ def _single_observable_moments(mbar, A_row, state_list, obs_index, n_obs, col_of
     shift = np.zeros(n_obs, dtype=np.float64)
     try:
         dm.set_sample_weights(None)
-        lognum0 = dm.lognum(f_k)                       # resident rows as states: -f_l
+        cached = hasattr(dm, "lognum_cached")
+        lognum0 = dm.lognum_cached(f_k) if cached else dm.lognum(f_k)   # resident rows as states: -f_l (kept across calls at the same f_k)
         shift[obs_index] = dm.vec_logshift(A_row)       # log(A - shift) stays on the device
         _weights_from_vec(dm, 1.0)
         lognum1 = dm.lognum(f_k)                       # log sum_n A'_n exp(-u_ln - logden_n)
@@ -292,7 +293,7 @@ def _single_observable_moments(mbar, A_row, state_list, obs_index, n_obs, col_of
             _weights_from_vec(dm, 2.0)
             G2, _ = dm.gram_w(f_k)
             dm.set_sample_weights(None)
-            G0, ws0 = dm.gram_w(f_k)
+            G0, ws0 = dm.gram_w_cached(f_k) if cached else dm.gram_w(f_k)
             # Theta on the (K + S) DISTINCT weight columns [K resident | S observables], observable s = A' W_l(s) scaled by
             # d_s = exp(f_s - f_k[l(s)]), f_s = -lognum1[l(s)].  The reference's layout [K sampled | NL state copies | S observables]
             # (mbar.py:886-903) holds, besides these, NL columns that are exact multiples c_l W_l of resident ones, c_l =

@@ -374,6 +374,8 @@ class MBAR:
 
     def _gram_w(self):
         self._dm.set_Nk(self.N_k)
+        if hasattr(self._dm, "gram_w_cached"):  # (kept while the matrix, N_k, the multiplicities and f_k stay what they are)
+            return self._dm.gram_w_cached(self.f_k)
         return self._dm.gram_w(self.f_k)
 
     def compute_effective_sample_number(self, verbose=False):

@@ -2,7 +2,7 @@
 """Where compute_perturbed_free_energies / compute_entropy_and_enthalpy spend their time at K=128, N=4e6 (the general
 augmented path of the expectation family): wall clock per call and, under ``rocprofv3 --kernel-trace --stats``, the kernels.
 
-    python tools/profile_expectations.py [perturbed|entropy|expect3|all] [repeats]"""
+    python tools/profile_expectations.py [perturbed|entropy|expect3|expect1|all] [repeats]"""
 import os
 import sys
 import time
@@ -25,6 +25,7 @@ calls = {
     "perturbed": lambda: m.compute_perturbed_free_energies(u_new),
     "entropy": lambda: m.compute_entropy_and_enthalpy(),
     "expect3": lambda: m.compute_expectations(x_n, u_kn=u_new),
+    "expect1": lambda: m.compute_expectations(x_n),
 }
 for name, fn in calls.items():
     if what not in ("all", name):

@@ -1,6 +1,8 @@
 #!/bin/bash
 # The round-6 evidence set in one call on the GPU box (outputs under gpurun_out/r6final/, copied into profiles/ by hand):
 #   bench_line.json                       python bench.py (the driver's command)
+#   (the profiled runs leave out the scaling model and the one-device config 4, whose launches of the same kernels at other sizes
+#   would mix into the per-kernel means)
 #   bench_kernel_stats.csv + bench_line_same_run_as_kernel_stats.json + iteration_timeline.txt
 #                                         rocprofv3 --kernel-trace --stats of a shorter bench run, the line printed inside it, the
 #                                         kernels of one iteration in start order (tools/trace_timeline.py)
@@ -17,12 +19,12 @@ mkdir -p $OUT
 REPO=$(pwd)
 export TMPDIR=/tmp
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
-BENCH="python $REPO/bench.py --steps 10 --warmup 3 --cpu-sample 0 --api-e2e 0"
+BENCH="python $REPO/bench.py --steps 10 --warmup 3 --cpu-sample 0 --api-e2e 0 --scaling-model 0 --config4-one-device 0"
 ( cd /tmp && rm -rf /tmp/prof_s && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o ks -- $BENCH > $REPO/$OUT/bench_line_same_run_as_kernel_stats.json 2> $REPO/$OUT/rocprof_stats.err )
 find /tmp/prof_s -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
 TRACE=$(find /tmp/prof_s -name "*kernel_trace.csv" | head -1)
 [ -n "$TRACE" ] && python tools/trace_timeline.py "$TRACE" k_select > $OUT/iteration_timeline.txt 2>&1
-SHORT="python $REPO/bench.py --steps 3 --warmup 1 --cpu-sample 0 --api-e2e 0"
+SHORT="python $REPO/bench.py --steps 3 --warmup 1 --cpu-sample 0 --api-e2e 0 --scaling-model 0 --config4-one-device 0 --small-configs 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rm -rf /tmp/prof_$C && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o pm -- $SHORT > /dev/null 2> $REPO/$OUT/rocprof_$C.err )
 done
