@@ -129,6 +129,10 @@ int mbar_device_synchronize(int device);
  *                    256-state panels, one read each, + 128 x 256 rectangles (default); 1 = in the 128-state panels and 64 x 128
  *                    rectangles of the sweep on u; 0 = both sweeps on u (what runs when P does not fit)
  *   "rect_waves"     8 = the 128 x 256 rectangles of that Gram sweep run two waves per SIMD (default); 4 = one
+ *   "newton_ldlt"    up to 128 states: 1 = the K x K Newton solve of the device-resident loop (mbar_solvers.py:581-583) is a blocked
+ *                    LDL^T factorisation on the fp64 matrix cores, pivots from the last state upwards, two barriers per 16 pivots
+ *                    (default; k_select_newton 66 -> 37 us at 127 unknowns); 0 = the register Gauss-Jordan solve of rounds 2-5
+ *                    (also: environment variable MBAR_NEWTON_LDLT)
  *   "pcache"         1 = the resident probability matrix outlives the solve that built it: a later adaptive solve on the same
  *                    matrix whose start lies within 200 kT of its anchor (bootstrap replicates, protocol stages) starts with
  *                    one fused sweep instead of the build sweep (default); 0 = every solve builds (cold-solve timings)
