@@ -354,7 +354,7 @@ def test_full_panel_gram_with_and_without_the_exponential_clamp(DM):
 def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
     """The adaptive iteration in its four forms -- host-driven loop, device-resident loop with per-sweep exponentials,
     with the resident probability matrix (two sweeps), and with the fused sweep (speculated Gram matrix of the Newton
-    candidate) -- gives the same free energies, iteration counts and per-iteration gradient norms, also when the
+    candidate) -- and with either K x K Newton solve (blocked LDL^T on the matrix cores, register Gauss-Jordan) gives the same free energies, iteration counts and per-iteration gradient norms, also when the
     self-consistent candidate is forced for the first iterations (every speculation of those iterations is rejected),
     with per-sample multiplicities, with a damped Newton step, and for a fixed number of iterations past convergence."""
     u_kn, N_k, f = random_problem(K, N, seed=K + 1, unsampled=unsampled)
@@ -365,6 +365,9 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
              "fused eager": dict(device_loop=1, pmode=1, fused=1, graph=0),
              "fused graphs of 2": dict(device_loop=1, pmode=1, fused=1, adapt_batch=2),   # (every batch a replay, also the first)
              "fused, own Newton launch": dict(device_loop=1, pmode=1, fused=1, merge_select=0),
+             # the K x K Newton solve of rounds 2-5 (register Gauss-Jordan) instead of the blocked LDL^T on the matrix cores
+             "fused, Gauss-Jordan Newton solve": dict(device_loop=1, pmode=1, fused=1, newton_ldlt=0),
+             "classic, Gauss-Jordan, own Newton launch": dict(device_loop=1, pmode=0, fused=0, merge_select=0, newton_ldlt=0),
              # the last iteration without its Gram matrix whatever the size (default: from 1e8 matrix entries on)
              "fused, light last sweep": dict(device_loop=1, pmode=1, fused=1, light_last=2),
              "fused, light last sweep, eager": dict(device_loop=1, pmode=1, fused=1, light_last=2, graph=0, merge_select=0)}
@@ -385,7 +388,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                      dict(min_sc_iter=0, fixed=30)):  # (30: batches of 6, 2, 4, 8, 8, 2 -- the full ones replay the captured hipGraph)
             out = {}
             for name, opts in modes.items():
-                for k, v in {"graph": 1, "adapt_batch": 8, "merge_select": 1, "light_last": 0, **opts}.items():
+                for k, v in {"graph": 1, "adapt_batch": 8, "merge_select": 1, "light_last": 0, "newton_ldlt": 1, **opts}.items():
                     dm.set_option(k, v)
                 dm.set_sample_weights(c_n if case.get("weights") else None)
                 try:
@@ -417,7 +420,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
                 f_or, _ = oracle.solve_mbar_for_all_states(u_kn, N_k, np.zeros(K), sws, tol=tol, min_sc_iter=case["min_sc_iter"])
                 if case.get("gamma", 1.0) == 1.0:
                     np.testing.assert_allclose(out["fused"][0][sws], (f_or - f_or[sws[0]])[sws], rtol=1e-9, atol=1e-10)
-        for k, v in dict(device_loop=1, pmode=1, fused=1, graph=1, adapt_batch=8, merge_select=1, light_last=1).items():
+        for k, v in dict(device_loop=1, pmode=1, fused=1, graph=1, adapt_batch=8, merge_select=1, light_last=1, newton_ldlt=1).items():
             dm.set_option(k, v)
     if K == 128:  # (it does happen -- where the grids of the two sweeps are commensurate: the converging cases end on an iteration
         assert light_seen >= 2, light_seen  # both candidates pass)
