@@ -299,7 +299,9 @@ int mbar_gram_w(mbar_ctx* ctx, const double* f, double* gramW, double* wsum);
  *                            mbar_ctx_rows_logshift, handed back (observables that ARE resident rows: entropy / enthalpy);
  *   mbar_lognum_ext          log normalisers of the extension's rows at f_base (the base's log-denominators / multiplicities);
  *   mbar_gram_w_ext          W^T W of [base | ext] at (f_base, f_ext), (K_base + K_ext)^2 row-major, ONE one-read sweep of both
- *                            matrices (k_gram_quad_split); wsum as in mbar_gram_w (N_k = 0 for the extension's rows).
+ *                            matrices (k_gram_quad_split); wsum as in mbar_gram_w (N_k = 0 for the extension's rows).  gram_base
+ *                            (or NULL) = mbar_gram_w of the base at f_base, kept by the caller: with it and at most 16 appended
+ *                            rows only the new entries are computed (a 16 x 128 rectangle + a 16 x 16 block);
  * Evaluations and solves on an extension context fail with MBAR_ERR_STATE; destroy it before its base. */
 int mbar_ctx_create_ext(mbar_ctx** out, mbar_ctx* base, int64_t K_rows);
 int mbar_ctx_rows_sub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows, const double* v_host);
@@ -307,7 +309,8 @@ int mbar_ctx_rows_rsub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int6
 int mbar_ctx_rows_obs_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* base, int64_t state_row0, int64_t obs_row0, int64_t nrows,
                            double* shift_out);
 int mbar_lognum_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, double* lognum_ext);
-int mbar_gram_w_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, const double* f_ext, double* gramW, double* wsum);
+int mbar_gram_w_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, const double* f_ext, const double* gram_base, double* gramW,
+                    double* wsum);
 
 /* ---- solver loops (replace adaptive(), mbar_solvers.py:510-667) ---------------------------- */
 typedef struct mbar_solve_result {

@@ -1559,7 +1559,12 @@ int mbar_lognum_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, double*
 
 // W^T W of the weight columns of [base rows | extension rows] at (f_base, f_ext): ONE one-read sweep over the two matrices
 // (gramW: (K_base + K_ext)^2 row-major; wsum as in mbar_gram_w, with N_k = 0 for the extension's rows).
-int mbar_gram_w_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, const double* f_ext, double* gramW, double* wsum) {
+// gram_base (or NULL): W^T W of the base's own states at f_base (mbar_gram_w of the base: the caller keeps it across calls).  With
+// it, and at most 16 appended rows on a base of 128 padded states, only the new entries are computed: a 16 x 128 rectangle between
+// the appended block row and the resident panel + the 16 x 16 block of the appended rows (a fifth of the joint sweep's matrix
+// instructions; the sweep is then bound by HBM and the operands' exponentials).
+int mbar_gram_w_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, const double* f_ext, const double* gram_base, double* gramW,
+                    double* wsum) {
     int rc = ext_pair_ok(ext, base, "mbar_gram_w_ext");
     if (rc) return rc;
     if (!f_base || !f_ext || !gramW) return fail(ext, MBAR_ERR_ARG, "NULL argument");
@@ -1574,6 +1579,71 @@ int mbar_gram_w_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, const d
     if (base->u_poison || ext->u_poison || !finite) {
         std::fill(gramW, gramW + (size_t)Kt * Kt, std::numeric_limits<double>::quiet_NaN());
         if (wsum) std::fill(wsum, wsum + Kt, std::numeric_limits<double>::quiet_NaN());
+        return MBAR_OK;
+    }
+    const double* logden_thin = base->logden[0];
+    if (gram_base && Ke <= 16 && base->Kp == 128) {
+        if (base->weighted) {
+            HIPCHK(ext, launch_shift_logden(ext->stream, logden_thin, base->cw, 0.5, base->N, base->lden_eff));
+            logden_thin = base->lden_eff;
+        }
+        const double ninf = -std::numeric_limits<double>::infinity();
+        std::vector<double> an((size_t)128 + 16, ninf);  // [f_base padded to 128 | f_ext padded to 16]
+        for (int64_t k = 0; k < Kb; ++k) an[k] = f_base[k];
+        for (int64_t k = 0; k < Ke; ++k) an[(size_t)128 + k] = f_ext[k];
+        double* an_dev = ext->small;
+        HIPCHK(ext, hipMemcpyAsync(an_dev, an.data(), an.size() * sizeof(double), hipMemcpyHostToDevice, ext->stream));
+        const int64_t ntiles = (ext->N + TS - 1) / TS;
+        const int64_t row_e = (reinterpret_cast<intptr_t>(ext->u) - reinterpret_cast<intptr_t>(base->u)) / (intptr_t)((size_t)base->ld * sizeof(double));
+        rc = ensure_red(ext, (size_t)9 * 256);
+        if (rc) return rc;
+        {   // rectangle: I = the appended block row, J = the resident panel
+            LaunchGeom g = gram_geometry(144, false, ext->num_cu, ntiles, ext->opt_grid);
+            const size_t rec = (size_t)8 * 256;
+            rc = ensure(ext, &ext->part, &ext->part_doubles, (size_t)g.nwaves * rec);
+            if (rc) return rc;
+            rc = ensure(ext, &ext->scratch, &ext->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * rec);
+            if (rc) return rc;
+            {
+                ScopedTimer t(ext, MBAR_TIMER_GRAM);
+                HIPCHK(ext, launch_gram_thin(ext->stream, g, base->u, base->ld, base->N, an_dev + 128, an_dev, logden_thin, row_e, 0, ext->part));
+            }
+            ScopedTimer t(ext, MBAR_TIMER_REDUCE);
+            HIPCHK(ext, launch_reduce(ext->stream, ext->part, g.nwaves, (int64_t)rec, ext->scratch, ext->red));
+        }
+        {   // the appended rows among themselves
+            LaunchGeom g = gram_geometry(16, true, ext->num_cu, ntiles, ext->opt_grid);
+            const size_t rec = 256;
+            rc = ensure(ext, &ext->part, &ext->part_doubles, (size_t)g.nwaves * rec);
+            if (rc) return rc;
+            rc = ensure(ext, &ext->scratch, &ext->scratch_doubles, ((size_t)g.nwaves / 32 + 1) * rec);
+            if (rc) return rc;
+            {
+                ScopedTimer t(ext, MBAR_TIMER_GRAM);
+                LoopCtl lo;
+                HIPCHK(ext, launch_gram_diag(ext->stream, 1, g, ext->u, ext->ld, ext->N, an_dev + 128, logden_thin, 0, ext->part, nullptr, lo));
+            }
+            ScopedTimer t(ext, MBAR_TIMER_REDUCE);
+            HIPCHK(ext, launch_reduce(ext->stream, ext->part, g.nwaves, (int64_t)rec, ext->scratch, ext->red + 8 * 256));
+        }
+        HIPCHK(ext, hipMemcpyAsync(ext->hred, ext->red, (size_t)9 * 256 * sizeof(double), hipMemcpyDeviceToHost, ext->stream));
+        rc = sync_stream(ext);
+        if (rc) return rc;
+        for (int64_t i = 0; i < Kb; ++i)
+            for (int64_t j = 0; j < Kb; ++j) gramW[(size_t)i * Kt + j] = gram_base[(size_t)i * Kb + j];
+        for (int64_t r = 0; r < Ke; ++r) {
+            for (int64_t j = 0; j < Kb; ++j) {
+                const double v = ext->hred[(size_t)(j / 16) * 256 + r * 16 + (j % 16)];  // block (0, J): element (r, q)
+                gramW[(size_t)(Kb + r) * Kt + j] = v;
+                gramW[(size_t)j * Kt + Kb + r] = v;
+            }
+            for (int64_t q = 0; q < Ke; ++q) gramW[(size_t)(Kb + r) * Kt + Kb + q] = ext->hred[(size_t)8 * 256 + r * 16 + q];
+        }
+        if (wsum) {
+            std::vector<double> Nk((size_t)Kt, 0.0);
+            for (int64_t k = 0; k < Kb; ++k) Nk[k] = base->Nk[k];
+            gram_operand_sums(gramW, Kt, Nk.data(), wsum);
+        }
         return MBAR_OK;
     }
     const int nbt = (int)(rows / 16);

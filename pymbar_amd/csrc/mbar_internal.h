@@ -130,6 +130,8 @@ hipError_t launch_gram_diag(hipStream_t s, int nb, const LaunchGeom& g, const do
                             const double* logden, int64_t row0, double* gram_part, double* psum_part,
                             const LoopCtl& lc = LoopCtl());
 // (pmode: `u` is the resident probability matrix, `logden` the reciprocals 1 / s_n, the anum vectors are not read)
+hipError_t launch_gram_thin(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* ai,
+                            const double* aj, const double* logden, int64_t ri, int64_t rj, double* gp);
 hipError_t launch_gram_off(hipStream_t s, int nbj /*4 or 8*/, const LaunchGeom& g, const double* u, int64_t ld,
                            int64_t N, const double* anum_i, const double* anum_j, const double* logden,
                            int64_t row_i0, int64_t row_j0, double* gram_part, bool pmode = false);

@@ -282,4 +282,13 @@ hipError_t launch_gram_off(hipStream_t s, int nbj, const LaunchGeom& g, const do
     return launch_gram_t<4, 4, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
 }
 
+// 16 x 128 rectangle: ONE block row (the I panel: up to 16 states) against a full 128-state panel -- a few rows appended to a
+// resident matrix against its states (mbar_gram_w_ext with the resident states' own W^T W supplied by the caller).  Every wave
+// streams its own 144-row tiles; 8 blocks per k-step, so the sweep is bound by the operands' exponentials and by HBM, not by the
+// matrix pipe.
+hipError_t launch_gram_thin(hipStream_t s, const LaunchGeom& g, const double* u, int64_t ld, int64_t N, const double* ai,
+                            const double* aj, const double* logden, int64_t ri, int64_t rj, double* gp) {
+    return launch_gram_t<1, 8, false, true>(s, g, u, ld, N, ai, aj, logden, ri, rj, gp, nullptr);
+}
+
 }  // namespace mbar

@@ -554,7 +554,10 @@ class ExtendedMatrix:
         fb, fe = np.ascontiguousarray(f[:self.Kb]), np.ascontiguousarray(f[self.Kb:])
         G = np.empty((self.K, self.K), dtype=np.float64)
         ws = np.empty(self.K, dtype=np.float64)
-        self._check(self._lib.mbar_gram_w_ext(self._ctx, self.base._ctx, _dptr(fb), _dptr(fe), _dptr(G), _dptr(ws)))
+        # (a few appended rows: only their entries are swept for, the resident states' own W^T W is the one the class keeps)
+        Gb = np.ascontiguousarray(self.base.gram_w_cached(fb)[0]) if self.K - self.Kb <= 16 else None
+        self._check(self._lib.mbar_gram_w_ext(self._ctx, self.base._ctx, _dptr(fb), _dptr(fe), None if Gb is None else _dptr(Gb),
+                                              _dptr(G), _dptr(ws)))
         return G, ws
 
 
