@@ -824,23 +824,30 @@ int adaptive_device_loop(mbar_ctx* c, std::vector<double>& f, double tol, int64_
     int32_t gram_sweeps = 0;
     while (it < maxiter && !done) {
         static const int64_t first_batches[3] = {6, 2, 4};
-        const int64_t want = std::min(ramp, nbatch < 3 ? std::min(batch, first_batches[nbatch]) : batch);
+        // (a fixed number of iterations -- no convergence test -- has nothing to look for early: full batches from the start, and up
+        // to four of them between two looks at the control words; a pause or a hand-back turns the rest into no-op launches as ever)
+        const bool fixed_count = !check_convergence;
+        const int64_t want = std::min(ramp, (nbatch < 3 && !fixed_count) ? std::min(batch, first_batches[nbatch]) : batch);
         ++nbatch;
         ramp = std::min(batch, ramp * 2);
-        int64_t nbat = std::min(want, maxiter - it);
-        if (use_graph && nbat == batch) {
-            rc = prepare_graph();
-            if (rc) return rc;
-            if (merged && need_newton) {  // (start of the solve / after a pause: the replayed iterations have no solve of their own)
-                HIPCHK(c, launch_newton(c->stream, q));
-                need_newton = false;
-            }
-            HIPCHK(c, hipGraphLaunch(c->ad_graph, c->stream));
-        } else {
-            for (int64_t b = 0; b < nbat; ++b) {
-                rc = enqueue_iteration(c->opt_timing != 0);
+        int64_t nbat = 0;
+        for (int rep = 0; rep < (fixed_count && ramp == batch ? 4 : 1) && it + nbat < maxiter; ++rep) {
+            const int64_t nb1 = std::min(want, maxiter - it - nbat);
+            if (use_graph && nb1 == batch) {
+                rc = prepare_graph();
                 if (rc) return rc;
+                if (merged && need_newton) {  // (start of the solve / after a pause: the replayed iterations have no solve of their own)
+                    HIPCHK(c, launch_newton(c->stream, q));
+                    need_newton = false;
+                }
+                HIPCHK(c, hipGraphLaunch(c->ad_graph, c->stream));
+            } else {
+                for (int64_t b = 0; b < nb1; ++b) {
+                    rc = enqueue_iteration(c->opt_timing != 0);
+                    if (rc) return rc;
+                }
             }
+            nbat += nb1;
         }
         HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ad_ints, CTL_WORDS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         rc = sync_stream(c);

@@ -385,7 +385,7 @@ def test_adaptive_loop_variants_agree(DM, K, N, unsampled):
         dm.set_Nk(N_k)
         for case in (dict(min_sc_iter=0), dict(min_sc_iter=3), dict(min_sc_iter=0, gamma=0.5), dict(min_sc_iter=0, weights=True),
                      dict(min_sc_iter=0, fixed=12),
-                     dict(min_sc_iter=0, fixed=30)):  # (30: batches of 6, 2, 4, 8, 8, 2 -- the full ones replay the captured hipGraph)
+                     dict(min_sc_iter=0, fixed=30)):  # (30: batches of 8, 8, 8, 6 between two looks at the control words -- the full ones replay the captured hipGraph)
             out = {}
             for name, opts in modes.items():
                 for k, v in {"graph": 1, "adapt_batch": 8, "merge_select": 1, "light_last": 0, "newton_ldlt": 1, **opts}.items():
