@@ -117,9 +117,20 @@ def check_case(DM, case):
         # problem; accepted iff the oracle's own gradient at OUR f is at its round-off level too.
         disconnected = (ra["success"] and not ro["success"] and np.abs(g_dev).max() <= 1e-8 * scale
                         and np.abs(g_or).max() <= 1e-8 * scale)
-        assert ra["success"] == ro["success"] or noise_floor or disconnected, (ra, ro["iterations"])
+        # ... and its mirror image (cases 17453 / 17455: two sampled states with ONE sample each, no overlap in fp64).  The 1 x 1
+        # Newton system is h x = g with h and g both a few ulps: noise over noise, in the reference (lstsq keeps the largest singular
+        # value whatever its size, mbar_solvers.py:582) as here.  Where that quotient happens to be 0 the stop test passes (the
+        # oracle's arithmetic: 11 / 15 iterations); where it is O(1) the self-consistent candidate wins every choice, f stops
+        # changing at once (max_delta = 0 exactly) and `max_diff < sqrt(tol)` (:636) is never met -- with either Newton solve of this
+        # library, whichever bits the exponentials leave.  Any f solves such a problem: accepted iff f has stopped moving and the
+        # oracle's gradient at OUR f is at its round-off level.
+        noise_newton = (ro["success"] and not ra["success"] and ra["max_delta"] == 0.0 and np.abs(g_dev).max() <= 1e-8 * scale
+                        and np.abs(g_or).max() <= 1e-8 * scale)
+        assert ra["success"] == ro["success"] or noise_floor or disconnected or noise_newton, (ra, ro["iterations"])
         if disconnected:
             return f"{ra['iterations']} iterations; states without overlap in fp64: the reference does not converge ({ro['iterations']})"
+        if noise_newton:
+            return f"f stationary; states without overlap in fp64: the Newton candidate is noise over noise, the stop test never met ({ro['iterations']})"
         assert np.abs(g_dev).max() <= 10.0 * np.abs(g_or).max() + 1e-8 * scale, (np.abs(g_dev).max(), np.abs(g_or).max())
         if ra.get("psum") is not None:
             # (mbar_gradient = psum - N_k; non-zero where the reference's loop itself runs out of iterations -- case 4089)
