@@ -296,7 +296,9 @@ int mbar_gram_w(mbar_ctx* ctx, const double* f, double* gramW, double* wsum);
  *   mbar_ctx_rows_sub_from   dst rows = src rows - v  (src = dst or its base; v as in mbar_ctx_rows_sub);
  *   mbar_ctx_rows_rsub_from  dst rows = src rows - dst rows;
  *   mbar_ctx_rows_obs_from   dst rows = base rows[state_row0 ..) - log(base rows[obs_row0 ..) - shift_r), shift_r as in
- *                            mbar_ctx_rows_logshift, handed back (observables that ARE resident rows: entropy / enthalpy);
+ *                            mbar_ctx_rows_logshift, handed back (observables that ARE resident rows: entropy / enthalpy); min_out /
+ *                            min_in (or NULL): the rows' minima out of one call and into the next on the same resident rows, which
+ *                            then skips the pass that finds them;
  *   mbar_lognum_ext          log normalisers of the extension's rows at f_base (the base's log-denominators / multiplicities);
  *   mbar_gram_w_ext          W^T W of [base | ext] at (f_base, f_ext), (K_base + K_ext)^2 row-major, ONE one-read sweep of both
  *                            matrices (k_gram_quad_split); wsum as in mbar_gram_w (N_k = 0 for the extension's rows).  gram_base
@@ -307,7 +309,7 @@ int mbar_ctx_create_ext(mbar_ctx** out, mbar_ctx* base, int64_t K_rows);
 int mbar_ctx_rows_sub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows, const double* v_host);
 int mbar_ctx_rows_rsub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int64_t src_row0, int64_t nrows);
 int mbar_ctx_rows_obs_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* base, int64_t state_row0, int64_t obs_row0, int64_t nrows,
-                           double* shift_out);
+                           double* shift_out, const double* min_in, double* min_out);
 int mbar_lognum_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, double* lognum_ext);
 int mbar_gram_w_ext(mbar_ctx* ext, mbar_ctx* base, const double* f_base, const double* f_ext, const double* gram_base, double* gramW,
                     double* wsum);

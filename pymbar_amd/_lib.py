@@ -100,7 +100,7 @@ SIGNATURES = {
     "mbar_ctx_create_ext": (C.c_int, [C.POINTER(_ctx), _ctx, C.c_int64]),
     "mbar_ctx_rows_sub_from": (C.c_int, [_ctx, C.c_int64, _ctx, C.c_int64, C.c_int64, _dp]),
     "mbar_ctx_rows_rsub_from": (C.c_int, [_ctx, C.c_int64, _ctx, C.c_int64, C.c_int64]),
-    "mbar_ctx_rows_obs_from": (C.c_int, [_ctx, C.c_int64, _ctx, C.c_int64, C.c_int64, C.c_int64, _dp]),
+    "mbar_ctx_rows_obs_from": (C.c_int, [_ctx, C.c_int64, _ctx, C.c_int64, C.c_int64, C.c_int64, _dp, _dp, _dp]),
     "mbar_lognum_ext": (C.c_int, [_ctx, _ctx, _dp, _dp]),
     "mbar_gram_w_ext": (C.c_int, [_ctx, _ctx, _dp, _dp, _dp, _dp, _dp]),
     "mbar_solve_adaptive": (C.c_int, [_ctx, _dp, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_int,

@@ -1494,8 +1494,10 @@ int mbar_ctx_rows_rsub_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* src, int6
 // dst rows = base rows [state_row0 ..) - log(base rows [obs_row0 ..) - shift_r), shift_r = min_r - |4 eps min_r| (mbar.py:827-832)
 // handed back: observables that ARE rows of the resident matrix (entropy / enthalpy: the reduced potentials), each at its own
 // state, in one read of the rows concerned -- no copy of them, no pass in place
+// min_in (or NULL): the minima of the observable rows, as min_out of an earlier call on the same resident rows handed them back --
+// the pass that finds them is skipped then; min_out (or NULL) receives them.
 int mbar_ctx_rows_obs_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* base, int64_t state_row0, int64_t obs_row0, int64_t nrows,
-                           double* shift_out) {
+                           double* shift_out, const double* min_in, double* min_out) {
     int rc = ext_pair_ok(dst, base, "mbar_ctx_rows_obs_from");
     if (rc) return rc;
     if (!shift_out) return fail(dst, MBAR_ERR_ARG, "NULL argument");
@@ -1508,11 +1510,30 @@ int mbar_ctx_rows_obs_from(mbar_ctx* dst, int64_t dst_row0, mbar_ctx* base, int6
     rc = ensure(dst, &dst->scratch, &dst->scratch_doubles, (size_t)nrows * 257);
     if (rc) return rc;
     double* shift_dev = dst->scratch + (size_t)nrows * 256;
+    if (min_in) HIPCHK(dst, hipMemcpyAsync(dst->scratch, min_in, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice, dst->stream));
     HIPCHK(dst, launch_rows_obs(dst->stream, dst->u + dst_row0 * dst->ld, base->u + obs_row0 * base->ld, base->u + state_row0 * base->ld,
-                                dst->ld, nrows, dst->N, dst->scratch, shift_dev));
+                                dst->ld, nrows, dst->N, dst->scratch, shift_dev, min_in != nullptr));
     HIPCHK(dst, hipMemcpyAsync(shift_out, shift_dev, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, dst->stream));
     ext_touched(dst);
-    return sync_stream(dst);
+    rc = sync_stream(dst);
+    if (rc) return rc;
+    if (min_out) {  // shift = m - |4 eps m|  <=>  m = shift / (1 -+ 4 eps): the minimum itself is what the kernel reduces, so hand back ITS bits
+        if (min_in) {
+            std::copy(min_in, min_in + nrows, min_out);
+        } else {
+            // (the partial minima are still in the scratch rows: reduce them on the host, the same fmin)
+            const int64_t want = (dst->N + 2047) / 2048;
+            const int64_t gx = want < 256 ? (want < 1 ? 1 : want) : 256;
+            std::vector<double> part((size_t)nrows * gx);
+            HIPCHK(dst, hipMemcpy(part.data(), dst->scratch, part.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int64_t r = 0; r < nrows; ++r) {
+                double m = std::numeric_limits<double>::infinity();
+                for (int64_t i = 0; i < gx; ++i) m = std::fmin(m, part[(size_t)r * gx + i]);
+                min_out[r] = m;
+            }
+        }
+    }
+    return MBAR_OK;
 }
 
 // Log normalisers of the extension's rows as unsampled states of the base's mixture at f_base (K_base entries):

@@ -117,7 +117,7 @@ LaunchGeom gram_geometry(int tile_rows, bool diag, int num_cu, int64_t ntiles, i
 hipError_t launch_row_sub(hipStream_t s, double* row, const double* v, int64_t n);  // row[i] -= v[i]
 hipError_t launch_rows_sub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, const double* v, int64_t n);
 hipError_t launch_rows_obs(hipStream_t s, double* dst, const double* obs, const double* state, int64_t ld, int64_t nrows, int64_t n,
-                           double* part, double* shift_out);
+                           double* part, double* shift_out, bool have_min = false);
 hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n);
 // rows r < nrows of base (pitch ld, n valid entries): row <- log(row - shift_r), shift_r = min_r - |4 eps min_r| -> shift_out[r]
 // (device); part: scratch of 256 * nrows doubles

@@ -1616,13 +1616,16 @@ __global__ void __launch_bounds__(256) k_rows_obs(double* __restrict__ dst, cons
         __syncthreads();
     }
 }
+// have_min: part[r] already holds the minimum of observable row r (one entry per row: the caller kept it from an earlier call on
+// the same resident rows) -- the pass over the rows that finds it is skipped
 hipError_t launch_rows_obs(hipStream_t s, double* dst, const double* obs, const double* state, int64_t ld, int64_t nrows, int64_t n,
-                           double* part, double* shift_out) {
+                           double* part, double* shift_out, bool have_min) {
     const int64_t want = (n + 2047) / 2048;
     const unsigned gx = (unsigned)(want < 256 ? (want < 1 ? 1 : want) : 256);
     const unsigned gy = (unsigned)(nrows < 1024 ? (nrows < 1 ? 1 : nrows) : 1024);
-    hipLaunchKernelGGL(k_rows_min_partial, dim3(gx, gy), dim3(256), 0, s, obs, ld, nrows, n, part);
-    hipLaunchKernelGGL(k_rows_obs, dim3(gx, gy), dim3(256), 0, s, dst, obs, state, ld, nrows, n, (const double*)part, (int)gx, shift_out);
+    if (!have_min) hipLaunchKernelGGL(k_rows_min_partial, dim3(gx, gy), dim3(256), 0, s, obs, ld, nrows, n, part);
+    hipLaunchKernelGGL(k_rows_obs, dim3(gx, gy), dim3(256), 0, s, dst, obs, state, ld, nrows, n, (const double*)part, have_min ? 1 : (int)gx,
+                       shift_out);
     return hipGetLastError();
 }
 hipError_t launch_rows_rsub(hipStream_t s, double* dst, const double* src, int64_t ld, int64_t nrows, int64_t n) {

@@ -516,8 +516,16 @@ class ExtendedMatrix:
     def rows_obs_from_base(self, dst_row0, state_row0, obs_row0, nrows):
         """Appended rows ``dst`` = resident rows ``state`` - log(resident rows ``obs`` - shift); ``shift`` per row is returned."""
         shift = np.empty(int(nrows), dtype=np.float64)
+        # (the minima of resident rows are a property of the resident matrix: kept on it, keyed by its version and the row run)
+        key = (self.base._version, int(obs_row0), int(nrows))
+        cache = getattr(self.base, "_rowmin_cache", None)
+        mins = cache[1] if cache is not None and cache[0] == key else None
+        out = np.empty(int(nrows), dtype=np.float64) if mins is None else None
         self._check(self._lib.mbar_ctx_rows_obs_from(self._ctx, self._ext_row(dst_row0, nrows), self.base._ctx, int(state_row0),
-                                                     int(obs_row0), int(nrows), _dptr(shift)))
+                                                     int(obs_row0), int(nrows), _dptr(shift), None if mins is None else _dptr(mins),
+                                                     None if out is None else _dptr(out)))
+        if mins is None:
+            self.base._rowmin_cache = (key, out)
         return shift
 
     def rows_logshift(self, row0, nrows):
